@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Case:
+    """Attribute view over the '<case>.<field>' keys of one golden npz."""
+
+    def __init__(self, npz, prefix):
+        self._d = {k[len(prefix) + 1:]: npz[k] for k in npz.files if k.startswith(prefix + ".")}
+
+    def __getattr__(self, k):
+        try:
+            return self._d[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def keys(self):
+        return self._d.keys()
+
+    def sub(self, prefix):
+        return {k[len(prefix) + 1:]: v for k, v in self._d.items() if k.startswith(prefix + ".")}
+
+
+def load_cases(fname):
+    z = np.load(os.path.join(GOLDEN, fname))
+    names = sorted({k.split(".")[0] for k in z.files})
+    return z, names
+
+
+@pytest.fixture(scope="session")
+def golden2d():
+    return load_cases("spectral2d.npz")[0]
+
+
+@pytest.fixture(scope="session")
+def golden3d():
+    return load_cases("spectral3d.npz")[0]
+
+
+@pytest.fixture(scope="session")
+def golden_blocks():
+    return load_cases("blocks.npz")[0]
+
+
+@pytest.fixture(scope="session")
+def golden_harness():
+    return load_cases("harness.npz")[0]
+
+
+def rel_err(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    d = np.linalg.norm((a - b).ravel())
+    n = np.linalg.norm(b.ravel())
+    return d / n if n > 0 else d
