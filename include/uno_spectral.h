@@ -1,0 +1,86 @@
+/* uno_spectral.h - C ABI of the MI355X-native U-NO spectral-convolution hot path.
+ *
+ * Drop-in boundary for the path BASELINE.json's north_star names: the reference
+ * (ashiq24/UNO) has no FFI - the path is Python calling torch ops - so each entry point
+ * below replaces one span of reference Python; the binding a maintainer adds is the
+ * ctypes stub shown in INTEGRATION.md (uno_amd/_native.py is that stub, in-tree).
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory of the current HIP device, borrowed for the call;
+ *  - float tensors are contiguous float32; complex tensors are interleaved (re, im)
+ *    float32 pairs (torch.complex64 / view_as_real layout), passed as float*;
+ *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work;
+ *  - return 0 on success, <0 on error (uno_last_error() gives the message; nothing was
+ *    enqueued for argument errors).  Error classes mirror what the reference surfaces as
+ *    torch RuntimeError: shape/mode incompatibilities.
+ *  - truncated-spectrum layout: (batch, channels, corner-rows = 2*modes1, modes2) for 2-D
+ *    with the "lo" corner rows first (rows [:modes1] of rfft2) then the "hi" corner rows
+ *    (rows [-modes1:]).
+ *  - no state is retained between calls except immutable per-(device, N) twiddle tables.
+ */
+#ifndef UNO_SPECTRAL_H
+#define UNO_SPECTRAL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNO_SPECTRAL_ABI_VERSION 1
+
+/* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
+int uno_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* uno_last_error(void);
+
+/* Bytes of scratch `ws` the 2-D forward / backward entry points need. */
+long long uno_spectral_conv2d_fwd_ws_bytes(int B, int Ci, int Co, int m1, int m2);
+long long uno_spectral_conv2d_bwd_ws_bytes(int B, int Ci, int Co, int m1, int m2);
+
+/* SpectralConv2d_Uno.forward - reference integral_operators.py:181-207
+ *   x  (B, Ci, H, W) f32;  w1, w2 (Ci, Co, m1, m2) c64;  y (B, Co, Ho, Wo) f32 [out]
+ *   xtrunc (B, Ci, 2*m1, m2) c64 [out] - the truncated rfft2(x, norm="forward"), the only
+ *   tensor backward needs besides the weights.  ws: scratch of ..._fwd_ws_bytes. */
+int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y,
+                                float* xtrunc, void* ws, int B, int Ci, int Co, int H, int W,
+                                int Ho, int Wo, int m1, int m2, void* stream);
+
+/* Autograd adjoint of the above (PyTorch's FftC2R/Bmm/CopySlices/FftR2C backward chain,
+ * SURVEY.md section 3.3 / Appendix A.2).  Complex gradients follow PyTorch's convention
+ * dL/dRe + i dL/dIm.  gx / (gw1, gw2) may be NULL to skip that gradient.
+ *   gy (B, Co, Ho, Wo) f32;  xtrunc as saved by forward;  gx (B, Ci, H, W) f32 [out]
+ *   gw1, gw2 (Ci, Co, m1, m2) c64 [out] */
+int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1,
+                                 const float* w2, float* gx, float* gw1, float* gw2, void* ws,
+                                 int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1,
+                                 int m2, void* stream);
+
+/* Stage-level entry points (the three kernels the two calls above are built from). */
+
+/* Pruned forward DFT: spec[img][j][l] = scale * c_l * keep_j * sum x e^{-2 pi i (K_j h/H + l w/W)}
+ *   images (n_img, H, W) f32 -> spec (n_img, 2*m1, m2) c64.
+ *   hermitian_cols: multiply column l by 1 (l = 0, Nyquist) or 2 - used for gO in backward.
+ *   mask_overlap:   zero lo-corner rows j >= H - m1 (later slice-assignment wins). */
+int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W, int m1, int m2,
+                      float scale, int hermitian_cols, int mask_overlap, void* stream);
+
+/* Pruned inverse DFT: images[h][w] = Re sum_{j,l} scale * c_l * keep_j * spec[j][l] e^{+2 pi i (...)}. */
+int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2,
+                      float scale, int hermitian_cols, int mask_overlap, void* stream);
+
+/* Per-mode channel mixing on the truncated spectrum, `ncorner` weight tensors of
+ * `modes_per_corner` modes each (2-D: ncorner = 2, modes_per_corner = m1*m2).
+ *   op 0: out[b,o] = sum_i in[b,i] * w[i,o]        (einsum "bixy,ioxy->boxy", :178-179)
+ *   op 1: out[b,i] = sum_o in[b,o] * conj(w[i,o])  (grad wrt the input spectrum)
+ *   in (B, Cin, ncorner*modes) c64, w[c] (Ci, Co, modes) c64, out (B, Cout, ncorner*modes) c64 */
+int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co,
+                 int ncorner, int modes_per_corner, void* stream);
+
+/* gw[c][i,o] = sum_b conj(xtrunc[b,i]) * go[b,o] per mode. */
+int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co,
+                   int ncorner, int modes_per_corner, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNO_SPECTRAL_H */

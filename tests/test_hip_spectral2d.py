@@ -1,0 +1,242 @@
+"""Parity of the HIP spectral-convolution path (through the C ABI) against the oracle and the
+reference-generated golden vectors.  Needs a real MI355X:  pytest -m gpu
+
+Tolerances (float32 path; stated as relative L2 error  ||a-b|| / ||b||):
+  TOL      = 2e-5   full operator and every stage vs the float64 dense oracle / golden vectors.
+             The HIP path accumulates direct DFT sums of length <= ~1100 in exact-f32 MFMA, the
+             reference uses float32 FFTs; both sit at a few 1e-7..1e-6 of the float64 result.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Case, load_cases, rel_err
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+Z2, NAMES2 = load_cases("spectral2d.npz")
+CASES2 = [n for n in NAMES2 if n not in ("fp64_in",)]
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+# ------------------------------------------------------------------ stage level: pruned DFTs
+DFT_SHAPES = [
+    # n_img, H, W, m1, m2
+    (3, 16, 16, 4, 5), (2, 21, 18, 4, 5), (2, 23, 23, 11, 12), (1, 40, 44, 17, 20), (2, 85, 85, 12, 12),
+    (1, 90, 90, 18, 18), (2, 111, 111, 8, 8), (1, 223, 223, 8, 8), (1, 64, 66, 32, 33), (2, 10, 14, 7, 5),
+    (1, 7, 130, 3, 40), (1, 130, 6, 40, 4), (1, 1, 2, 1, 2), (1, 421, 421, 20, 20),
+]
+
+
+@pytest.mark.parametrize("shape", DFT_SHAPES)
+@pytest.mark.parametrize("flags", [(False, False), (True, True)])
+def test_dft2d_forward_stage(shape, flags):
+    from uno_amd import _native
+    n, H, W, m1, m2 = shape
+    herm, mask = flags
+    rng = np.random.default_rng(1000 + H * 7 + W)
+    x = rng.standard_normal((n, 1, H, W)).astype(np.float32)
+    got = _native.dft2d_forward(cu(x), m1, m2, scale=0.5, hermitian_cols=herm, mask_overlap=mask).cpu().numpy()
+    ref = so.truncated_rfft2_dense(x, m1, m2) * (H * W) * 0.5
+    if herm:
+        ref = ref * so.hermitian_weights(W, m2)[None, None, None, :]
+    if mask:
+        ref = ref * so.later_wins_mask(H, m1)[None, None, :, None]
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < TOL
+    if mask:
+        dead = so.later_wins_mask(H, m1) == 0
+        assert np.all(got[:, :, dead, :] == 0)
+
+
+@pytest.mark.parametrize("shape", DFT_SHAPES)
+@pytest.mark.parametrize("flags", [(False, False), (True, True)])
+def test_dft2d_inverse_stage(shape, flags):
+    from uno_amd import _native
+    n, H, W, m1, m2 = shape
+    herm, mask = flags
+    rng = np.random.default_rng(2000 + H * 7 + W)
+    O = (rng.standard_normal((n, 1, 2 * m1, m2)) + 1j * rng.standard_normal((n, 1, 2 * m1, m2))).astype(np.complex64)
+    got = _native.dft2d_inverse(cu(O), H, W, scale=0.25, hermitian_cols=herm, mask_overlap=mask).cpu().numpy()
+    Gh = so._dft(so.corner_rows(H, m1), H, +1.0)
+    Gw = so._dft(np.arange(m2), W, +1.0)
+    keep = so.later_wins_mask(H, m1) if mask else np.ones(2 * m1)
+    c = so.hermitian_weights(W, m2) if herm else np.ones(m2)
+    U = np.einsum("bojl,jh->bohl", O.astype(np.complex128) * keep[None, None, :, None], Gh)
+    ref = 0.25 * np.einsum("bohl,lw->bohw", U * c, Gw).real
+    assert rel_err(got, ref) < TOL
+
+
+# ------------------------------------------------------------------ stage level: per-mode GEMMs
+MIX_SHAPES = [
+    # B, Ci, Co, ncorner, modes-per-corner shape
+    (2, 3, 4, 2, (4, 5)), (16, 64, 64, 2, (20, 20)), (8, 32, 32, 2, (12, 12)), (5, 7, 9, 2, (3, 11)),
+    (17, 20, 33, 2, (2, 9)), (1, 1, 1, 2, (1, 1)), (4, 6, 5, 4, (3, 3, 2)), (3, 48, 24, 2, (18, 18)),
+]
+
+
+@pytest.mark.parametrize("shape", MIX_SHAPES)
+def test_mode_gemms(shape):
+    from uno_amd import _native
+    B, Ci, Co, nc, mshape = shape
+    rng = np.random.default_rng(3000 + B + Ci * 3 + Co * 5)
+    cplx = lambda *s: (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
+    X = cplx(B, Ci, nc, *mshape)
+    gO = cplx(B, Co, nc, *mshape)
+    ws = [cplx(Ci, Co, *mshape) for _ in range(nc)]
+    wd = [cu(w) for w in ws]
+    O = _native.mode_mix(cu(X), wd, 0).cpu().numpy()
+    gX = _native.mode_mix(cu(gO), wd, 1).cpu().numpy()
+    gW = [g.cpu().numpy() for g in _native.mode_wgrad(cu(X), cu(gO), ws[0].shape, nc)]
+    X64, gO64 = X.astype(np.complex128), gO.astype(np.complex128)
+    for c in range(nc):
+        w64 = ws[c].astype(np.complex128)
+        assert rel_err(O[:, :, c], np.einsum("bi...,io...->bo...", X64[:, :, c], w64)) < TOL
+        assert rel_err(gX[:, :, c], np.einsum("bo...,io...->bi...", gO64[:, :, c], np.conj(w64))) < TOL
+        assert rel_err(gW[c], np.einsum("bi...,bo...->io...", np.conj(X64[:, :, c]), gO64[:, :, c])) < TOL
+
+
+# ------------------------------------------------------------------ full operator vs golden vectors
+@pytest.mark.parametrize("name", CASES2)
+def test_golden_forward_backward(name):
+    from uno_amd.integral_operators import spectral_conv2d
+    c = Case(Z2, name)
+    B, Ci, Co, H, W, Ho, Wo, m1, m2 = [int(v) for v in c.meta]
+    x = cu(c.x).requires_grad_(True)
+    w1 = cu(c.w1).requires_grad_(True)
+    w2 = cu(c.w2).requires_grad_(True)
+    y = spectral_conv2d(x, w1, w2, Ho, Wo)
+    assert y.dtype == torch.float32 and tuple(y.shape) == c.y.shape
+    assert rel_err(y.detach().cpu().numpy(), c.y) < TOL
+    y.backward(cu(c.gy))
+    assert rel_err(x.grad.cpu().numpy(), c.gx) < TOL
+    assert rel_err(w1.grad.cpu().numpy(), c.gw1) < TOL
+    assert rel_err(w2.grad.cpu().numpy(), c.gw2) < TOL
+    # later-wins: weights1 rows overwritten by weights2's corner receive exactly zero gradient
+    zero_ref = c.gw1 == 0
+    if zero_ref.any():
+        assert np.all(w1.grad.cpu().numpy()[zero_ref] == 0)
+
+
+def test_noncontiguous_input_matches():
+    from uno_amd.integral_operators import spectral_conv2d
+    c = Case(Z2, "noncontig")
+    B, Ci, Co, H, W, Ho, Wo, m1, m2 = [int(v) for v in c.meta]
+    xt = cu(np.ascontiguousarray(np.swapaxes(c.x, -1, -2))).transpose(-1, -2)
+    assert not xt.is_contiguous()
+    y = spectral_conv2d(xt, cu(c.w1), cu(c.w2), Ho, Wo)
+    assert rel_err(y.cpu().numpy(), c.y) < TOL
+
+
+# ------------------------------------------------------------------ seeded cases vs the dense oracle
+SEEDED = [
+    # B, Ci, Co, H, W, Ho, Wo, m1, m2
+    (8, 32, 32, 85, 85, 85, 85, 12, 12),        # BASELINE config 1 block
+    (2, 8, 16, 90, 90, 45, 45, 18, 18),         # UNO_9.conv0 geometry
+    (2, 16, 8, 45, 45, 90, 90, 18, 18),         # UNO_9.conv5 geometry
+    (2, 4, 4, 64, 64, 64, 64, 32, 33),          # Nyquist column + full rows
+    (3, 5, 3, 37, 50, 29, 31, 9, 13),
+]
+
+
+@pytest.mark.parametrize("cfg", SEEDED)
+def test_seeded_vs_dense_oracle(cfg):
+    from uno_amd.integral_operators import spectral_conv2d
+    B, Ci, Co, H, W, Ho, Wo, m1, m2 = cfg
+    rng = np.random.default_rng(sum(cfg))
+    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    sc = (1 / (2 * Ci)) ** 0.5
+    w1 = (sc * (rng.standard_normal((Ci, Co, m1, m2)) + 1j * rng.standard_normal((Ci, Co, m1, m2)))).astype(np.complex64)
+    w2 = (sc * (rng.standard_normal((Ci, Co, m1, m2)) + 1j * rng.standard_normal((Ci, Co, m1, m2)))).astype(np.complex64)
+    gy = rng.standard_normal((B, Co, Ho, Wo)).astype(np.float32)
+    y_ref, X = so.spectral_conv2d_dense(x, w1, w2, Ho, Wo)
+    gx_ref, gw1_ref, gw2_ref, _, _ = so.spectral_conv2d_dense_bwd(gy, X, w1, w2, H, W)
+    xd, w1d, w2d = cu(x).requires_grad_(True), cu(w1).requires_grad_(True), cu(w2).requires_grad_(True)
+    y = spectral_conv2d(xd, w1d, w2d, Ho, Wo)
+    y.backward(cu(gy))
+    assert rel_err(y.detach().cpu().numpy(), y_ref) < TOL
+    assert rel_err(xd.grad.cpu().numpy(), gx_ref) < TOL
+    assert rel_err(w1d.grad.cpu().numpy(), gw1_ref) < TOL
+    assert rel_err(w2d.grad.cpu().numpy(), gw2_ref) < TOL
+
+
+# ------------------------------------------------------------------ BASELINE config 2 at full size
+def test_full_size_421_vs_fft_oracle_and_properties():
+    """Darcy 421x421, 64 ch, modes 20, batch 16 (BASELINE.json configs[1], block level): direct
+    comparison with the FFT-sequence oracle on the host plus size-independent properties
+    (linearity, adjoint identity <A x, g> = <x, A^T g>, determinism)."""
+    from uno_amd.integral_operators import spectral_conv2d
+    B, C, S, m = 16, 64, 421, 20
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, C, S, S, generator=g)
+    sc = (1 / (2 * C)) ** 0.5
+    w1 = sc * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)
+    w2 = sc * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)
+    gy = torch.randn(B, C, S, S, generator=g)
+
+    xr, w1r, w2r = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    y_ref = so.spectral_conv2d_fft(xr, w1r, w2r, S, S)
+    y_ref.backward(gy)
+
+    xd, w1d, w2d = x.to(dev()).requires_grad_(True), w1.to(dev()).requires_grad_(True), w2.to(dev()).requires_grad_(True)
+    y = spectral_conv2d(xd, w1d, w2d, S, S)
+    y.backward(gy.to(dev()))
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < TOL
+    assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < TOL
+    assert rel_err(w1d.grad.cpu().numpy(), w1r.grad.numpy()) < TOL
+    assert rel_err(w2d.grad.cpu().numpy(), w2r.grad.numpy()) < TOL
+
+    with torch.no_grad():
+        # determinism: identical bits on a second run
+        y2 = spectral_conv2d(xd, w1d, w2d, S, S)
+        assert torch.equal(y2, y.detach())
+        # linearity in x
+        x2 = torch.randn(B, C, S, S, generator=g).to(dev())
+        lhs = spectral_conv2d(2.0 * xd - 3.0 * x2, w1d, w2d, S, S)
+        rhs = 2.0 * y.detach() - 3.0 * spectral_conv2d(x2, w1d, w2d, S, S)
+        assert rel_err(lhs.cpu().numpy(), rhs.cpu().numpy()) < TOL
+        # adjoint identity in float64 accumulation
+        a = torch.dot(y.detach().double().flatten(), gy.to(dev()).double().flatten())
+        b = torch.dot(xd.detach().double().flatten(), xd.grad.double().flatten())
+        assert abs(a.item() - b.item()) <= 1e-5 * max(abs(a.item()), abs(b.item()))
+
+
+# ------------------------------------------------------------------ interface behaviour
+def test_module_interface_and_errors():
+    from uno_amd.integral_operators import SpectralConv2d_Uno
+    torch.manual_seed(0)
+    conv = SpectralConv2d_Uno(3, 4, 16, 16, 4, 5)
+    x_cpu = torch.randn(2, 3, 20, 20)
+    with pytest.raises(RuntimeError):           # no CPU fallback on the product path
+        conv(x_cpu)
+    conv = conv.to(dev())
+    x = x_cpu.to(dev())
+    y = conv(x)
+    assert tuple(y.shape) == (2, 4, 16, 16) and y.dtype == torch.float32
+    y2 = conv(x, 12, 10)
+    assert tuple(y2.shape) == (2, 4, 12, 10)
+    assert (conv.dim1, conv.dim2) == (12, 10)   # dims override persists (reference :182-184)
+    assert tuple(conv(x).shape) == (2, 4, 12, 10)
+    with pytest.raises(RuntimeError):           # float64 input: the reference raises too
+        conv(x.double())
+    with pytest.raises(RuntimeError):           # modes2 > W//2+1 of the requested output
+        conv(x, 12, 6)
+    with pytest.raises(RuntimeError):
+        conv(torch.randn(2, 5, 20, 20, device=dev()))
+
+
+def test_empty_batch():
+    from uno_amd.integral_operators import spectral_conv2d
+    w = torch.randn(3, 4, 2, 3, dtype=torch.cfloat, device=dev())
+    x = torch.zeros(0, 3, 8, 8, device=dev())
+    assert tuple(spectral_conv2d(x, w, w, 8, 8).shape) == (0, 4, 8, 8)

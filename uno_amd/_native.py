@@ -1,0 +1,189 @@
+"""ctypes binding of libuno_spectral.so (C ABI: include/uno_spectral.h).
+
+This is the host side of the drop-in boundary: plain pointers, sizes and a hipStream_t cross
+it, nothing torch-typed.  There is NO fallback: if the library is missing or a call fails the
+error is raised to the caller (RuntimeError, as the reference surfaces torch RuntimeErrors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+_fp = C.c_void_p
+_i = C.c_int
+_SIGNATURES = {
+    "uno_abi_version": (C.c_int, []),
+    "uno_last_error": (C.c_char_p, []),
+    "uno_spectral_conv2d_fwd_ws_bytes": (C.c_longlong, [_i] * 5),
+    "uno_spectral_conv2d_bwd_ws_bytes": (C.c_longlong, [_i] * 5),
+    "uno_spectral_conv2d_forward": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
+    "uno_spectral_conv2d_backward": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
+    "uno_dft2d_forward": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_mode_mix": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
+    "uno_mode_wgrad": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 5 + [_fp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the native library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"uno_amd: native library {LIB_PATH} is missing - build it with "
+                        "`python -m uno_amd.build` (hipcc, gfx950); there is no CPU fallback")
+                h = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(h, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                if h.uno_abi_version() != ABI_VERSION:
+                    raise RuntimeError(f"uno_amd: ABI mismatch, library {h.uno_abi_version()} != binding {ABI_VERSION}")
+                _lib = h
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().uno_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _require(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"uno_amd: {name} must live on a HIP device (got {t.device}); the spectral "
+                           "convolution runs only on the MI355X kernels")
+    if t.dtype != dtype:
+        raise RuntimeError(f"uno_amd: {name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"uno_amd: {name} must be contiguous")
+
+
+def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
+    """-> (y (B,Co,Ho,Wo) f32, xtrunc (B,Ci,2*m1,m2) c64)."""
+    _require(x, torch.float32, "x")
+    _require(w1, torch.complex64, "weights1")
+    _require(w2, torch.complex64, "weights2")
+    B, Ci, H, W = x.shape
+    Ci2, Co, m1, m2 = w1.shape
+    if Ci2 != Ci or tuple(w2.shape) != tuple(w1.shape):
+        raise RuntimeError(f"uno_amd: weight shapes {tuple(w1.shape)} / {tuple(w2.shape)} do not match input channels {Ci}")
+    L = lib()
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x.device)
+        ws = torch.empty(max(1, L.uno_spectral_conv2d_fwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=x.device)
+        rc = L.uno_spectral_conv2d_forward(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws),
+                                           B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(x))
+    _check(rc, "uno_spectral_conv2d_forward")
+    return y, xt
+
+
+def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_gw=True):
+    """-> (gx or None, gw1 or None, gw2 or None)."""
+    _require(gy, torch.float32, "grad_output")
+    _require(xt, torch.complex64, "xtrunc")
+    _require(w1, torch.complex64, "weights1")
+    _require(w2, torch.complex64, "weights2")
+    B, Co, Ho, Wo = gy.shape
+    Ci, Co2, m1, m2 = w1.shape
+    if Co2 != Co:
+        raise RuntimeError("uno_amd: grad_output channels do not match the weights")
+    L = lib()
+    with torch.cuda.device(gy.device):
+        gx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=gy.device) if need_gx else None
+        gw1 = torch.empty_like(w1) if need_gw else None
+        gw2 = torch.empty_like(w2) if need_gw else None
+        ws = torch.empty(max(1, L.uno_spectral_conv2d_bwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=gy.device)
+        null = C.c_void_p(0)
+        rc = L.uno_spectral_conv2d_backward(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2),
+                                            _ptr(gx) if need_gx else null,
+                                            _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
+                                            _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(gy))
+    _check(rc, "uno_spectral_conv2d_backward")
+    return gx, gw1, gw2
+
+
+def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=False):
+    _require(images, torch.float32, "images")
+    *lead, H, W = images.shape
+    n = 1
+    for d in lead:
+        n *= d
+    spec = torch.empty((*lead, 2 * m1, m2), dtype=torch.complex64, device=images.device)
+    with torch.cuda.device(images.device):
+        rc = lib().uno_dft2d_forward(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                                     int(mask_overlap), _stream(images))
+    _check(rc, "uno_dft2d_forward")
+    return spec
+
+
+def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True):
+    _require(spec, torch.complex64, "spec")
+    *lead, r2, m2 = spec.shape
+    m1 = r2 // 2
+    n = 1
+    for d in lead:
+        n *= d
+    img = torch.empty((*lead, H, W), dtype=torch.float32, device=spec.device)
+    with torch.cuda.device(spec.device):
+        rc = lib().uno_dft2d_inverse(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                                     int(mask_overlap), _stream(spec))
+    _check(rc, "uno_dft2d_inverse")
+    return img
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def mode_mix(inp, weights, op: int):
+    """inp (B, Cin, ncorner, modes) c64; weights: list of (Ci, Co, modes...) c64."""
+    _require(inp, torch.complex64, "spectrum")
+    for w in weights:
+        _require(w, torch.complex64, "weights")
+    B = inp.shape[0]
+    Ci, Co = weights[0].shape[:2]
+    nc = len(weights)
+    Mc = weights[0][0, 0].numel()
+    cout = Co if op == 0 else Ci
+    out = torch.empty((B, cout, *inp.shape[2:]), dtype=torch.complex64, device=inp.device)
+    with torch.cuda.device(inp.device):
+        rc = lib().uno_mode_mix(_ptr(inp), _ptr_array(weights), _ptr(out), op, B, Ci, Co, nc, Mc, _stream(inp))
+    _check(rc, "uno_mode_mix")
+    return out
+
+
+def mode_wgrad(xt, go, weight_shape, ncorner: int):
+    _require(xt, torch.complex64, "xtrunc")
+    _require(go, torch.complex64, "grad spectrum")
+    B, Ci = xt.shape[:2]
+    Co = go.shape[1]
+    gws = [torch.empty(weight_shape, dtype=torch.complex64, device=xt.device) for _ in range(ncorner)]
+    Mc = gws[0][0, 0].numel()
+    with torch.cuda.device(xt.device):
+        rc = lib().uno_mode_wgrad(_ptr(xt), _ptr(go), _ptr_array(gws), B, Ci, Co, ncorner, Mc, _stream(xt))
+    _check(rc, "uno_mode_wgrad")
+    return gws

@@ -1,0 +1,236 @@
+// C ABI of libuno_spectral.so (declared in include/uno_spectral.h) + twiddle-table cache.
+#include "../../include/uno_spectral.h"
+#include "uno_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace uno {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// (cos, sin)(2 pi n / N) evaluated in double with the phase reduced in integers, exact at the
+// multiples of pi/2 (so that sin(pi l) terms of Nyquist / w = 0 columns vanish identically).
+static void fill_twiddles(int N, std::vector<float2>& t) {
+    t.resize(N);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n = 0; n < N; ++n) {
+        double c, s;
+        const long long n4 = 4LL * n;
+        if (n4 % N == 0) {
+            switch ((n4 / N) & 3) {
+                case 0: c = 1; s = 0; break;
+                case 1: c = 0; s = 1; break;
+                case 2: c = -1; s = 0; break;
+                default: c = 0; s = -1; break;
+            }
+        } else {
+            c = std::cos(two_pi * n / N);
+            s = std::sin(two_pi * n / N);
+        }
+        t[n] = make_float2((float)c, (float)s);
+    }
+}
+
+const float2* twiddle_table(int N) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, float2*> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({dev, N});
+    if (it != cache.end()) return it->second;
+    std::vector<float2> host;
+    fill_twiddles(N, host);
+    float2* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(float2) * N) != hipSuccess ||
+        hipMemcpy(d, host.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("twiddle table allocation for N=%d failed: %s", N, hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    cache[{dev, N}] = d;
+    return d;
+}
+
+static int check_modes2d(const char* who, int H, int W, int Ho, int Wo, int m1, int m2) {
+    if (H < 1 || W < 1 || Ho < 1 || Wo < 1) { set_error("%s: empty grid %dx%d -> %dx%d", who, H, W, Ho, Wo); return -1; }
+    if (m1 < 1 || m1 > H || m1 > Ho) {
+        set_error("%s: modes1=%d incompatible with grid rows %d -> %d (need 1 <= modes1 <= min rows)", who, m1, H, Ho);
+        return -1;
+    }
+    if (m2 < 1 || m2 > W / 2 + 1 || m2 > Wo / 2 + 1) {
+        set_error("%s: modes2=%d incompatible with grid cols %d -> %d (need modes2 <= cols/2+1)", who, m2, W, Wo);
+        return -1;
+    }
+    return 0;
+}
+
+static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, int W, int m1, int m2, float scale,
+                 int herm, int mask, hipStream_t s) {
+    const char* who = inverse ? "uno_dft2d_inverse" : "uno_dft2d_forward";
+    if (!in || !out) { set_error("%s: null pointer", who); return -1; }
+    if (n_img < 0) { set_error("%s: negative image count", who); return -1; }
+    if (int rc = check_modes2d(who, H, W, H, W, m1, m2)) return rc;
+    if (n_img == 0) return 0;
+    Dft2dParams p;
+    p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
+    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0;
+    p.twH = twiddle_table(H);
+    p.twW = twiddle_table(W);
+    if (!p.twH || !p.twW) return -6;
+    return inverse ? launch_dft2d_inv(p, s) : launch_dft2d_fwd(p, s);
+}
+
+// op 0: forward mix, op 1: grad wrt input spectrum, op 2: weight grad
+static int mode_gemm(int op, const float2* act, const float2* const* w, const float2* go, float2* out_act,
+                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s) {
+    if (B < 0 || Ci < 1 || Co < 1 || nc < 1 || nc > 4 || Mc < 1) {
+        set_error("mode gemm: bad sizes B=%d Ci=%d Co=%d corners=%d modes=%d", B, Ci, Co, nc, Mc);
+        return -1;
+    }
+    if (B == 0 && op != 2) return 0;
+    const long long P = (long long)nc * Mc;
+    ModeGemmParams p;
+    p.ncorner = nc; p.Mc = Mc;
+    for (int c = 0; c < 4; ++c) { p.A.base[c] = nullptr; p.B.base[c] = nullptr; p.out[c] = nullptr; }
+    if (op == 0) {              // O[b,o] = sum_i X[b,i] W[i,o]
+        p.M = B; p.N = Co; p.K = Ci;
+        p.A.s0 = (long long)Ci * P; p.A.s1 = P; p.A.conj = 0;
+        p.B.s0 = (long long)Co * Mc; p.B.s1 = Mc; p.B.conj = 0;
+        p.o_sm = (long long)Co * P; p.o_sn = P;
+        for (int c = 0; c < nc; ++c) { p.A.base[c] = act + (long long)c * Mc; p.B.base[c] = w[c]; p.out[c] = out_act + (long long)c * Mc; }
+    } else if (op == 1) {       // gX[b,i] = sum_o gO[b,o] conj(W[i,o])
+        p.M = B; p.N = Ci; p.K = Co;
+        p.A.s0 = (long long)Co * P; p.A.s1 = P; p.A.conj = 0;
+        p.B.s0 = Mc; p.B.s1 = (long long)Co * Mc; p.B.conj = 1;
+        p.o_sm = (long long)Ci * P; p.o_sn = P;
+        for (int c = 0; c < nc; ++c) { p.A.base[c] = act + (long long)c * Mc; p.B.base[c] = w[c]; p.out[c] = out_act + (long long)c * Mc; }
+    } else {                    // gW[i,o] = sum_b conj(X[b,i]) gO[b,o]
+        p.M = Ci; p.N = Co; p.K = B;
+        p.A.s0 = P; p.A.s1 = (long long)Ci * P; p.A.conj = 1;
+        p.B.s0 = (long long)Co * P; p.B.s1 = P; p.B.conj = 0;
+        p.o_sm = (long long)Co * Mc; p.o_sn = Mc;
+        for (int c = 0; c < nc; ++c) { p.A.base[c] = act + (long long)c * Mc; p.B.base[c] = go + (long long)c * Mc; p.out[c] = out_w[c]; }
+        if (B == 0) {
+            for (int c = 0; c < nc; ++c)
+                if (hipMemsetAsync(out_w[c], 0, sizeof(float2) * (size_t)Ci * Co * Mc, s) != hipSuccess) { set_error("memset failed"); return -5; }
+            return 0;
+        }
+    }
+    return launch_mode_gemm(p, s);
+}
+
+}  // namespace uno
+
+using namespace uno;
+
+extern "C" {
+
+int uno_abi_version(void) { return UNO_SPECTRAL_ABI_VERSION; }
+
+const char* uno_last_error(void) { return g_err; }
+
+long long uno_spectral_conv2d_fwd_ws_bytes(int B, int Ci, int Co, int m1, int m2) {
+    (void)Ci;
+    return 8LL * B * Co * 2 * m1 * m2;
+}
+
+long long uno_spectral_conv2d_bwd_ws_bytes(int B, int Ci, int Co, int m1, int m2) {
+    return 8LL * B * (Ci + Co) * 2 * m1 * m2;
+}
+
+int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
+                      int hermitian_cols, int mask_overlap, void* stream) {
+    return dft2d(false, images, spec, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream);
+}
+
+int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale,
+                      int hermitian_cols, int mask_overlap, void* stream) {
+    return dft2d(true, spec, images, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream);
+}
+
+int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,
+                 int modes_per_corner, void* stream) {
+    if (!in || !w || !out) { set_error("uno_mode_mix: null pointer"); return -1; }
+    if (op != 0 && op != 1) { set_error("uno_mode_mix: op must be 0 or 1"); return -1; }
+    if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_mix: ncorner=%d out of range", ncorner); return -1; }
+    for (int c = 0; c < ncorner; ++c)
+        if (!w[c]) { set_error("uno_mode_mix: null weight pointer %d", c); return -1; }
+    return mode_gemm(op, reinterpret_cast<const float2*>(in), reinterpret_cast<const float2* const*>(w), nullptr,
+                     reinterpret_cast<float2*>(out), nullptr, B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream);
+}
+
+int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
+                   int modes_per_corner, void* stream) {
+    if (!xtrunc || !go || !gw) { set_error("uno_mode_wgrad: null pointer"); return -1; }
+    if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_wgrad: ncorner=%d out of range", ncorner); return -1; }
+    for (int c = 0; c < ncorner; ++c)
+        if (!gw[c]) { set_error("uno_mode_wgrad: null output pointer %d", c); return -1; }
+    return mode_gemm(2, reinterpret_cast<const float2*>(xtrunc), nullptr, reinterpret_cast<const float2*>(go), nullptr,
+                     reinterpret_cast<float2* const*>(gw), B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream);
+}
+
+int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
+                                int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
+    if (!x || !w1 || !w2 || !y || !xtrunc || !ws) { set_error("uno_spectral_conv2d_forward: null pointer"); return -1; }
+    if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_forward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
+    if (int rc = check_modes2d("uno_spectral_conv2d_forward", H, W, Ho, Wo, m1, m2)) return rc;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    float* O = static_cast<float*>(ws);
+    // rfft2(x, norm="forward") restricted to the two corners            (reference :187)
+    if (int rc = dft2d(false, x, xtrunc, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s)) return rc;
+    // einsum("bixy,ioxy->boxy") with weights1 / weights2                  (reference :198-203)
+    const float* wv[2] = {w1, w2};
+    if (int rc = uno_mode_mix(xtrunc, wv, O, 0, B, Ci, Co, 2, m1 * m2, stream)) return rc;
+    // irfft2(out_ft, s=(Ho, Wo), norm="forward"), later-wins on overlapping rows (reference :190-206)
+    return dft2d(true, O, y, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s);
+}
+
+int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
+                                 float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                 int m1, int m2, void* stream) {
+    if (!gy || !xtrunc || !w1 || !w2 || !ws) { set_error("uno_spectral_conv2d_backward: null pointer"); return -1; }
+    if ((gw1 == nullptr) != (gw2 == nullptr)) { set_error("uno_spectral_conv2d_backward: gw1/gw2 must both be given or both be NULL"); return -1; }
+    if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_backward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
+    if (int rc = check_modes2d("uno_spectral_conv2d_backward", H, W, Ho, Wo, m1, m2)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long long P = 2LL * m1 * m2;
+    float* gO = static_cast<float*>(ws);
+    float* gX = gO + 2LL * B * Co * P;
+    if (B == 0) {
+        if (gw1) {
+            if (hipMemsetAsync(gw1, 0, 8ULL * Ci * Co * m1 * m2, s) != hipSuccess || hipMemsetAsync(gw2, 0, 8ULL * Ci * Co * m1 * m2, s) != hipSuccess) {
+                set_error("memset failed"); return -5;
+            }
+        }
+        return 0;
+    }
+    // gO = c (.) keep (.) DFT_trunc(gy)                                   (adjoint of irfft2 + CopySlices)
+    if (int rc = dft2d(false, gy, gO, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s)) return rc;
+    if (gw1) {
+        float* gwv[2] = {gw1, gw2};
+        if (int rc = uno_mode_wgrad(xtrunc, gO, gwv, B, Ci, Co, 2, m1 * m2, stream)) return rc;
+    }
+    if (gx) {
+        const float* wv[2] = {w1, w2};
+        if (int rc = uno_mode_mix(gO, wv, gX, 1, B, Ci, Co, 2, m1 * m2, stream)) return rc;
+        // gx = 1/(H W) Re iDFT_trunc(gX)                                   (adjoint of rfft2(norm="forward"))
+        if (int rc = dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s)) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// K2/K4 - batched per-mode complex GEMM on the truncated spectrum.
+//
+//   out(m, n, p) = sum_k A'(m, k, p) * B'(k, n, p)          (' = optional complex conjugate)
+//
+// One kernel serves the three contractions of SpectralConv{2,3}d_Uno (reference
+// integral_operators.py:178-179 / :382-383 and their autograd adjoints):
+//   forward   O[b,o]  = sum_i X[b,i]        * W[i,o]          einsum "bixy,ioxy->boxy"
+//   grad X    gX[b,i] = sum_o gO[b,o]       * conj(W[i,o])
+//   grad W    gW[i,o] = sum_b conj(X[b,i])  * gO[b,o]
+// by choosing operand strides (ModeGemmParams).  Modes p are independent; they are split into
+// `ncorner` contiguous runs of Mc modes (one run per weight tensor).
+//
+// Workgroup tile: 16 (m) x 16 (n) x QC = 16 consecutive modes, K streamed in chunks of KC = 8.
+// Both operands are read from HBM/L2 in 128-byte runs along the mode axis (the minor axis of the
+// reference's (Ci, Co, m1, m2) parameter layout), transposed through LDS into per-mode
+// [k][16] planes (re / im), and consumed as v_mfma_f32_16x16x4_f32 fragments with conflict-free
+// ds_read_b32.  A complex product is four real MFMAs.  The 16x16x16-mode result tile goes back
+// through LDS so the stores are 128-byte runs again.  The next K chunk is prefetched into registers
+// while the current one is multiplied.
+#include "uno_common.h"
+
+namespace uno {
+
+constexpr int QC = 16;          // modes per workgroup
+constexpr int KC = 8;           // reduction chunk staged in LDS
+constexpr int PLANE = KC * 16 + 4;      // floats per (mode) plane; +4 breaks the power-of-two stride on the transposing writes
+constexpr int TILE_ELEMS = 16 * KC * QC;        // complex elements of one operand chunk = 2048
+constexpr int EPT = TILE_ELEMS / 256;           // elements per thread per operand = 8
+
+__global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
+    // [operand A|B][re|im][QC][PLANE] floats; reused as the [16 m][16 n][QC] c64 output tile
+    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * QC * PLANE > 16 * 16 * (QC + 1) * 2 ? 2 * 2 * QC * PLANE : 16 * 16 * (QC + 1) * 2];
+    float* sA = sm;
+    float* sB = sm + 2 * QC * PLANE;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+
+    const int nq = (p.Mc + QC - 1) / QC;
+    const int corner = blockIdx.x / nq;
+    const int q0 = (blockIdx.x % nq) * QC;
+    const int n0 = blockIdx.y * 16;
+    const int m0 = blockIdx.z * 16;
+    const int nmodes = min(QC, p.Mc - q0);
+
+    const float2* Ab = p.A.base[corner] + q0;
+    const float2* Bb = p.B.base[corner] + q0;
+    const float sgnA = p.A.conj ? -1.f : 1.f;
+    const float sgnB = p.B.conj ? -1.f : 1.f;
+
+    // staging map: element e = tid + 256 * u  ->  (row = e / QC, q = e % QC); A rows = (k, m), B rows = (k, n)
+    float2 ra[EPT], rb[EPT];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = tid + 256 * u;
+            const int q = e & (QC - 1), row = e >> 4;
+            const int kl = row >> 4, x = row & 15;          // kl in [0, KC), x = m or n within the tile
+            const int k = k0 + kl;
+            float2 va = make_float2(0.f, 0.f), vb = make_float2(0.f, 0.f);
+            if (q < nmodes && k < p.K) {
+                if (m0 + x < p.M) va = Ab[(long long)(m0 + x) * p.A.s0 + (long long)k * p.A.s1 + q];
+                if (n0 + x < p.N) vb = Bb[(long long)k * p.B.s0 + (long long)(n0 + x) * p.B.s1 + q];
+            }
+            ra[u] = va; rb[u] = vb;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = tid + 256 * u;
+            const int q = e & (QC - 1), row = e >> 4;
+            const int o = q * PLANE + row;                  // row = kl * 16 + x
+            sA[o] = ra[u].x; sA[QC * PLANE + o] = sgnA * ra[u].y;
+            sB[o] = rb[u].x; sB[QC * PLANE + o] = sgnB * rb[u].y;
+        }
+    };
+
+    f32x4 accr[QC / 4], acci[QC / 4];       // this wave's modes q = wave + 4 * v
+#pragma unroll
+    for (int v = 0; v < QC / 4; ++v) { accr[v] = f32x4{0, 0, 0, 0}; acci[v] = f32x4{0, 0, 0, 0}; }
+
+    load_chunk(0);
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        __syncthreads();                    // previous chunk fully consumed
+        store_chunk();
+        __syncthreads();
+        if (k0 + KC < p.K) load_chunk(k0 + KC);
+#pragma unroll
+        for (int v = 0; v < QC / 4; ++v) {
+            const int q = wave + 4 * v;
+            const float* pa = sA + q * PLANE + kk * 16 + r16;
+            const float* pb = sB + q * PLANE + kk * 16 + r16;
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                const float ar = pa[ks * 64], ai = pa[QC * PLANE + ks * 64];
+                const float br = pb[ks * 64], bi = pb[QC * PLANE + ks * 64];
+                accr[v] = mfma16(ar, br, accr[v]);
+                acci[v] = mfma16(ar, bi, acci[v]);
+                accr[v] = mfma16(-ai, bi, accr[v]);
+                acci[v] = mfma16(ai, br, acci[v]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // result tile -> LDS as [m][n][QC+1] c64, then 128-byte runs along the mode axis
+    float2* sO = reinterpret_cast<float2*>(sm);
+#pragma unroll
+    for (int v = 0; v < QC / 4; ++v) {
+        const int q = wave + 4 * v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * kk + r;
+            sO[(m * 16 + r16) * (QC + 1) + q] = make_float2(accr[v][r], acci[v][r]);
+        }
+    }
+    __syncthreads();
+    float2* Ob = p.out[corner] + q0;
+    for (int e = tid; e < 16 * 16 * QC; e += 256) {
+        const int q = e & (QC - 1), mn = e >> 4;
+        const int m = mn >> 4, n = mn & 15;
+        if (q < nmodes && m0 + m < p.M && n0 + n < p.N)
+            Ob[(long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q] = sO[mn * (QC + 1) + q];
+    }
+}
+
+int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
+    if (p.ncorner < 1 || p.ncorner > 4 || p.Mc < 1 || p.M < 1 || p.N < 1 || p.K < 1) {
+        set_error("mode_gemm: bad sizes M=%d N=%d K=%d corners=%d modes=%d", p.M, p.N, p.K, p.ncorner, p.Mc);
+        return -2;
+    }
+    const int nq = (p.Mc + QC - 1) / QC;
+    dim3 grid(p.ncorner * nq, (p.N + 15) / 16, (p.M + 15) / 16);
+    hipLaunchKernelGGL(mode_gemm_kernel, grid, dim3(256), 0, s, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+}  // namespace uno

@@ -1,0 +1,79 @@
+// Shared device/host helpers for the U-NO spectral-convolution kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uno {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact f32 (k-ordered fmaf chain).
+// Lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// lane l, register r of C/D holds D[row = 4 * (l >> 4) + r][col = l & 15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// idx, inc and lim are byte offsets into a float2 table of lim/8 entries; idx < lim, inc < lim.
+__device__ __forceinline__ unsigned wrap_add(unsigned idx, unsigned inc, unsigned lim) {
+    unsigned t = idx + inc;
+    return min(t, t - lim);          // t - lim wraps to a huge value when t < lim
+}
+__device__ __forceinline__ unsigned wrap_sub(unsigned idx, unsigned dec, unsigned lim) {
+    unsigned t = idx - dec;          // wraps when idx < dec
+    return min(t, t + lim);
+}
+
+// 4-byte-aligned 16-byte load: rows of odd length leave row starts only 4-byte aligned.
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+
+__device__ __forceinline__ float2 lds_tw(const float2* tab, unsigned byte_off) {
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab) + byte_off);
+}
+
+// Hermitian weight of column l of a one-sided spectrum of a length-N real axis.
+__device__ __forceinline__ float herm_weight(int l, int N) {
+    return (l == 0 || 2 * l == N) ? 1.0f : 2.0f;
+}
+
+// Spectrum row of corner-row index j (0 <= j < 2m) on a full-complex axis of length N:
+// the "lo" corner holds rows 0..m-1, the "hi" corner rows N-m..N-1.
+__host__ __device__ __forceinline__ int corner_freq(int j, int m, int N) { return j < m ? j : N - 2 * m + j; }
+
+// "Later slice-assignment wins": lo-corner row j is overwritten by the hi corner when j >= N - m.
+__host__ __device__ __forceinline__ bool row_survives(int j, int m, int N) { return j >= m || j < N - m; }
+
+struct Dft2dParams {
+    const float* in;        // forward: images (n_img, H, W) f32; inverse: spectra (n_img, 2*m1, m2) c64
+    float* out;             // forward: spectra; inverse: images
+    const float2* twH;      // (cos, sin)(2 pi n / H), n in [0, H)
+    const float2* twW;
+    int n_img, H, W, m1, m2;
+    float scale;            // applied to every spectrum entry
+    int herm;               // 1: multiply column l by the Hermitian weight c_l of W
+    int mask;               // 1: zero lo-corner rows overwritten by the hi corner (later-wins)
+};
+
+// Batched per-mode complex GEMM: out(m, n, p) = sum_k A'(m, k, p) * B'(k, n, p), ' = optional conj.
+// All offsets are in complex (float2) elements.  Modes are split in `ncorner` contiguous runs
+// of Mc modes; operand X (X = A, B, O) of corner c starts at X.base[c].
+struct ModeOperand {
+    const float2* base[4];
+    long long s0, s1;       // A: (m, k); B: (k, n); out: (m, n)
+    int conj;
+};
+struct ModeGemmParams {
+    ModeOperand A, B;
+    float2* out[4];
+    long long o_sm, o_sn;
+    int M, N, K, ncorner, Mc;
+};
+
+const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
+void set_error(const char* fmt, ...);
+
+int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
+int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
+int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
+
+}  // namespace uno
