@@ -80,8 +80,8 @@ static int check_modes2d(const char* who, int H, int W, int Ho, int Wo, int m1, 
 static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, int W, int m1, int m2, float scale,
                  int herm, int mask, hipStream_t s) {
     const char* who = inverse ? "uno_dft2d_inverse" : "uno_dft2d_forward";
-    if (!in || !out) { set_error("%s: null pointer", who); return -1; }
     if (n_img < 0) { set_error("%s: negative image count", who); return -1; }
+    if (n_img > 0 && (!in || !out)) { set_error("%s: null pointer", who); return -1; }
     if (int rc = check_modes2d(who, H, W, H, W, m1, m2)) return rc;
     if (n_img == 0) return 0;
     Dft2dParams p;
@@ -163,7 +163,7 @@ int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W,
 
 int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,
                  int modes_per_corner, void* stream) {
-    if (!in || !w || !out) { set_error("uno_mode_mix: null pointer"); return -1; }
+    if (!w || (B > 0 && (!in || !out))) { set_error("uno_mode_mix: null pointer"); return -1; }
     if (op != 0 && op != 1) { set_error("uno_mode_mix: op must be 0 or 1"); return -1; }
     if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_mix: ncorner=%d out of range", ncorner); return -1; }
     for (int c = 0; c < ncorner; ++c)
@@ -174,7 +174,7 @@ int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int
 
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
                    int modes_per_corner, void* stream) {
-    if (!xtrunc || !go || !gw) { set_error("uno_mode_wgrad: null pointer"); return -1; }
+    if (!gw || (B > 0 && (!xtrunc || !go))) { set_error("uno_mode_wgrad: null pointer"); return -1; }
     if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_wgrad: ncorner=%d out of range", ncorner); return -1; }
     for (int c = 0; c < ncorner; ++c)
         if (!gw[c]) { set_error("uno_mode_wgrad: null output pointer %d", c); return -1; }
@@ -184,10 +184,10 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
 
 int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
                                 int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
-    if (!x || !w1 || !w2 || !y || !xtrunc || !ws) { set_error("uno_spectral_conv2d_forward: null pointer"); return -1; }
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_forward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
     if (int rc = check_modes2d("uno_spectral_conv2d_forward", H, W, Ho, Wo, m1, m2)) return rc;
-    if (B == 0) return 0;
+    if (B == 0) return 0;           // empty batch: nothing to do (empty tensors carry null pointers)
+    if (!x || !w1 || !w2 || !y || !xtrunc || !ws) { set_error("uno_spectral_conv2d_forward: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     float* O = static_cast<float*>(ws);
     // rfft2(x, norm="forward") restricted to the two corners            (reference :187)
@@ -202,7 +202,7 @@ int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2
 int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
                                  float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
                                  int m1, int m2, void* stream) {
-    if (!gy || !xtrunc || !w1 || !w2 || !ws) { set_error("uno_spectral_conv2d_backward: null pointer"); return -1; }
+    if (B > 0 && (!gy || !xtrunc || !w1 || !w2 || !ws)) { set_error("uno_spectral_conv2d_backward: null pointer"); return -1; }
     if ((gw1 == nullptr) != (gw2 == nullptr)) { set_error("uno_spectral_conv2d_backward: gw1/gw2 must both be given or both be NULL"); return -1; }
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_backward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
     if (int rc = check_modes2d("uno_spectral_conv2d_backward", H, W, Ho, Wo, m1, m2)) return rc;
