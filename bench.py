@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: U-NO training samples/s on synthetic 421x421 Darcy (BASELINE.json configs[1])
++ live HBM-roofline figure of the dominant spectral kernel + the CPU baseline timed beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + relative-L2 loss + backward + gradient all-reduce (N > 1) + complex-modulus Adam
+update on one minibatch of 16 synthetic samples per GPU (weak scaling).  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+S, WIDTH, PAD, BATCH = 421, 64, 5, 16          # BASELINE.json configs[1]: Darcy 421^2, 64 ch, batch 16
+BLOCK_MODES = 20                               # block-level roofline config: modes = 20
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host CPU leg (developer runs)")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the bounded CPU-baseline step")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch: int):
+    """The oracle's FFT-sequence restatement of the reference step (rfft2 -> einsum -> irfft2 blocks,
+    same loss, reference-Adam arithmetic) timed on the host cores: one step on `batch` samples of the
+    same 421^2 workload (the full 16-sample step costs ~30 s on 8 cores)."""
+    from oracle import spectral_oracle as so            # checker/baseline only - never the product path
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = UNO_9(3, WIDTH, pad=PAD, block_cls=so.OracleOperatorBlock2d)
+    tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    a1, u1 = synthetic_darcy_batch(1, S, 99, "cpu")
+    tr.step(a1, u1)                                     # untimed: thread pool, allocator, MKL plans
+    a, u = synthetic_darcy_batch(batch, S, 1234, "cpu")
+    t0 = time.perf_counter()
+    tr.step(a, u)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step on {batch} synthetic 421x421 samples ({dt:.1f} s), UNO_9(3,{WIDTH},pad={PAD}), "
+                      f"torch {torch.__version__} CPU FFT path, {cores} threads"}
+
+
+def spectral_block_roofline(dev, iters=10):
+    """BASELINE's second figure: SpectralConv2d(64,64,421,421,20,20), batch 16, forward and backward
+    against the algorithmic bytes of SURVEY.md section 8(d) (fwd 1478.2 MB, bwd 1504.4 MB)."""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(0)
+    C, m = WIDTH, BLOCK_MODES
+    x = torch.randn(BATCH, C, S, S, generator=g).to(dev)
+    sc = (1 / (2 * C)) ** 0.5
+    w1 = (sc * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)).to(dev)
+    w2 = (sc * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)).to(dev)
+    gy = torch.randn(BATCH, C, S, S, generator=g).to(dev)
+    y, xt = _native.spectral_conv2d_forward(x, w1, w2, S, S)
+    _native.spectral_conv2d_backward(gy, xt, w1, w2, S, S)
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    tf = timed(lambda: _native.spectral_conv2d_forward(x, w1, w2, S, S))
+    tb = timed(lambda: _native.spectral_conv2d_backward(gy, xt, w1, w2, S, S))
+    img = BATCH * C * S * S * 4
+    wb = 2 * C * C * m * m * 8
+    fwd_b, bwd_b = 2 * img + wb, 2 * img + 2 * wb
+    return {"config": f"SpectralConv2d({C},{C},{S},{S},{m},{m}) batch {BATCH} f32",
+            "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_bytes": fwd_b, "bwd_bytes": bwd_b,
+            "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
+                     f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the product path")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
+
+    from uno_amd import _native
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+
+    torch.manual_seed(0)                                    # same init everywhere (then broadcast from rank 0)
+    model = UNO_9(3, WIDTH, pad=PAD).to(dev)
+    trainer = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    a, u = synthetic_darcy_batch(BATCH, S, 1234 + rank, dev)   # per-rank shard of the global batch, in HBM
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(a, u)
+    sync_all()
+    _native.profile_begin(200000)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(a, u)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    records = _native.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss)
+    assert loss_val == loss_val, "training produced NaN"
+
+    if rank == 0:
+        # live per-kernel timing (HIP events on the launch stream, recorded inside the library)
+        agg = {}
+        for name, ms, by in records:
+            if ms < 0:
+                continue
+            a_ = agg.setdefault(name, [0, 0.0, 0.0])
+            a_[0] += 1
+            a_[1] += ms
+            a_[2] += by
+        roofline = None
+        if agg:
+            dom = max(agg, key=lambda k: agg[k][1])
+            n, ms, by = agg[dom]
+            achieved = by / (ms * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n,
+                        "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n,
+                        "kernels": {k: {"launches": v[0], "total_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9}
+                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        block = spectral_block_roofline(dev) if world == 1 else None
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_batch)
+        out = {
+            "metric": "UNO training samples/s (421^2 Darcy)", "value": world * BATCH * args.steps / elapsed,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Darcy 2D {S}x{S}, UNO_9(3,{WIDTH},pad={PAD}) 64ch, batch {BATCH}/GPU, train step "
+                                   "(fwd+loss+bwd+allreduce+Adam)", "global_batch": world * BATCH,
+                       "parallelism": f"dp{world}", "final_loss": loss_val},
+            "roofline": roofline, "spectral_block": block, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

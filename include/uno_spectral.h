@@ -80,6 +80,17 @@ int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co,
                    int ncorner, int modes_per_corner, void* stream);
 
+/* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
+ * this library enqueues), used by bench.py for the live roofline figure.
+ *   uno_profile_begin(max_records): start recording (drops records beyond max_records).
+ *   uno_profile_end():   stop, wait for the recorded events, return the number of records.
+ *   uno_profile_get(i, name, name_len, &ms, &bytes): record i - kernel name as rocprofv3 prints it
+ *     (e.g. "uno::dft2d_fwd_kernel<2, 3>"), its duration in ms and its ALGORITHMIC bytes
+ *     (each operand counted once, DESIGN.md section "Roofline accounting"). */
+int uno_profile_begin(int max_records);
+int uno_profile_end(void);
+int uno_profile_get(int index, char* name, int name_len, double* ms, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

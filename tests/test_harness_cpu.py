@@ -1,0 +1,134 @@
+"""Host logic of the harness on CPU: the UNO_9 counterpart, relative-L2 loss, ComplexAdam and the
+data-parallel step, pinned by reference-generated golden vectors (tests/golden/harness.npz).
+
+The spectral layers have no CPU path in the product, so these tests plug the ORACLE's operator block
+in as a test double (block_cls=...) - this exercises the harness, not the HIP kernels (those are
+covered by the -m gpu tests)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import Case, load_cases, rel_err
+from oracle import spectral_oracle as so
+from uno_amd.harness import ComplexAdam, DarcyTrainer, UNO_9, lp_loss_rel_sum, synthetic_darcy_batch
+
+ZH, _ = load_cases("harness.npz")
+
+
+def _uno9_from_golden():
+    c = Case(ZH, "uno9")
+    S, B, width, pad = [int(v) for v in c.meta]
+    model = UNO_9(3, width, pad=pad, block_cls=so.OracleOperatorBlock2d)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}
+    model.load_state_dict(sd, strict=True)
+    return c, model, S, B
+
+
+def test_state_dict_is_reference_compatible():
+    c = Case(ZH, "uno9")
+    product = UNO_9(3, int(c.meta[2]), pad=int(c.meta[3]))        # product blocks (constructible on CPU)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}
+    product.load_state_dict(sd, strict=True)
+    assert product.conv0.conv.weights1.dtype == torch.complex64
+    assert [k for k in product.state_dict()] == list(sd)
+
+
+def test_uno9_forward_loss_grads_match_reference():
+    c, model, S, B = _uno9_from_golden()
+    a, u = torch.from_numpy(c.a), torch.from_numpy(c.u)
+    pred = model(a).reshape(B, S, S)
+    assert rel_err(pred.detach().numpy(), c.pred0) < 1e-5
+    loss = lp_loss_rel_sum(pred.view(B, -1), u.view(B, -1))
+    assert abs(float(loss) - float(c.losses[0])) < 1e-5 * abs(float(c.losses[0]))
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = float(getattr(c, f"gradnorm.{k}"))
+        assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-4 * ref + 1e-9, k
+    for k, g in c.sub("grad").items():
+        assert rel_err(dict(model.named_parameters())[k].grad.numpy(), g) < 2e-4, k
+
+
+def test_three_training_steps_match_reference_adam():
+    c, model, S, B = _uno9_from_golden()
+    a, u = torch.from_numpy(c.a), torch.from_numpy(c.u)
+    tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    losses = [float(tr.step(a, u)) for _ in range(3)]
+    assert np.allclose(losses, c.losses, rtol=2e-4)
+    for k, p in model.named_parameters():
+        ref = float(getattr(c, f"after3.norm.{k}"))
+        assert abs(float(torch.linalg.vector_norm(p)) - ref) <= 1e-4 * ref + 1e-9, k
+    for k, v in c.sub("after3").items():
+        if k.startswith("norm.") or k.startswith("sum."):
+            continue
+        assert rel_err(dict(model.named_parameters())[k].detach().numpy(), v) < 1e-3, k
+
+
+def test_complex_adam_matches_reference():
+    c = Case(ZH, "adam")
+    pc = torch.nn.Parameter(torch.from_numpy(c.pc0.copy()))
+    pr = torch.nn.Parameter(torch.from_numpy(c.pr0.copy()))
+    opt = ComplexAdam([pc, pr], lr=1e-2, weight_decay=1e-3)
+    for t in range(3):
+        pc.grad = torch.from_numpy(c.gc[t].copy())
+        pr.grad = torch.from_numpy(c.gr[t].copy())
+        opt.step()
+    assert rel_err(pc.detach().numpy(), c.pc3) < 1e-6
+    assert rel_err(pr.detach().numpy(), c.pr3) < 1e-6
+
+
+def test_grid_matches_numpy_linspace():
+    m = UNO_9(3, 4)
+    g = m.get_grid((2, 7, 5, 1), torch.device("cpu"))
+    gx = np.linspace(0, 1, 7).astype(np.float32)
+    gy = np.linspace(0, 1, 5).astype(np.float32)
+    assert np.array_equal(g[0, :, 0, 0].numpy(), gx) and np.array_equal(g[1, 3, :, 1].numpy(), gy)
+
+
+# ----------------------------------------------------------------------------- data parallel (gloo)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
+        model = UNO_9(3, 4, pad=5, block_cls=so.OracleOperatorBlock2d)
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+        a, u = synthetic_darcy_batch(4, 72, seed=7, device="cpu")      # global batch, identical on all ranks
+        sl = slice(rank * 2, rank * 2 + 2)
+        for _ in range(2):
+            loss = tr.step(a[sl], u[sl])
+        if rank == 0:
+            torch.save({k: v.clone() for k, v in model.state_dict().items()}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_equals_single_process_global_batch(tmp_path):
+    """world_size=2 gloo: two ranks on half batches == one process on the concatenated batch
+    (gradients are SUMMED across ranks because the reference loss is a sum over samples)."""
+    out_path = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    dp = torch.load(out_path)
+
+    torch.manual_seed(100)                            # rank 0's init is what gets broadcast
+    model = UNO_9(3, 4, pad=5, block_cls=so.OracleOperatorBlock2d)
+    tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    a, u = synthetic_darcy_batch(4, 72, seed=7, device="cpu")
+    for _ in range(2):
+        tr.step(a, u)
+    for k, v in model.state_dict().items():
+        assert rel_err(torch.view_as_real(dp[k]).numpy() if v.is_complex() else dp[k].numpy(),
+                       torch.view_as_real(v).numpy() if v.is_complex() else v.numpy()) < 2e-4, k

@@ -1,0 +1,100 @@
+"""Operator blocks and the UNO_9 harness model on the MI355X (HIP spectral path + stock ROCm ops for
+the point-wise branch) against reference-generated golden vectors.  pytest -m gpu
+
+Tolerances: blocks 2e-5 (spectral part) .. 1e-4 (after bicubic-AA + InstanceNorm + GELU on a
+different backend); end-to-end model 1e-3 on outputs/gradient norms (5 blocks + 2 InstanceNorms)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Case, load_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+ZB, NAMESB = load_cases("blocks.npz")
+ZH, _ = load_cases("harness.npz")
+B2D = [n for n in NAMESB if n.startswith("b2d_")]
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", B2D)
+def test_operator_block_2d_golden(name):
+    from uno_amd.integral_operators import OperatorBlock_2D
+    c = Case(ZB, name)
+    B, Ci, Co, H, W, Ho, Wo, m1, m2, nrm, nl = [int(v) for v in c.meta]
+    blk = OperatorBlock_2D(Ci, Co, Ho, Wo, m1, m2, Normalize=bool(nrm), Non_Lin=bool(nl))
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    blk = blk.to(dev())
+    x = torch.from_numpy(c.x).to(dev()).requires_grad_(True)
+    y = blk(x)
+    assert rel_err(y.detach().cpu().numpy(), c.y) < 1e-4
+    y.backward(torch.from_numpy(c.gy).to(dev()))
+    assert rel_err(x.grad.cpu().numpy(), c.gx) < 1e-4
+    params = dict(blk.named_parameters())
+    for k, g in c.sub("grad").items():
+        assert rel_err(params[k].grad.cpu().numpy(), g) < 2e-4, k
+
+
+def test_dim_mutation_quirk():
+    from uno_amd.integral_operators import OperatorBlock_2D
+    c = Case(ZB, "dimmut")
+    blk = OperatorBlock_2D(3, 4, 16, 16, 4, 4)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    blk = blk.to(dev())
+    x = torch.from_numpy(c.x).to(dev())
+    y = blk(x, 12, 12)
+    assert rel_err(y.detach().cpu().numpy(), c.y_override) < 1e-4
+    assert [blk.conv.dim1, blk.conv.dim2, blk.w.dim1, blk.w.dim2] == [int(v) for v in c.state]
+    assert rel_err(blk.conv(x).detach().cpu().numpy(), c.y_conv_after) < 2e-5
+
+
+def test_uno9_training_steps_match_reference():
+    """UNO_9(3,4,pad=5), S=72: prediction, loss, gradient norms and 3 reference-Adam steps."""
+    from uno_amd.harness import DarcyTrainer, UNO_9
+    c = Case(ZH, "uno9")
+    S, B, width, pad = [int(v) for v in c.meta]
+    model = UNO_9(3, width, pad=pad)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    model = model.to(dev())
+    a, u = torch.from_numpy(c.a).to(dev()), torch.from_numpy(c.u).to(dev())
+    with torch.no_grad():
+        pred = model(a).reshape(B, S, S)
+    assert rel_err(pred.cpu().numpy(), c.pred0) < 1e-3
+    tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    losses = []
+    for step in range(3):
+        losses.append(float(tr.step(a, u)))
+        if step == 0:
+            for k, p in model.named_parameters():
+                ref = float(getattr(c, f"gradnorm.{k}"))
+                assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-3 * ref + 1e-8, k
+    assert np.allclose(losses, c.losses, rtol=1e-3)
+    for k, p in model.named_parameters():
+        ref = float(getattr(c, f"after3.norm.{k}"))
+        assert abs(float(torch.linalg.vector_norm(p)) - ref) <= 1e-3 * ref + 1e-8, k
+
+
+def test_model_product_vs_oracle_blocks_same_weights():
+    """Same UNO_9 weights, product blocks on the GPU vs the oracle's FFT blocks on the host, at a
+    non-golden size (S=100 -> padded 110, scale=2)."""
+    from oracle import spectral_oracle as so
+    from uno_amd.harness import UNO_9, lp_loss_rel_sum, synthetic_darcy_batch
+    torch.manual_seed(3)
+    ref = UNO_9(3, 8, pad=5, block_cls=so.OracleOperatorBlock2d)
+    prod = UNO_9(3, 8, pad=5)
+    prod.load_state_dict(ref.state_dict(), strict=True)
+    prod = prod.to(dev())
+    a, u = synthetic_darcy_batch(2, 100, 11, "cpu")
+    lr = lp_loss_rel_sum(ref(a).reshape(2, -1), u.reshape(2, -1))
+    lr.backward()
+    lp = lp_loss_rel_sum(prod(a.to(dev())).reshape(2, -1), u.to(dev()).reshape(2, -1))
+    lp.backward()
+    assert abs(float(lp) - float(lr)) < 1e-4 * abs(float(lr))
+    pr = dict(ref.named_parameters())
+    for k, p in prod.named_parameters():
+        g, gr = p.grad.cpu(), pr[k].grad
+        n = float(torch.linalg.vector_norm(gr))
+        assert float(torch.linalg.vector_norm(g - gr)) <= 2e-3 * n + 1e-7, k

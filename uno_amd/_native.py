@@ -32,6 +32,9 @@ _SIGNATURES = {
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_mode_mix": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
     "uno_mode_wgrad": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 5 + [_fp]),
+    "uno_profile_begin": (C.c_int, [_i]),
+    "uno_profile_end": (C.c_int, []),
+    "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -187,3 +190,20 @@ def mode_wgrad(xt, go, weight_shape, ncorner: int):
         rc = lib().uno_mode_wgrad(_ptr(xt), _ptr(go), _ptr_array(gws), B, Ci, Co, ncorner, Mc, _stream(xt))
     _check(rc, "uno_mode_wgrad")
     return gws
+
+
+def profile_begin(max_records: int = 100000):
+    _check(lib().uno_profile_begin(int(max_records)), "uno_profile_begin")
+
+
+def profile_end():
+    """-> list of (kernel name, milliseconds, algorithmic bytes), one per kernel launch recorded."""
+    L = lib()
+    n = L.uno_profile_end()
+    out = []
+    name = C.create_string_buffer(64)
+    ms, by = C.c_double(), C.c_double()
+    for i in range(n):
+        _check(L.uno_profile_get(i, name, 64, C.byref(ms), C.byref(by)), "uno_profile_get")
+        out.append((name.value.decode(), ms.value, by.value))
+    return out

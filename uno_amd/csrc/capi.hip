@@ -64,6 +64,33 @@ const float2* twiddle_table(int N) {
     return d;
 }
 
+// ---------------------------------------------------------------------------- profiling
+struct ProfRecord { char name[64]; double bytes; hipEvent_t e0, e1; float ms; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRecord> g_prof;
+static int g_prof_cap = 0;
+static bool g_prof_on = false;
+
+ProfScope::ProfScope(const char* name, double bytes, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (!g_prof_on || (int)g_prof.size() >= g_prof_cap) return;
+    ProfRecord r;
+    snprintf(r.name, sizeof(r.name), "%s", name);
+    r.bytes = bytes; r.ms = 0.f;
+    if (hipEventCreate(&r.e0) != hipSuccess) return;
+    if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+    (void)hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
+}
+
 static int check_modes2d(const char* who, int H, int W, int Ho, int Wo, int m1, int m2) {
     if (H < 1 || W < 1 || Ho < 1 || Wo < 1) { set_error("%s: empty grid %dx%d -> %dx%d", who, H, W, Ho, Wo); return -1; }
     if (m1 < 1 || m1 > H || m1 > Ho) {
@@ -139,6 +166,37 @@ using namespace uno;
 extern "C" {
 
 int uno_abi_version(void) { return UNO_SPECTRAL_ABI_VERSION; }
+
+int uno_profile_begin(int max_records) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_cap = max_records > 0 ? max_records : 0;
+    g_prof.reserve(g_prof_cap);
+    g_prof_on = g_prof_cap > 0;
+    return 0;
+}
+
+int uno_profile_end(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof_on = false;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&r.ms, r.e0, r.e1) != hipSuccess) r.ms = -1.f;
+    }
+    return (int)g_prof.size();
+}
+
+int uno_profile_get(int index, char* name, int name_len, double* ms, double* bytes) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (index < 0 || index >= (int)g_prof.size() || !name || name_len < 1 || !ms || !bytes) {
+        set_error("uno_profile_get: bad index or null pointer");
+        return -1;
+    }
+    snprintf(name, (size_t)name_len, "%s", g_prof[index].name);
+    *ms = g_prof[index].ms;
+    *bytes = g_prof[index].bytes;
+    return 0;
+}
 
 const char* uno_last_error(void) { return g_err; }
 

@@ -18,6 +18,7 @@
 // Each wave keeps a partial X for its tiles; a tree reduction through LDS (fixed order: deterministic)
 // combines them and wave 0 writes the 2*m1*m2 complex results.
 #include "uno_common.h"
+#include <cstdio>
 
 namespace uno {
 
@@ -257,7 +258,12 @@ static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
             return -4;
         }
     }
-    hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
+    char name[64];
+    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d>", NT, MT);
+    {
+        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
+        hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dft2d_fwd launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

@@ -14,6 +14,7 @@
 //     (k-step s, lane group kk <-> mode 4s+kk).  Symmetric form: Ey = sum Ur cos, Dy = sum Ui sin over
 //     w <= W/2, then y[w] = Ey - Dy and y[W-w] = Ey + Dy: half the flops, no padding waste in K.
 #include "uno_common.h"
+#include <cstdio>
 
 namespace uno {
 
@@ -140,7 +141,12 @@ static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
             return -4;
         }
     }
-    hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
+    char name[64];
+    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d>", NT, JT);
+    {
+        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
+        hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dft2d_inv launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

@@ -132,7 +132,12 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
     }
     const int nq = (p.Mc + QC - 1) / QC;
     dim3 grid(p.ncorner * nq, (p.N + 15) / 16, (p.M + 15) / 16);
-    hipLaunchKernelGGL(mode_gemm_kernel, grid, dim3(256), 0, s, p);
+    {
+        // each operand counted once: A (M x K), B (K x N), out (M x N) complex64 per mode
+        const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
+        ProfScope prof("uno::mode_gemm_kernel", per_mode * p.ncorner * p.Mc, s);
+        hipLaunchKernelGGL(mode_gemm_kernel, grid, dim3(256), 0, s, p);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

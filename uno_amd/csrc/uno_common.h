@@ -72,6 +72,14 @@ struct ModeGemmParams {
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
 void set_error(const char* fmt, ...);
 
+// RAII timing scope around one kernel launch (no-op unless uno_profile_begin() is active).
+struct ProfScope {
+    int slot;
+    hipStream_t stream;
+    ProfScope(const char* name, double bytes, hipStream_t s);
+    ~ProfScope();
+};
+
 int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);

@@ -1,0 +1,70 @@
+"""Adam with the semantics of the reference's optimiser (Adam.py:27-52), which differ from
+torch.optim.Adam on complex parameters: the second moment is built from g * conj(g) (the squared
+complex modulus, one real number per complex entry), weight decay is the coupled L2 form
+(g += wd * p).  Implemented with multi-tensor (_foreach) ops over real views so a step is a handful
+of launches instead of a Python loop of complex sqrt/addcdiv per parameter."""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+
+class ComplexAdam(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @staticmethod
+    def _real(t):
+        return torch.view_as_real(t) if t.is_complex() else t
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            ps, gs, ms, vs, steps = [], [], [], [], set()
+            cplx = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(self._real(p))
+                    # one real second-moment entry per (possibly complex) parameter entry
+                    st["exp_avg_sq"] = torch.zeros(p.shape, dtype=st["exp_avg"].dtype, device=p.device)
+                st["step"] += 1
+                steps.add(st["step"])
+                ps.append(self._real(p))
+                gs.append(self._real(p.grad))
+                ms.append(st["exp_avg"])
+                vs.append(st["exp_avg_sq"])
+                cplx.append(p.is_complex())
+            if not ps:
+                continue
+            assert len(steps) == 1, "parameters of one group must be stepped together"
+            t = steps.pop()
+            bc1 = 1 - beta1 ** t
+            bc2 = 1 - beta2 ** t
+            if wd != 0:
+                gs = torch._foreach_add(gs, ps, alpha=wd)
+            torch._foreach_mul_(ms, beta1)
+            torch._foreach_add_(ms, gs, alpha=1 - beta1)
+            sq = torch._foreach_mul(gs, gs)
+            sq = [s.sum(-1) if c else s for s, c in zip(sq, cplx)]       # |g|^2 for complex entries
+            torch._foreach_mul_(vs, beta2)
+            torch._foreach_add_(vs, sq, alpha=1 - beta2)
+            denom = torch._foreach_sqrt(vs)
+            torch._foreach_div_(denom, math.sqrt(bc2))
+            torch._foreach_add_(denom, eps)
+            denom = [d.unsqueeze(-1) if c else d for d, c in zip(denom, cplx)]
+            torch._foreach_addcdiv_(ps, ms, denom, value=-lr / bc1)
+        return loss
