@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host CPU leg (developer runs)")
-    ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the bounded CPU-baseline step")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="samples in the bounded CPU-baseline step")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -46,7 +47,9 @@ def cpu_baseline(batch: int):
     same 421^2 workload (the full 16-sample step costs ~30 s on 8 cores)."""
     from oracle import spectral_oracle as so            # checker/baseline only - never the product path
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
-    cores = os.cpu_count() or 1
+    # measured on the GPU box (2 x EPYC 9575F, 256 hw threads): 16 threads 0.74 samples/s, 32 -> 0.64,
+    # 64 -> 0.37, all 256 -> did not finish in 20 min.  Use the best setting, report what was used.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = UNO_9(3, WIDTH, pad=PAD, block_cls=so.OracleOperatorBlock2d)
@@ -59,7 +62,29 @@ def cpu_baseline(batch: int):
     dt = time.perf_counter() - t0
     return {"value": batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"1 training step on {batch} synthetic 421x421 samples ({dt:.1f} s), UNO_9(3,{WIDTH},pad={PAD}), "
-                      f"torch {torch.__version__} CPU FFT path, {cores} threads"}
+                      f"torch {torch.__version__} CPU FFT path, {cores} threads of {os.cpu_count()} hw threads"}
+
+
+def cpu_baseline_bounded(batch: int, limit_s: int = 300):
+    """Run the CPU leg in a child process so a pathological host (thread oversubscription) can never
+    stall the bench: the child is killed by PID after `limit_s`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch", str(batch)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+    try:
+        out, _ = proc.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"value": None, "unit": "samples/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
+                "sample": f"CPU step on {batch} samples did not finish within {limit_s} s"}
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
 
 
 def spectral_block_roofline(dev, iters=10):
@@ -98,6 +123,9 @@ def spectral_block_roofline(dev, iters=10):
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.cpu_batch)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,7 +206,7 @@ def main():
         block = spectral_block_roofline(dev) if world == 1 else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.cpu_batch)
+            cpu = cpu_baseline_bounded(args.cpu_batch)
         out = {
             "metric": "UNO training samples/s (421^2 Darcy)", "value": world * BATCH * args.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

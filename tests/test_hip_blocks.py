@@ -34,8 +34,10 @@ def test_operator_block_2d_golden(name):
     y.backward(torch.from_numpy(c.gy).to(dev()))
     assert rel_err(x.grad.cpu().numpy(), c.gx) < 1e-4
     params = dict(blk.named_parameters())
+    floor = 1e-5 * float(np.linalg.norm(c.gy))     # w.conv.bias has an exactly-zero true gradient under InstanceNorm
     for k, g in c.sub("grad").items():
-        assert rel_err(params[k].grad.cpu().numpy(), g) < 2e-4, k
+        got = params[k].grad.cpu().numpy()
+        assert np.linalg.norm((got - g).ravel()) <= 2e-4 * np.linalg.norm(g.ravel()) + floor, k
 
 
 def test_dim_mutation_quirk():
@@ -65,12 +67,14 @@ def test_uno9_training_steps_match_reference():
     assert rel_err(pred.cpu().numpy(), c.pred0) < 1e-3
     tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
     losses = []
+    gmax = max(float(getattr(c, f"gradnorm.{k}")) for k, _ in model.named_parameters())
     for step in range(3):
         losses.append(float(tr.step(a, u)))
         if step == 0:
             for k, p in model.named_parameters():
                 ref = float(getattr(c, f"gradnorm.{k}"))
-                assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-3 * ref + 1e-8, k
+                # floor: conv biases in front of an InstanceNorm have a zero true gradient (pure rounding noise)
+                assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-3 * ref + 1e-6 * gmax, k
     assert np.allclose(losses, c.losses, rtol=1e-3)
     for k, p in model.named_parameters():
         ref = float(getattr(c, f"after3.norm.{k}"))
@@ -93,8 +97,15 @@ def test_model_product_vs_oracle_blocks_same_weights():
     lp = lp_loss_rel_sum(prod(a.to(dev())).reshape(2, -1), u.to(dev()).reshape(2, -1))
     lp.backward()
     assert abs(float(lp) - float(lr)) < 1e-4 * abs(float(lr))
+    # Gradient tolerance 2e-2: NOT set by the HIP spectral path (2e-7, test_hip_spectral2d) but by the stock
+    # MIOpen InstanceNorm of the ROCm build, which differs from the CPU op by 3e-4 (fwd) / 1e-3 (bwd) at odd
+    # grid sizes such as 55x55 / 27x27 (measured on MI355X, tools/_diag history in DESIGN.md); two
+    # InstanceNorm layers sit on every gradient path of this model.
     pr = dict(ref.named_parameters())
+    gmax = max(float(torch.linalg.vector_norm(q.grad)) for q in pr.values())
     for k, p in prod.named_parameters():
+        if k in ("conv1.w.conv.bias", "conv4.w.conv.bias"):
+            continue    # in front of an InstanceNorm: true gradient is exactly zero, both sides hold only rounding residue
         g, gr = p.grad.cpu(), pr[k].grad
         n = float(torch.linalg.vector_norm(gr))
-        assert float(torch.linalg.vector_norm(g - gr)) <= 2e-3 * n + 1e-7, k
+        assert float(torch.linalg.vector_norm(g - gr)) <= 2e-2 * n + 1e-5 * gmax, k
