@@ -55,6 +55,26 @@ int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const flo
                                  int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1,
                                  int m2, void* stream);
 
+/* SpectralConv3d_Uno.forward - reference integral_operators.py:385-427
+ *   x (B, Ci, H, W, T) f32;  w[0..3] = weights1..4 (Ci, Co, m1, m2, m3) c64 in the reference's corner
+ *   order (lo,lo), (hi,lo), (lo,hi), (hi,hi);  y (B, Co, Ho, Wo, To) f32 [out]
+ *   xtrunc (B, Ci, 4, m1, m2, m3) c64 [out]: truncated rfftn(x, norm="forward"), corner-major. */
+long long uno_spectral_conv3d_fwd_ws_bytes(int B, int Ci, int Co, int H, int Ho, int m1, int m2, int m3);
+long long uno_spectral_conv3d_bwd_ws_bytes(int B, int Ci, int Co, int H, int Ho, int m1, int m2, int m3);
+int uno_spectral_conv3d_forward(const float* x, const float* const* w, float* y, float* xtrunc, void* ws,
+                                int B, int Ci, int Co, int H, int W, int T, int Ho, int Wo, int To,
+                                int m1, int m2, int m3, void* stream);
+/* Adjoint; gx or gw (array of 4 output pointers) may be NULL to skip that gradient. */
+int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const float* const* w, float* gx,
+                                 float* const* gw, void* ws, int B, int Ci, int Co, int H, int W, int T,
+                                 int Ho, int Wo, int To, int m1, int m2, int m3, void* stream);
+
+/* Pruned complex DFT along the leading axis of a 3-D transform:
+ *   inverse = 0: planes (n_img, H, 2*m2*m3) c64 -> corner-major spectrum (n_img, 4, m1, m2, m3) c64
+ *   inverse = 1: the reverse direction (e^{+i...}); mask_overlap applies on the spectrum side. */
+int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3,
+                  float scale, int mask_overlap, void* stream);
+
 /* Stage-level entry points (the three kernels the two calls above are built from). */
 
 /* Pruned forward DFT: spec[img][j][l] = scale * c_l * keep_j * sum x e^{-2 pi i (K_j h/H + l w/W)}

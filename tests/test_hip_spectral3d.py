@@ -1,0 +1,134 @@
+"""Parity of the 3-D HIP spectral convolution (C ABI) vs golden vectors and the dense oracle.  pytest -m gpu
+Tolerance: relative L2 <= 2e-5 (float32 path, measured ~3e-7)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Case, load_cases, rel_err
+from oracle import spectral_oracle as so
+
+Z3, NAMES3 = load_cases("spectral3d.npz")
+ZB, NAMESB = load_cases("blocks.npz")
+TOL = 2e-5
+
+
+def test_later_wins_mask_is_separable():
+    """CPU: the 3-D later-wins mask of the ordered corner writes (integral_operators.py:410-421) factorises
+    into one 1-D mask per axis - what the kernels apply."""
+    for (Ho, Wo, m1, m2) in [(8, 8, 6, 6), (12, 12, 4, 4), (8, 12, 6, 4), (12, 8, 4, 7), (7, 7, 7, 7), (9, 6, 5, 4)]:
+        full = so._keep3d(Ho, Wo, m1, m2)
+        sep = np.outer(so.later_wins_mask(Ho, m1), so.later_wins_mask(Wo, m2))
+        assert np.array_equal(full, sep), (Ho, Wo, m1, m2)
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def corner_major(X, m1, m2):
+    """(B,C,2m1,2m2,m3) -> (B,C,4,m1,m2,m3) in weights1..4 order."""
+    parts = [X[:, :, :m1, :m2], X[:, :, m1:, :m2], X[:, :, :m1, m2:], X[:, :, m1:, m2:]]
+    return np.stack(parts, axis=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES3)
+def test_golden_3d_forward_backward(name):
+    from uno_amd.spectral3d import spectral_conv3d
+    c = Case(Z3, name)
+    meta = [int(v) for v in c.meta]
+    dout = meta[6:9]
+    x = cu(c.x).requires_grad_(True)
+    ws = [cu(getattr(c, f"w{k}")).requires_grad_(True) for k in range(1, 5)]
+    y = spectral_conv3d(x, ws, *dout)
+    assert y.dtype == torch.float32 and tuple(y.shape) == c.y.shape
+    assert rel_err(y.detach().cpu().numpy(), c.y) < TOL
+    y.backward(cu(c.gy))
+    assert rel_err(x.grad.cpu().numpy(), c.gx) < TOL
+    for k in range(4):
+        ref = getattr(c, f"gw{k + 1}")
+        got = ws[k].grad.cpu().numpy()
+        assert rel_err(got, ref) < TOL, k
+        assert np.all(got[ref == 0] == 0)           # overwritten corner entries get exactly zero gradient
+
+
+SEEDED3 = [
+    # B, Ci, Co, (H,W,T), (Ho,Wo,To), (m1,m2,m3)
+    (2, 4, 3, (16, 16, 10), (16, 16, 10), (6, 6, 4)),
+    (1, 8, 8, (32, 32, 13), (24, 24, 15), (11, 11, 5)),
+    (2, 3, 5, (9, 20, 7), (11, 14, 12), (4, 7, 4)),
+    (1, 2, 2, (8, 8, 6), (8, 8, 6), (4, 4, 4)),        # Nyquist bin on T, full rows on H, W
+    (1, 4, 4, (64, 64, 20), (64, 64, 20), (16, 16, 8)),    # BASELINE config 4 geometry (few channels)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", SEEDED3)
+def test_seeded_3d_vs_dense_oracle(cfg):
+    from uno_amd import _native
+    from uno_amd.spectral3d import spectral_conv3d
+    B, Ci, Co, din, dout, modes = cfg
+    rng = np.random.default_rng(B + Ci * 7 + sum(din) + sum(modes))
+    x = rng.standard_normal((B, Ci, *din)).astype(np.float32)
+    sc = (1 / (2 * Ci)) ** 0.5
+    ws = [(sc * (rng.standard_normal((Ci, Co, *modes)) + 1j * rng.standard_normal((Ci, Co, *modes)))).astype(np.complex64)
+          for _ in range(4)]
+    gy = rng.standard_normal((B, Co, *dout)).astype(np.float32)
+    y_ref, X = so.spectral_conv3d_dense(x, ws, *dout)
+    gx_ref, gws_ref, _, _ = so.spectral_conv3d_dense_bwd(gy, X, ws, *din)
+    xd = cu(x).requires_grad_(True)
+    wd = [cu(w).requires_grad_(True) for w in ws]
+    y = spectral_conv3d(xd, wd, *dout)
+    y.backward(cu(gy))
+    assert rel_err(y.detach().cpu().numpy(), y_ref) < TOL
+    assert rel_err(xd.grad.cpu().numpy(), gx_ref) < TOL
+    for k in range(4):
+        assert rel_err(wd[k].grad.cpu().numpy(), gws_ref[k]) < TOL, k
+    # the saved truncated spectrum is rfftn(x, norm="forward") on the corners, corner-major
+    _, xt = _native.spectral_conv3d_forward(cu(x), [cu(w) for w in ws], *dout)
+    assert rel_err(xt.cpu().numpy(), corner_major(X, modes[0], modes[1])) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in NAMESB if n.startswith("b3d_")])
+def test_operator_block_3d_golden(name):
+    from uno_amd.integral_operators import OperatorBlock_3D
+    c = Case(ZB, name)
+    meta = [int(v) for v in c.meta]
+    B, Ci, Co = meta[:3]
+    dout, modes, nrm, nl = meta[6:9], meta[9:12], meta[12], meta[13]
+    blk = OperatorBlock_3D(Ci, Co, *dout, *modes, Normalize=bool(nrm), Non_Lin=bool(nl))
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    blk = blk.to(dev())
+    x = cu(c.x).requires_grad_(True)
+    y = blk(x)
+    assert rel_err(y.detach().cpu().numpy(), c.y) < 1e-4
+    y.backward(cu(c.gy))
+    assert rel_err(x.grad.cpu().numpy(), c.gx) < 2e-4
+    params = dict(blk.named_parameters())
+    floor = 1e-5 * float(np.linalg.norm(c.gy))
+    for k, g in c.sub("grad").items():
+        got = params[k].grad.cpu().numpy()
+        assert np.linalg.norm((got - g).ravel()) <= 2e-4 * np.linalg.norm(g.ravel()) + floor, k
+
+
+@pytest.mark.gpu
+def test_module_3d_interface():
+    from uno_amd.integral_operators import SpectralConv3d_Uno
+    torch.manual_seed(0)
+    conv = SpectralConv3d_Uno(2, 3, 8, 8, 6, 3, 3, 2).to(dev())
+    x = torch.randn(2, 2, 10, 10, 8, device=dev())
+    assert tuple(conv(x).shape) == (2, 3, 8, 8, 6)
+    assert tuple(conv(x, 12, 10, 9).shape) == (2, 3, 12, 10, 9)
+    assert (conv.dim1, conv.dim2, conv.dim3) == (12, 10, 9)
+    with pytest.raises(RuntimeError):
+        conv(x.cpu())
+    with pytest.raises(RuntimeError):
+        conv(x, 2, 10, 9)           # modes1 = 3 > 2 output rows
+    with pytest.raises(RuntimeError):
+        conv(x, 12, 10, 1)          # modes3 = 2 > 1//2+1

@@ -32,6 +32,11 @@ _SIGNATURES = {
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_mode_mix": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
     "uno_mode_wgrad": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 5 + [_fp]),
+    "uno_spectral_conv3d_fwd_ws_bytes": (C.c_longlong, [_i] * 8),
+    "uno_spectral_conv3d_bwd_ws_bytes": (C.c_longlong, [_i] * 8),
+    "uno_spectral_conv3d_forward": (C.c_int, [_fp, C.POINTER(_fp), _fp, _fp, _fp] + [_i] * 12 + [_fp]),
+    "uno_spectral_conv3d_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp), _fp] + [_i] * 12 + [_fp]),
+    "uno_cdft_axis": (C.c_int, [_fp, _fp] + [_i] * 6 + [C.c_float, _i, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -190,6 +195,53 @@ def mode_wgrad(xt, go, weight_shape, ncorner: int):
         rc = lib().uno_mode_wgrad(_ptr(xt), _ptr(go), _ptr_array(gws), B, Ci, Co, ncorner, Mc, _stream(xt))
     _check(rc, "uno_mode_wgrad")
     return gws
+
+
+def spectral_conv3d_forward(x, ws_, Ho: int, Wo: int, To: int):
+    """x (B,Ci,H,W,T) f32, ws_ = [weights1..4] (Ci,Co,m1,m2,m3) c64 -> (y, xtrunc (B,Ci,4,m1,m2,m3) c64)."""
+    _require(x, torch.float32, "x")
+    if len(ws_) != 4:
+        raise RuntimeError("uno_amd: the 3-D spectral convolution takes four weight tensors")
+    for w in ws_:
+        _require(w, torch.complex64, "weights")
+        if tuple(w.shape) != tuple(ws_[0].shape):
+            raise RuntimeError("uno_amd: weights1..4 must have one shape")
+    B, Ci, H, W, T = x.shape
+    Ci2, Co, m1, m2, m3 = ws_[0].shape
+    if Ci2 != Ci:
+        raise RuntimeError(f"uno_amd: weight shape {tuple(ws_[0].shape)} does not match input channels {Ci}")
+    L = lib()
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, Co, Ho, Wo, To), dtype=torch.float32, device=x.device)
+        xt = torch.empty((B, Ci, 4, m1, m2, m3), dtype=torch.complex64, device=x.device)
+        scratch = torch.empty(max(1, L.uno_spectral_conv3d_fwd_ws_bytes(B, Ci, Co, H, Ho, m1, m2, m3)), dtype=torch.uint8,
+                              device=x.device)
+        rc = L.uno_spectral_conv3d_forward(_ptr(x), _ptr_array(ws_), _ptr(y), _ptr(xt), _ptr(scratch), B, Ci, Co,
+                                           H, W, T, Ho, Wo, To, m1, m2, m3, _stream(x))
+    _check(rc, "uno_spectral_conv3d_forward")
+    return y, xt
+
+
+def spectral_conv3d_backward(gy, xt, ws_, H: int, W: int, T: int, need_gx=True, need_gw=True):
+    _require(gy, torch.float32, "grad_output")
+    _require(xt, torch.complex64, "xtrunc")
+    for w in ws_:
+        _require(w, torch.complex64, "weights")
+    B, Co, Ho, Wo, To = gy.shape
+    Ci, Co2, m1, m2, m3 = ws_[0].shape
+    if Co2 != Co:
+        raise RuntimeError("uno_amd: grad_output channels do not match the weights")
+    L = lib()
+    with torch.cuda.device(gy.device):
+        gx = torch.empty((B, Ci, H, W, T), dtype=torch.float32, device=gy.device) if need_gx else None
+        gws = [torch.empty_like(w) for w in ws_] if need_gw else None
+        scratch = torch.empty(max(1, L.uno_spectral_conv3d_bwd_ws_bytes(B, Ci, Co, H, Ho, m1, m2, m3)), dtype=torch.uint8,
+                              device=gy.device)
+        rc = L.uno_spectral_conv3d_backward(_ptr(gy), _ptr(xt), _ptr_array(ws_), _ptr(gx) if need_gx else C.c_void_p(0),
+                                            _ptr_array(gws) if need_gw else None, _ptr(scratch), B, Ci, Co,
+                                            H, W, T, Ho, Wo, To, m1, m2, m3, _stream(gy))
+    _check(rc, "uno_spectral_conv3d_backward")
+    return gx, gws
 
 
 def profile_begin(max_records: int = 100000):

@@ -240,6 +240,98 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
                      reinterpret_cast<float2* const*>(gw), B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream);
 }
 
+int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
+                  int mask_overlap, void* stream) {
+    if (n_img < 0 || H < 1 || m1 < 1 || m1 > H || m2 < 1 || m3 < 1) {
+        set_error("uno_cdft_axis: bad sizes n_img=%d H=%d modes=(%d,%d,%d)", n_img, H, m1, m2, m3);
+        return -1;
+    }
+    if (n_img == 0) return 0;
+    if (!in || !out) { set_error("uno_cdft_axis: null pointer"); return -1; }
+    CdftParams p;
+    p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.C = 2 * m2 * m3; p.m1 = m1; p.m2 = m2; p.m3 = m3;
+    p.scale = scale; p.mask = mask_overlap ? 1 : 0;
+    p.tw = twiddle_table(H);
+    if (!p.tw) return -6;
+    return launch_cdft(p, inverse != 0, (hipStream_t)stream);
+}
+
+static int check_modes3d(const char* who, int H, int W, int T, int Ho, int Wo, int To, int m1, int m2, int m3) {
+    if (H < 1 || W < 1 || T < 1 || Ho < 1 || Wo < 1 || To < 1) { set_error("%s: empty grid", who); return -1; }
+    if (m1 < 1 || m1 > H || m1 > Ho) { set_error("%s: modes1=%d incompatible with axis %d -> %d", who, m1, H, Ho); return -1; }
+    if (m2 < 1 || m2 > W || m2 > Wo) { set_error("%s: modes2=%d incompatible with axis %d -> %d", who, m2, W, Wo); return -1; }
+    if (m3 < 1 || m3 > T / 2 + 1 || m3 > To / 2 + 1) {
+        set_error("%s: modes3=%d incompatible with axis %d -> %d (need modes3 <= n/2+1)", who, m3, T, To);
+        return -1;
+    }
+    return 0;
+}
+
+long long uno_spectral_conv3d_fwd_ws_bytes(int B, int Ci, int Co, int H, int Ho, int m1, int m2, int m3) {
+    const long long C = 2LL * m2 * m3;
+    return 8LL * B * ((long long)Ci * H * C + (long long)Co * Ho * C + 4LL * Co * m1 * m2 * m3);
+}
+
+long long uno_spectral_conv3d_bwd_ws_bytes(int B, int Ci, int Co, int H, int Ho, int m1, int m2, int m3) {
+    const long long C = 2LL * m2 * m3;
+    return 8LL * B * ((long long)Ci * H * C + (long long)Co * Ho * C + 4LL * (Ci + Co) * m1 * m2 * m3);
+}
+
+int uno_spectral_conv3d_forward(const float* x, const float* const* w, float* y, float* xtrunc, void* ws, int B, int Ci,
+                                int Co, int H, int W, int T, int Ho, int Wo, int To, int m1, int m2, int m3, void* stream) {
+    const char* who = "uno_spectral_conv3d_forward";
+    if (B < 0 || Ci < 1 || Co < 1) { set_error("%s: bad sizes B=%d Ci=%d Co=%d", who, B, Ci, Co); return -1; }
+    if (int rc = check_modes3d(who, H, W, T, Ho, Wo, To, m1, m2, m3)) return rc;
+    if (B == 0) return 0;
+    if (!x || !w || !y || !xtrunc || !ws) { set_error("%s: null pointer", who); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const long long C = 2LL * m2 * m3, Mc = (long long)m1 * m2 * m3;
+    float* Z1 = static_cast<float*>(ws);                         // (B*Ci*H, 2 m2, m3) c64
+    float* Z2 = Z1 + 2LL * B * Ci * H * C;                        // (B*Co*Ho, 2 m2, m3) c64
+    float* O5 = Z2 + 2LL * B * Co * Ho * C;                       // (B, Co, 4, m1, m2, m3) c64
+    const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
+    // rfftn over (W, T) plane by plane, then the H axis                       (reference :398)
+    if (int rc = dft2d(false, x, Z1, B * Ci * H, W, T, m2, m3, inv_n, 0, 0, s)) return rc;
+    if (int rc = uno_cdft_axis(Z1, xtrunc, 0, B * Ci, H, m1, m2, m3, 1.0f, 0, stream)) return rc;
+    // four corner einsums "bixyz,ioxyz->boxyz"                                  (reference :410-421)
+    if (int rc = uno_mode_mix(xtrunc, w, O5, 0, B, Ci, Co, 4, (int)Mc, stream)) return rc;
+    // irfftn(out_ft, s=(Ho, Wo, To), norm="forward"); later-wins masks are separable per axis (reference :400-426)
+    if (int rc = uno_cdft_axis(O5, Z2, 1, B * Co, Ho, m1, m2, m3, 1.0f, 1, stream)) return rc;
+    return dft2d(true, Z2, y, B * Co * Ho, Wo, To, m2, m3, 1.0f, 1, 1, s);
+}
+
+int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const float* const* w, float* gx, float* const* gw,
+                                 void* ws, int B, int Ci, int Co, int H, int W, int T, int Ho, int Wo, int To, int m1,
+                                 int m2, int m3, void* stream) {
+    const char* who = "uno_spectral_conv3d_backward";
+    if (B < 0 || Ci < 1 || Co < 1) { set_error("%s: bad sizes B=%d Ci=%d Co=%d", who, B, Ci, Co); return -1; }
+    if (int rc = check_modes3d(who, H, W, T, Ho, Wo, To, m1, m2, m3)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long long C = 2LL * m2 * m3, Mc = (long long)m1 * m2 * m3;
+    if (B == 0) {
+        if (gw)
+            for (int c = 0; c < 4; ++c)
+                if (hipMemsetAsync(gw[c], 0, 8ULL * Ci * Co * Mc, s) != hipSuccess) { set_error("memset failed"); return -5; }
+        return 0;
+    }
+    if (!gy || !xtrunc || !w || !ws) { set_error("%s: null pointer", who); return -1; }
+    float* Z1 = static_cast<float*>(ws);
+    float* Z2 = Z1 + 2LL * B * Ci * H * C;
+    float* gO = Z2 + 2LL * B * Co * Ho * C;
+    float* gX = gO + 2LL * B * Co * 4 * Mc;
+    if (int rc = dft2d(false, gy, Z2, B * Co * Ho, Wo, To, m2, m3, 1.0f, 1, 1, s)) return rc;
+    if (int rc = uno_cdft_axis(Z2, gO, 0, B * Co, Ho, m1, m2, m3, 1.0f, 1, stream)) return rc;
+    if (gw)
+        if (int rc = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, stream)) return rc;
+    if (gx) {
+        if (int rc = uno_mode_mix(gO, w, gX, 1, B, Ci, Co, 4, (int)Mc, stream)) return rc;
+        if (int rc = uno_cdft_axis(gX, Z1, 1, B * Ci, H, m1, m2, m3, 1.0f, 0, stream)) return rc;
+        const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
+        if (int rc = dft2d(true, Z1, gx, B * Ci * H, W, T, m2, m3, inv_n, 0, 0, s)) return rc;
+    }
+    return 0;
+}
+
 int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
                                 int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_forward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }

@@ -69,6 +69,16 @@ struct ModeGemmParams {
     int M, N, K, ncorner, Mc;
 };
 
+// Pruned complex DFT along the leading axis of (n_img, H, C) <-> corner-major (n_img, 4, m1, m2, m3).
+struct CdftParams {
+    const float* in;
+    float* out;
+    const float2* tw;       // twiddles of length H
+    int n_img, H, C, m1, m2, m3;
+    float scale;
+    int mask;               // zero lo-corner rows overwritten by the hi corner (on the spectrum side)
+};
+
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
 void set_error(const char* fmt, ...);
 
@@ -83,5 +93,6 @@ struct ProfScope {
 int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
+int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 
 }  // namespace uno
