@@ -22,16 +22,22 @@
 
 namespace uno {
 
-constexpr int TAILMAX = 9;      // tail <= 31 pairs + w=0 + Nyquist column = 33 elements = 9 k-steps
+constexpr int TAILMAX = 5;      // tail <= 15 pairs + w=0 + Nyquist column = 17 elements = 5 k-steps
 
+// waves per SIMD the register allocator is asked to fit (accumulators: 8 NT MT for X + 8 NT for T)
 template <int NT, int MT>
-__global__ __launch_bounds__(256) void dft2d_fwd_kernel(Dft2dParams p) {
+constexpr int fwd_waves_per_simd() {
+    constexpr int acc = 8 * NT * MT + 8 * NT;
+    return acc <= 16 ? 4 : (acc <= 48 ? 3 : (acc <= 104 ? 2 : 1));
+}
+
+template <int NT, int MT, bool VEC>
+__global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd_kernel(Dft2dParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, W = p.W, m1 = p.m1, m2 = p.m2;
     float2* sTwW = reinterpret_cast<float2*>(smem);
     float2* sTwH = sTwW + W;
-    unsigned* sTail = reinterpret_cast<unsigned*>(sTwH + H);        // [TAILMAX][NT][64] byte offsets
-    float* sRed = reinterpret_cast<float*>(sTail + TAILMAX * NT * 64);
+    float* sRed = reinterpret_cast<float*>(sTwH + H);
 
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -44,32 +50,24 @@ __global__ __launch_bounds__(256) void dft2d_fwd_kernel(Dft2dParams p) {
 
     // column-pair bookkeeping: pairs (w, W-w), w = 1..P; singles w = 0 and (W even) w = W/2
     const int P = (W - 1) >> 1;
-    const int nfull = P >> 5;                   // chunks of 32 pairs handled by the vector path
-    const int prem = P - (nfull << 5);
+    const int nfull = P >> 4;                   // chunks of 16 pairs handled by the vector path
+    const int prem = P - (nfull << 4);
     const int ntail = prem + 1 + ((W & 1) ? 0 : 1);
     const int tailsteps = (ntail + 3) >> 2;
 
     for (int n = tid; n < W; n += nthreads) sTwW[n] = p.twW[n];
     for (int n = tid; n < H; n += nthreads) sTwH[n] = p.twH[n];
-    for (int e = tid; e < TAILMAX * NT * 64; e += nthreads) {
-        const int ln = e & 63, t = (e >> 6) % NT, s = e / (64 * NT);
-        const int q = 4 * s + (ln >> 4);
-        int w = 0;
-        if (q < prem) w = 1 + 32 * nfull + q;
-        else if (q == prem + 1 && !(W & 1)) w = W >> 1;
-        const int l = min(16 * t + (ln & 15), m2 - 1);
-        sTail[e] = 8u * (unsigned)(((long long)w * l) % W);
-    }
     __syncthreads();
 
-    // per-lane twiddle walk state for the vector path (B operand: k = kk, column = mode l)
+    // per-lane twiddle walk of the vector path (B operand: k-slot kk, column = mode l): this lane owns
+    // column pairs w = 1 + 16 c + 4 kk + s, s = 0..3, of chunk c
     unsigned idx0[NT], stepL[NT], jump[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int l = min(16 * t + r16, m2 - 1);
-        idx0[t] = 8u * (unsigned)(((1 + 8 * kk) * l) % W);
+        idx0[t] = 8u * (unsigned)(((1 + 4 * kk) * l) % W);
         stepL[t] = 8u * (unsigned)l;
-        jump[t] = 8u * (unsigned)((24 * l) % W);
+        jump[t] = 8u * (unsigned)((13 * l) % W);      // step from the last column pair of a chunk to the first of the next
     }
     // stage-B A operand rows (corner rows) owned by this lane
     int Kj[MT];
@@ -90,94 +88,157 @@ __global__ __launch_bounds__(256) void dft2d_fwd_kernel(Dft2dParams p) {
     const float* img = p.in + (size_t)blockIdx.x * H * W;
     const int nrt = (H + 15) >> 4;
 
-    float L[8], R[8], Ln[8], Rn[8];
+    // Ring of four chunk buffers: chunk c of a row tile lives in buffer c & 3, loads run three chunks ahead.
+    // Every load below is UNCONDITIONAL (chunk / row indices are clamped instead of branched around) so the
+    // compiler can count outstanding loads and emit s_waitcnt vmcnt(N) with N > 0; a load under a branch
+    // makes it fall back to vmcnt(0), which would expose the full HBM latency once per chunk.
+    f4u bl[4], br[4];
     auto row_ptr = [&](int rt) { return img + (size_t)min(rt * 16 + r16, H - 1) * W; };
-    auto load_chunk = [&](float (&l)[8], float (&r)[8], const float* xr, int c) {
-        const int a = 32 * c + 8 * kk;
-        const f4u l0 = *reinterpret_cast<const f4u*>(xr + 1 + a);
-        const f4u l1 = *reinterpret_cast<const f4u*>(xr + 5 + a);
-        const f4u r0 = *reinterpret_cast<const f4u*>(xr + W - 8 - a);
-        const f4u r1 = *reinterpret_cast<const f4u*>(xr + W - 4 - a);
+    const int clast = max(nfull - 1, 0);
+#define UNO_LOAD_CHUNK(buf, xr, c)                                                        \
+    do {                                                                                  \
+        const int a_ = 16 * min((c), clast) + 4 * kk;                                     \
+        bl[buf] = *reinterpret_cast<const f4u*>((xr) + 1 + a_);                           \
+        br[buf] = *reinterpret_cast<const f4u*>((xr) + W - 4 - a_);                       \
+        __builtin_amdgcn_sched_barrier(0);  /* keep the prefetch where it is issued */    \
+    } while (0)
+
+    // tail element of k-step s owned by this lane (-1 = none) and its twiddle index per mode tile
+    int tlw[TAILMAX], trw[TAILMAX];
+    unsigned tailidx[TAILMAX][NT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { l[s] = l0.v[s]; l[4 + s] = l1.v[s]; r[s] = r0.v[s]; r[4 + s] = r1.v[s]; }
-    };
+    for (int s = 0; s < TAILMAX; ++s) {
+        const int q = 4 * s + kk;
+        const bool pair = q < prem;
+        const bool nyq = (q == prem + 1) && !(W & 1);
+        const int w = pair ? 1 + 16 * nfull + q : (nyq ? (W >> 1) : 0);
+        tlw[s] = (pair || q == prem || nyq) ? w : -1;
+        trw[s] = pair ? W - w : -1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tailidx[s][t] = 8u * (unsigned)(((long long)w * (stepL[t] >> 3)) % W);
+    }
 
     int rt = wave;
-    if (rt < nrt && nfull > 0) load_chunk(L, R, row_ptr(rt), 0);
+    if constexpr (VEC) {
+        const float* xr0 = row_ptr(min(rt, nrt - 1));
+        UNO_LOAD_CHUNK(0, xr0, 0);
+        UNO_LOAD_CHUNK(1, xr0, 1);
+        UNO_LOAD_CHUNK(2, xr0, 2);
+    }
 
     for (; rt < nrt; rt += NW) {
         const float* xr = row_ptr(rt);
-        // tail elements: issued early, consumed after the vector chunks
         float TL[TAILMAX], TR[TAILMAX];
 #pragma unroll
         for (int s = 0; s < TAILMAX; ++s) {
-            TL[s] = 0.f; TR[s] = 0.f;
-            if (s < tailsteps) {
-                const int q = 4 * s + kk;
-                if (q < prem) {
-                    const int w = 1 + 32 * nfull + q;
-                    TL[s] = xr[w]; TR[s] = xr[W - w];
-                } else if (q == prem) {
-                    TL[s] = xr[0];
-                } else if (q == prem + 1 && !(W & 1)) {
-                    TL[s] = xr[W >> 1];
-                }
-            }
+            const float vl = xr[max(tlw[s], 0)];
+            const float vr = xr[max(trw[s], 0)];
+            TL[s] = tlw[s] >= 0 ? vl : 0.f;
+            TR[s] = trw[s] >= 0 ? vr : 0.f;
         }
 
         f32x4 Tr[NT], Tn[NT];           // Tn = -Im T
-        unsigned idx[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { Tr[t] = f32x4{0, 0, 0, 0}; Tn[t] = f32x4{0, 0, 0, 0}; idx[t] = idx0[t]; }
+        for (int t = 0; t < NT; ++t) { Tr[t] = f32x4{0, 0, 0, 0}; Tn[t] = f32x4{0, 0, 0, 0}; }
 
-        for (int c = 0; c < nfull; ++c) {
-            if (c + 1 < nfull) load_chunk(Ln, Rn, xr, c + 1);
-            else if (rt + NW < nrt) load_chunk(Ln, Rn, row_ptr(rt + NW), 0);
+        if constexpr (VEC) {
+            // software-pipelined twiddle gather: tw = twiddles of the step being multiplied, idx = table
+            // offset of the step after it (LDS latency hides behind the current step's MFMAs)
+            unsigned idx[NT];
+            float2 tw[NT];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float E = L[s] + R[7 - s];
-                const float D = L[s] - R[7 - s];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float2 tw = lds_tw(sTwW, idx[t]);
-                    Tr[t] = mfma16(E, tw.x, Tr[t]);
-                    Tn[t] = mfma16(D, tw.y, Tn[t]);
-                    idx[t] = wrap_add(idx[t], stepL[t], W8);
-                }
+            for (int t = 0; t < NT; ++t) {
+                tw[t] = lds_tw(sTwW, idx0[t]);
+                idx[t] = wrap_add(idx0[t], stepL[t], W8);
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) idx[t] = wrap_add(idx[t], jump[t], W8);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { L[s] = Ln[s]; R[s] = Rn[s]; }
+#define UNO_COMPUTE_CHUNK(buf)                                                            \
+    do {                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                   \
+            const float E = bl[buf].v[s] + br[buf].v[3 - s];                              \
+            const float D = bl[buf].v[s] - br[buf].v[3 - s];                              \
+            float2 twn[NT];                                                               \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                              \
+                twn[t] = lds_tw(sTwW, idx[t]);                                            \
+                idx[t] = wrap_add(idx[t], s == 2 ? jump[t] : stepL[t], W8);               \
+            }                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                              \
+                Tr[t] = mfma16(E, tw[t].x, Tr[t]);                                        \
+                Tn[t] = mfma16(D, tw[t].y, Tn[t]);                                        \
+            }                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) tw[t] = twn[t];                \
+        }                                                                                 \
+    } while (0)
+
+            int c = 0;
+            for (; c + 4 <= nfull; c += 4) {
+                UNO_LOAD_CHUNK(3, xr, c + 3);
+                UNO_COMPUTE_CHUNK(0);
+                UNO_LOAD_CHUNK(0, xr, c + 4);
+                UNO_COMPUTE_CHUNK(1);
+                UNO_LOAD_CHUNK(1, xr, c + 5);
+                UNO_COMPUTE_CHUNK(2);
+                UNO_LOAD_CHUNK(2, xr, c + 6);
+                UNO_COMPUTE_CHUNK(3);
+            }
+            // 0..3 remaining chunks are already in buffers 0..2 (prefetched by the last group / the row prologue)
+            const int rem = nfull - c;
+            if (rem > 0) UNO_COMPUTE_CHUNK(0);
+            if (rem > 1) UNO_COMPUTE_CHUNK(1);
+            if (rem > 2) UNO_COMPUTE_CHUNK(2);
         }
+        {
+            float2 twt[NT];
 #pragma unroll
-        for (int s = 0; s < TAILMAX; ++s) {
-            if (s < tailsteps) {
-                const float E = TL[s] + TR[s];
-                const float D = TL[s] - TR[s];
+            for (int t = 0; t < NT; ++t) twt[t] = lds_tw(sTwW, tailidx[0][t]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float2 tw = lds_tw(sTwW, sTail[(s * NT + t) * 64 + lane]);
-                    Tr[t] = mfma16(E, tw.x, Tr[t]);
-                    Tn[t] = mfma16(D, tw.y, Tn[t]);
+            for (int s = 0; s < TAILMAX; ++s) {
+                float2 twn[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) twn[t] = lds_tw(sTwW, tailidx[s + 1 < TAILMAX ? s + 1 : s][t]);
+                if (s < tailsteps) {
+                    const float E = TL[s] + TR[s];
+                    const float D = TL[s] - TR[s];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        Tr[t] = mfma16(E, twt[t].x, Tr[t]);
+                        Tn[t] = mfma16(D, twt[t].y, Tn[t]);
+                    }
                 }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) twt[t] = twn[t];
             }
+        }
+        if constexpr (VEC) {
+            // all buffers are free: start the next row tile's first chunks, they land during stage B
+            const float* xn = row_ptr(min(rt + NW, nrt - 1));
+            UNO_LOAD_CHUNK(0, xn, 0);
+            UNO_LOAD_CHUNK(1, xn, 1);
+            UNO_LOAD_CHUNK(2, xn, 2);
         }
 
         // stage B: X[j][l] += exp(-i theta(j,h)) * T[h][l], h = 16 rt + 4 kk + s
         unsigned idxB[MT];
+        float2 twB[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            idxB[mt] = 8u * (unsigned)(((long long)Kj[mt] * (16 * rt + 4 * kk)) % H);
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned i0 = 8u * (unsigned)(((long long)Kj[mt] * (16 * rt + 4 * kk)) % H);
+            twB[mt] = lds_tw(sTwH, i0);
+            idxB[mt] = wrap_add(i0, 8u * (unsigned)Kj[mt], H8);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool hvalid = (16 * rt + 4 * kk + s) < H;
+            float2 twBn[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float2 tw = lds_tw(sTwH, idxB[mt]);
+                twBn[mt] = lds_tw(sTwH, idxB[mt]);
+                idxB[mt] = wrap_add(idxB[mt], 8u * (unsigned)Kj[mt], H8);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
                 const bool v = hvalid && jvalid[mt];
-                const float ac = v ? tw.x : 0.f;
-                const float ans = v ? -tw.y : 0.f;
+                const float ac = v ? twB[mt].x : 0.f;
+                const float ans = v ? -twB[mt].y : 0.f;
                 const float anc = -ac;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -186,10 +247,13 @@ __global__ __launch_bounds__(256) void dft2d_fwd_kernel(Dft2dParams p) {
                     Xr[mt][t] = mfma16(ans, Tn[t][s], Xr[mt][t]);
                     Xi[mt][t] = mfma16(ans, Tr[t][s], Xi[mt][t]);
                 }
-                idxB[mt] = wrap_add(idxB[mt], 8u * (unsigned)Kj[mt], H8);
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) twB[mt] = twBn[mt];
         }
     }
+#undef UNO_LOAD_CHUNK
+#undef UNO_COMPUTE_CHUNK
 
     // deterministic tree reduction of the per-wave partial spectra through LDS
     constexpr int NACC = MT * NT * 8;
@@ -244,14 +308,14 @@ __global__ __launch_bounds__(256) void dft2d_fwd_kernel(Dft2dParams p) {
     }
 }
 
-template <int NT, int MT>
+template <int NT, int MT, bool VEC>
 static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
     const int nrt = (p.H + 15) / 16;
     const int NW = nrt >= 4 ? 4 : (nrt >= 2 ? 2 : 1);
     const size_t red = (size_t)(NW / 2) * MT * NT * 8 * 64 * sizeof(float);
-    const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)TAILMAX * NT * 64 * 4 + red;
+    const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + red;
     if (lds > 160 * 1024) { set_error("dft2d_fwd: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
-    auto k = dft2d_fwd_kernel<NT, MT>;
+    auto k = dft2d_fwd_kernel<NT, MT, VEC>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", lds);
@@ -271,7 +335,8 @@ static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
 
 int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s) {
     const int NT = (p.m2 + 15) / 16, MT = (2 * p.m1 + 15) / 16;
-#define UNO_CASE(nt, mt) if (NT == nt && MT == mt) return launch_fwd_t<nt, mt>(p, s);
+    const bool vec = ((p.W - 1) >> 1) >= 16;       // at least one full chunk of 16 column pairs
+#define UNO_CASE(nt, mt) if (NT == nt && MT == mt) return vec ? launch_fwd_t<nt, mt, true>(p, s) : launch_fwd_t<nt, mt, false>(p, s);
     UNO_CASE(1, 1) UNO_CASE(1, 2) UNO_CASE(1, 3) UNO_CASE(1, 4) UNO_CASE(1, 5)
     UNO_CASE(2, 1) UNO_CASE(2, 2) UNO_CASE(2, 3) UNO_CASE(2, 4) UNO_CASE(2, 5)
     UNO_CASE(3, 1) UNO_CASE(3, 2) UNO_CASE(3, 3) UNO_CASE(3, 4) UNO_CASE(3, 5)
