@@ -10,24 +10,45 @@
 //   stage B' (columns): U^T[l][h] = sum_j O[l][j] exp(+i theta(j,h)):  M = modes, N = the tile's 16
 //     rows, K = corner rows.  The O operand is loaded once per image into registers (A operand); the
 //     mode <-> M-row assignment is permuted (row 4g+r computes mode 4r+g) so that ...
-//   stage A' (rows): ... the stage-B' accumulators are directly the A operand of the row transform
-//     (k-step s, lane group kk <-> mode 4s+kk).  Symmetric form: Ey = sum Ur cos, Dy = sum Ui sin over
-//     w <= W/2, then y[w] = Ey - Dy and y[W-w] = Ey + Dy: half the flops, no padding waste in K.
+//   stage A' (rows): ... the stage-B' accumulators are directly the B operand of the row transform
+//     (k-step s, lane group kk <-> mode 4s+kk), with the twiddles as A operand: D[w][h], i.e. every lane
+//     ends up with FOUR CONSECUTIVE COLUMNS of one row.  Symmetric form: Ey = sum Ur cos, Dy = sum Ui sin
+//     over w <= W/2, then y[w] = Ey - Dy and y[W-w] = Ey + Dy: half the flops, no padding waste in K.
+//   stores: a scattered 16-rows-per-instruction store pattern costs more than all the MFMAs (measured:
+//     117 of 295 us), so each wave stages 64-column chunks of its 16 rows (left half and mirrored half)
+//     in a private LDS buffer (ds_write_b128) and writes them out as 256-byte row segments with
+//     16-byte-per-lane stores.
 #include "uno_common.h"
 #include <cstdio>
 
+#ifndef UNO_ABLATE
+#define UNO_ABLATE 0        // developer ablation builds only (tools/ablate.sh); 0 = product
+#endif
+
 namespace uno {
 
+constexpr int STG_COLS = 64;            // columns per staged chunk (4 MFMA column tiles)
+constexpr int STG_RS = STG_COLS + 4;    // LDS row stride in floats: 16-byte aligned, 4-bank skew per row
+
 template <int NT, int JT>
-__global__ __launch_bounds__(256) void dft2d_inv_kernel(Dft2dParams p) {
+constexpr int inv_waves_per_simd() {
+    // resident O operand (8 NT JT) + U accumulators and twiddle walk state (36 NT) + addressing etc.
+    constexpr int regs = 8 * NT * JT + 36 * NT + 40;
+    return regs <= 120 ? 4 : (regs <= 160 ? 3 : (regs <= 230 ? 2 : 1));
+}
+
+template <int NT, int JT>
+__global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv_kernel(Dft2dParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, W = p.W, m1 = p.m1, m2 = p.m2;
-    float2* sTwW = reinterpret_cast<float2*>(smem);
-    float2* sTwH = sTwW + W;
-
+    float* sStage = reinterpret_cast<float*>(smem);                       // [NW][2][16][STG_RS]
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const int NW = nthreads >> 6;
+    float2* sTwW = reinterpret_cast<float2*>(sStage + NW * 2 * 16 * STG_RS);
+    float2* sTwH = sTwW + W;
+    unsigned* sIdxA0 = reinterpret_cast<unsigned*>(sTwH + H);          // [4 NT][64]: start of the stage-A' twiddle walk
+
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int r16 = lane & 15;
@@ -56,72 +77,124 @@ __global__ __launch_bounds__(256) void dft2d_inv_kernel(Dft2dParams p) {
             Oi[t][ks] = v.y * cs;
         }
     }
-    // stage-A' twiddle walk: k-step sp covers mode l = 4 sp + kk at column w = 16 wt + r16
-    unsigned idxA0[KSA], stepA[KSA];
+    // stage-A' twiddle walk (A operand): lane (i = r16 -> column w = 16 wt + r16, k-slot kk -> mode 4 sp + kk)
+    unsigned stepA[KSA];
 #pragma unroll
     for (int sp = 0; sp < KSA; ++sp) {
-        const int l = min(4 * sp + kk, m2 - 1);
-        idxA0[sp] = 8u * (unsigned)((l * r16) % W);
-        stepA[sp] = 8u * (unsigned)((16 * l) % W);
+        const unsigned l = (unsigned)min(4 * sp + kk, m2 - 1);
+        stepA[sp] = 8u * ((16u * l) % (unsigned)W);
+    }
+    for (int e = tid; e < KSA * 64; e += nthreads) {
+        const unsigned l = (unsigned)min(4 * (e >> 6) + ((e & 63) >> 4), m2 - 1);
+        sIdxA0[e] = 8u * ((l * (unsigned)(e & 15)) % (unsigned)W);
     }
     __syncthreads();
 
     float* img = p.out + (size_t)blockIdx.x * H * W;
     const int nrt = (H + 15) >> 4;
-    const int NE = (W >> 1) + 1;                // columns 0..W/2 are computed, the rest mirrored
-    const int nwt = (NE + 15) >> 4;
+    const int Wh = W >> 1;                      // columns 0..Wh are computed, Wh+1..W-1 are their mirror images
+    const int nwt = (Wh + 16) >> 4;             // 16-column tiles covering 0..Wh
+    const int nchunk = (nwt + 3) >> 2;
+    float* stL = sStage + (size_t)wave * 2 * 16 * STG_RS;     // this wave's left-half chunk  [16][STG_RS]
+    float* stR = stL + 16 * STG_RS;                            // mirrored-half chunk
 
     for (int rt = wave; rt < nrt; rt += NW) {
-        // ---- stage B': B operand = exp(+i theta), theta = 2 pi K_j h / H, lane: k = kk (j = 4ks+kk), col = h
-        const int hB = min(16 * rt + r16, H - 1);
-        const unsigned a4 = 8u * (unsigned)((4 * hB) % H);               // advance of (j h mod H) per k-step
-        const unsigned b2 = 8u * (unsigned)(((long long)2 * m1 * hB) % H);   // (2 m1 h) mod H
-        unsigned aj = 8u * (unsigned)((kk * hB) % H);                    // (j h) mod H, j = kk
+        // ---- stage B': B operand = exp(+i theta), theta = 2 pi K_j h / H, lane: k-slot kk (j = 4ks+kk), col = h
+        const unsigned hB = (unsigned)min(16 * rt + r16, H - 1);
+        const unsigned a4 = 8u * ((4u * hB) % (unsigned)H);               // advance of (j h mod H) per k-step
+        const unsigned b2 = 8u * ((2u * (unsigned)m1 * hB) % (unsigned)H);  // (2 m1 h) mod H
+        unsigned aj = 8u * (((unsigned)kk * hB) % (unsigned)H);          // (j h) mod H, j = kk
         f32x4 Ur[NT], Ui[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Ur[t] = f32x4{0, 0, 0, 0}; Ui[t] = f32x4{0, 0, 0, 0}; }
+        float2 twb = lds_tw(sTwH, (kk >= m1) ? wrap_sub(aj, b2, H8) : aj);
 #pragma unroll
         for (int ks = 0; ks < KSJ; ++ks) {
-            const int j = 4 * ks + kk;
-            // K_j = j for the lo corner, j - 2 m1 (mod H) for the hi corner
-            const unsigned id = (j >= m1) ? wrap_sub(aj, b2, H8) : aj;
-            const float2 tw = lds_tw(sTwH, id);
-            const float ns = -tw.y;
+            // prefetch the next k-step's twiddle: K_j = j (lo corner) or j - 2 m1 mod H (hi corner)
+            aj = wrap_add(aj, a4, H8);
+            const int jn = 4 * (ks + 1) + kk;
+            const float2 twn = lds_tw(sTwH, (jn >= m1) ? wrap_sub(aj, b2, H8) : aj);
+            const float ns = -twb.y;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                Ur[t] = mfma16(Or[t][ks], tw.x, Ur[t]);
-                Ui[t] = mfma16(Or[t][ks], tw.y, Ui[t]);
+                Ur[t] = mfma16(Or[t][ks], twb.x, Ur[t]);
+                Ui[t] = mfma16(Or[t][ks], twb.y, Ui[t]);
                 Ur[t] = mfma16(Oi[t][ks], ns, Ur[t]);
-                Ui[t] = mfma16(Oi[t][ks], tw.x, Ui[t]);
+                Ui[t] = mfma16(Oi[t][ks], twb.x, Ui[t]);
             }
-            aj = wrap_add(aj, a4, H8);
+            twb = twn;
         }
 
-        // ---- stage A': per 16-column tile, K = modes
+        // ---- stage A': D[w][h] = sum_modes tw[w][mode] * U[mode][h]; lane (h = r16, g = kk) gets columns 4g..4g+3
         unsigned idxA[KSA];
+        float2 twa[KSA];
+        asm volatile("" ::: "memory");          // keep the loop-invariant table read below inside the loop (register pressure)
 #pragma unroll
-        for (int sp = 0; sp < KSA; ++sp) idxA[sp] = idxA0[sp];
-        for (int wt = 0; wt < nwt; ++wt) {
-            f32x4 Ey = f32x4{0, 0, 0, 0}, Dy = f32x4{0, 0, 0, 0};
+        for (int sp = 0; sp < KSA; ++sp) {
+            const unsigned i0 = sIdxA0[sp * 64 + lane];
+            twa[sp] = lds_tw(sTwW, i0);
+            idxA[sp] = wrap_add(i0, stepA[sp], W8);
+        }
+        for (int ch = 0; ch < nchunk; ++ch) {
 #pragma unroll
-            for (int sp = 0; sp < KSA; ++sp) {
-                if (sp < ksa) {
-                    const float2 tw = lds_tw(sTwW, idxA[sp]);
-                    Ey = mfma16(Ur[sp >> 2][sp & 3], tw.x, Ey);
-                    Dy = mfma16(Ui[sp >> 2][sp & 3], tw.y, Dy);
-                    idxA[sp] = wrap_add(idxA[sp], stepA[sp], W8);
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int wt = 4 * ch + t4;
+                if (wt < nwt) {
+                    float2 twn[KSA];
+#pragma unroll
+                    for (int sp = 0; sp < KSA; ++sp) {
+                        if (sp < ksa) {
+                            twn[sp] = (UNO_ABLATE & 1) ? twa[sp] : lds_tw(sTwW, idxA[sp]);
+                            idxA[sp] = wrap_add(idxA[sp], stepA[sp], W8);
+                        }
+                    }
+                    f32x4 Ey = f32x4{0, 0, 0, 0}, Dy = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int sp = 0; sp < KSA; ++sp) {
+                        if (sp < ksa) {
+                            Ey = mfma16(twa[sp].x, Ur[sp >> 2][sp & 3], Ey);
+                            Dy = mfma16(twa[sp].y, Ui[sp >> 2][sp & 3], Dy);
+                        }
+                    }
+#pragma unroll
+                    for (int sp = 0; sp < KSA; ++sp)
+                        if (sp < ksa) twa[sp] = twn[sp];
+                    // stage: left columns ascending, mirrored columns (W - w) ascending == w descending
+                    const f32x4 yl = Ey - Dy;
+                    const f32x4 yr = Ey + Dy;
+                    *reinterpret_cast<f32x4*>(stL + r16 * STG_RS + 16 * t4 + 4 * kk) = yl;
+                    *reinterpret_cast<f32x4*>(stR + r16 * STG_RS + 60 - 16 * t4 - 4 * kk) = f32x4{yr[3], yr[2], yr[1], yr[0]};
                 }
             }
-            const int w = 16 * wt + r16;
-            const bool lv = w < NE;
-            const bool rv = lv && w >= 1 && 2 * w != W;
+            // write the chunk out: pass q covers rows 4q..4q+3, each 16-lane group one 256-byte row segment
+            const int c0 = STG_COLS * ch;                   // left chunk = columns c0 .. c0+63
+            const int cr0 = W - c0 - (STG_COLS - 1);        // mirrored chunk = columns cr0 .. cr0+63  (= W - w)
+            if (!(UNO_ABLATE & 2)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int h = 16 * rt + 4 * kk + r;
-                if (h < H) {
-                    float* row = img + (size_t)h * W;
-                    if (lv) row[w] = Ey[r] - Dy[r];
-                    if (rv) row[W - w] = Ey[r] + Dy[r];
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 4 * q + kk;
+                    const int h = 16 * rt + row;
+                    const f32x4 vl = *reinterpret_cast<const f32x4*>(stL + row * STG_RS + 4 * r16);
+                    const f32x4 vr = *reinterpret_cast<const f32x4*>(stR + row * STG_RS + 4 * r16);
+                    if (h < H) {
+                        float* rowp = img + (size_t)h * W;
+                        const int cl = c0 + 4 * r16;        // first of this lane's four left columns
+                        if (cl + 3 <= Wh) {
+                            *reinterpret_cast<f4u*>(rowp + cl) = f4u{{vl[0], vl[1], vl[2], vl[3]}};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (cl + e <= Wh) rowp[cl + e] = vl[e];
+                        }
+                        const int cr = cr0 + 4 * r16;       // mirrored columns must stay in (Wh, W-1]
+                        if (cr > Wh && cr + 3 < W) {
+                            *reinterpret_cast<f4u*>(rowp + cr) = f4u{{vr[0], vr[1], vr[2], vr[3]}};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (cr + e > Wh && cr + e < W) rowp[cr + e] = vr[e];
+                        }
+                    }
                 }
             }
         }
@@ -131,8 +204,8 @@ __global__ __launch_bounds__(256) void dft2d_inv_kernel(Dft2dParams p) {
 template <int NT, int JT>
 static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
     const int nrt = (p.H + 15) / 16;
-    const int NW = nrt >= 4 ? 4 : (nrt >= 2 ? 2 : 1);
-    const size_t lds = (size_t)(p.W + p.H) * sizeof(float2);
+    const int NW = pick_waves_per_image(nrt);
+    const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)NW * 2 * 16 * STG_RS * sizeof(float) + (size_t)4 * NT * 64 * 4;
     if (lds > 160 * 1024) { set_error("dft2d_inv: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
     auto k = dft2d_inv_kernel<NT, JT>;
     if (lds > 64 * 1024) {

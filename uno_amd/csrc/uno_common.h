@@ -43,6 +43,20 @@ __host__ __device__ __forceinline__ int corner_freq(int j, int m, int N) { retur
 // "Later slice-assignment wins": lo-corner row j is overwritten by the hi corner when j >= N - m.
 __host__ __device__ __forceinline__ bool row_survives(int j, int m, int N) { return j >= m || j < N - m; }
 
+// Waves per image (workgroup size / 64) for the row-tiled DFT kernels: the 16-row tiles of an image are
+// dealt round-robin to the waves, so pick the count in {4, 3, 2, 1} that leaves the fewest idle tile slots
+// (421 rows = 27 tiles -> 3 waves x 9; 446 rows = 28 tiles -> 4 x 7), preferring more waves on a tie.
+inline int pick_waves_per_image(int n_row_tiles) {
+    int best = 1, best_waste = 1 << 30;
+    for (int nw = 4; nw >= 1; --nw) {
+        if (nw > n_row_tiles) continue;
+        const int per = (n_row_tiles + nw - 1) / nw;
+        const int waste = (per * nw - n_row_tiles) * 12 / nw;      // idle slots, normalised to 12 waves
+        if (waste < best_waste) { best_waste = waste; best = nw; }
+    }
+    return best;
+}
+
 struct Dft2dParams {
     const float* in;        // forward: images (n_img, H, W) f32; inverse: spectra (n_img, 2*m1, m2) c64
     float* out;             // forward: spectra; inverse: images
