@@ -100,6 +100,14 @@ int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co,
                    int ncorner, int modes_per_corner, void* stream);
 
+/* Separable banded resampling out = A . in . B^T of n_img images (H, W) -> (Ho, Wo): the resampling half of
+ * pointwise_op_2D (reference integral_operators.py:240-242, bicubic / align_corners / antialias) and, with the
+ * transposed band tables, its adjoint.  Row i of A has its first nonzero at column startH[i] and KH weights
+ * wtH[i*KH .. i*KH+KH-1] (zero padded); likewise B.  tmp: scratch of 4*n_img*min(Ho*W, H*Wo) bytes. */
+int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo,
+                   const int* startH, const float* wtH, int KH, const int* startW, const float* wtW, int KW,
+                   void* stream);
+
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.
  *   uno_profile_begin(max_records): start recording (drops records beyond max_records).

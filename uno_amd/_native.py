@@ -37,6 +37,7 @@ _SIGNATURES = {
     "uno_spectral_conv3d_forward": (C.c_int, [_fp, C.POINTER(_fp), _fp, _fp, _fp] + [_i] * 12 + [_fp]),
     "uno_spectral_conv3d_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp), _fp] + [_i] * 12 + [_fp]),
     "uno_cdft_axis": (C.c_int, [_fp, _fp] + [_i] * 6 + [C.c_float, _i, _fp]),
+    "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -242,6 +243,24 @@ def spectral_conv3d_backward(gy, xt, ws_, H: int, W: int, T: int, need_gx=True, 
                                             H, W, T, Ho, Wo, To, m1, m2, m3, _stream(gy))
     _check(rc, "uno_spectral_conv3d_backward")
     return gx, gws
+
+
+def resample2d(x, Ho: int, Wo: int, tabH, tabW):
+    """x (..., H, W) f32 -> (..., Ho, Wo); tabX = (start int32 [out], weights f32 [out, K]) band tables on x.device."""
+    _require(x, torch.float32, "x")
+    *lead, H, W = x.shape
+    n = 1
+    for d in lead:
+        n *= d
+    sH, wH = tabH
+    sW, wW = tabW
+    out = torch.empty((*lead, Ho, Wo), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        tmp = torch.empty(max(1, n * min(Ho * W, H * Wo)), dtype=torch.float32, device=x.device)
+        rc = lib().uno_resample2d(_ptr(x), _ptr(out), _ptr(tmp), n, H, W, Ho, Wo, _ptr(sH), _ptr(wH), wH.shape[1],
+                                  _ptr(sW), _ptr(wW), wW.shape[1], _stream(x))
+    _check(rc, "uno_resample2d")
+    return out
 
 
 def profile_begin(max_records: int = 100000):

@@ -1,0 +1,95 @@
+// K7 - separable banded resampling of images:  out = A . in . B^T  per image,
+//   A (Ho x H) and B (Wo x W) banded matrices given as (first source index, taps) per output index.
+//
+// This is the resampling half of pointwise_op_2D (reference integral_operators.py:240-242:
+// F.interpolate(mode="bicubic", align_corners=True, antialias=True)) and, with the transposed band tables, its
+// adjoint.  The band tables hold exactly the weights the reference's CPU op applies (they are read off that op
+// once per (in, out) size pair on the host, uno_amd/resample.py), so the forward result matches the reference
+// to float32 rounding; what this kernel replaces is the GPU implementation of the op, whose backward
+// (upsample_gen2d_aa_backward_out_frame) took 196 ms of a 286 ms training step.
+//
+// Memory-bound stencil, two passes (rows then columns, or columns then rows - whichever makes the
+// intermediate smaller); every load and store is unit-stride along the image row.
+#include "uno_common.h"
+#include <cstdio>
+
+namespace uno {
+
+// out[n][i][q] = sum_t wt[i][t] * in[n][start[i] + t][q]      (rows of length W)
+__global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const int* __restrict__ start, const float* __restrict__ wt,
+                                                            int K, int H, int Ho, int W, int rows_per_block) {
+    const int n = blockIdx.z;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= W) return;
+    const float* src = in + (size_t)n * H * W + q;
+    float* dst = out + (size_t)n * Ho * W + q;
+    const int i0 = blockIdx.y * rows_per_block;
+    const int i1 = min(i0 + rows_per_block, Ho);
+    for (int i = i0; i < i1; ++i) {
+        const int s = start[i];
+        const float* w = wt + (size_t)i * K;
+        float acc = 0.f;
+        for (int t = 0; t < K; ++t) {
+            const int p = min(s + t, H - 1);            // taps beyond the band carry weight 0
+            acc = fmaf(w[t], src[(size_t)p * W], acc);
+        }
+        dst[(size_t)i * W] = acc;
+    }
+}
+
+// out[n][r][j] = sum_t wt[j][t] * in[n][r][start[j] + t]
+__global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const int* __restrict__ start, const float* __restrict__ wt,
+                                                            int K, int R, int W, int Wo, int rows_per_block) {
+    const int n = blockIdx.z;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Wo) return;
+    const int s = start[j];
+    float w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = t < K ? wt[(size_t)j * K + t] : 0.f;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, R);
+    for (int r = r0; r < r1; ++r) {
+        const float* src = in + ((size_t)n * R + r) * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < K) acc = fmaf(w[t], src[min(s + t, W - 1)], acc);
+        out[((size_t)n * R + r) * Wo + j] = acc;
+    }
+}
+
+int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+                      const float* wtH, int KH, const int* startW, const float* wtW, int KW, hipStream_t s) {
+    if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
+    const int RPB = 16;
+    // rows first when that shrinks the intermediate (Ho*W <= H*Wo), columns first otherwise
+    const bool rows_first = (long long)Ho * W <= (long long)H * Wo;
+    const double img_bytes = 4.0 * n_img;
+    if (rows_first) {
+        {
+            ProfScope prof("uno::resample_rows_kernel", img_bytes * ((double)H * W + (double)Ho * W), s);
+            hipLaunchKernelGGL(resample_rows_kernel, dim3((W + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startH, wtH, KH, H, Ho, W, RPB);
+        }
+        {
+            ProfScope prof("uno::resample_cols_kernel", img_bytes * ((double)Ho * W + (double)Ho * Wo), s);
+            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startW, wtW, KW, Ho, W, Wo, RPB);
+        }
+    } else {
+        {
+            ProfScope prof("uno::resample_cols_kernel", img_bytes * ((double)H * W + (double)H * Wo), s);
+            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (H + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB);
+        }
+        {
+            ProfScope prof("uno::resample_rows_kernel", img_bytes * ((double)H * Wo + (double)Ho * Wo), s);
+            hipLaunchKernelGGL(resample_rows_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startH, wtH, KH, H, Ho, Wo, RPB);
+        }
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+}  // namespace uno

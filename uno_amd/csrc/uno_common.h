@@ -108,5 +108,7 @@ int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
+int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+                      const float* wtH, int KH, const int* startW, const float* wtW, int KW, hipStream_t s);
 
 }  // namespace uno

@@ -128,7 +128,15 @@ class pointwise_op_2D(nn.Module):
     def forward(self, x, dim1=None, dim2=None):
         if dim1 is None:
             dim1, dim2 = self.dim1, self.dim2
-        return F.interpolate(self.conv(x), size=(dim1, dim2), mode="bicubic", align_corners=True, antialias=True)
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            return F.interpolate(self.conv(x), size=(dim1, dim2), mode="bicubic", align_corners=True, antialias=True)
+        # HIP path: the resampling is a separable banded operator with the reference's weights (uno_amd/resample.py).
+        # It commutes with the 1x1 convolution (both linear, resampling rows sum to 1 so the bias passes through),
+        # so the convolution runs on whichever side has fewer pixels.
+        from .resample import resample2d_bicubic_aa
+        if dim1 * dim2 < x.shape[-2] * x.shape[-1]:
+            return self.conv(resample2d_bicubic_aa(x, dim1, dim2))
+        return resample2d_bicubic_aa(self.conv(x), dim1, dim2)
 
 
 class OperatorBlock_2D(nn.Module):
