@@ -46,9 +46,11 @@ def test_uno9_forward_loss_grads_match_reference():
     loss = lp_loss_rel_sum(pred.view(B, -1), u.view(B, -1))
     assert abs(float(loss) - float(c.losses[0])) < 1e-5 * abs(float(c.losses[0]))
     loss.backward()
+    gmax = max(float(getattr(c, f"gradnorm.{k}")) for k, _ in model.named_parameters())
     for k, p in model.named_parameters():
         ref = float(getattr(c, f"gradnorm.{k}"))
-        assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-4 * ref + 1e-9, k
+        # floor: a conv bias in front of an InstanceNorm has a zero true gradient (what is stored is rounding residue)
+        assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-4 * ref + 1e-6 * gmax, k
     for k, g in c.sub("grad").items():
         assert rel_err(dict(model.named_parameters())[k].grad.numpy(), g) < 2e-4, k
 

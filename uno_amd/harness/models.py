@@ -1,8 +1,12 @@
 """Darcy-flow U-NO (the 5-block "UNO_9" of the reference, darcy_flow_uno2d.py:27-141) built on the
 MI355X-native operator blocks.  Sub-module names, shapes and registration order follow the reference,
-so its state_dict loads with strict=True.  Differences are host-side hygiene only: the positional
-grid is built once per (shape, device) and cached on the device instead of being rebuilt on the host
-and copied every forward (reference :135-141)."""
+so its state_dict loads with strict=True.  Differences are host-side hygiene only:
+  * the positional grid is built once per (shape, device) and cached on the device instead of being rebuilt
+    on the host and copied every forward (reference :135-141);
+  * lift and projection run channels-first (the nn.Linear weights applied as batched GEMMs on the
+    (B, C, pixels) view), which removes the two full-size permute copies around the U (reference :104, :126);
+  * the point-wise projection runs before the crop (they commute), so the crop touches one channel.
+The arithmetic is the reference's up to float32 summation order."""
 from __future__ import annotations
 
 import math
@@ -11,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import OperatorBlock_2D
+from ..integral_operators import OperatorBlock_2D, channel_mix
 
 
 class UNO_9(nn.Module):
@@ -48,9 +52,10 @@ class UNO_9(nn.Module):
         return grid
 
     def forward(self, x):
-        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1)
-        lifted = F.gelu(self.fc0(F.gelu(self.fc_n1(x)))).permute(0, 3, 1, 2)
-        scale = math.ceil(lifted.shape[-1] / 85)
+        S1, S2 = x.shape[1], x.shape[2]
+        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()   # (B, 3, S, S): tiny
+        lifted = F.gelu(channel_mix(F.gelu(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias)), self.fc0.weight, self.fc0.bias))
+        scale = math.ceil(S2 / 85)
         margin = scale * self.padding
         lifted = F.pad(lifted, [0, margin, 0, margin])
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
@@ -60,6 +65,5 @@ class UNO_9(nn.Module):
         c2 = self.conv2(c1, d1 // 4, d2 // 4)
         c4 = torch.cat([self.conv4(c2, d1 // 2, d2 // 2), c0], dim=1)
         c5 = torch.cat([self.conv5(c4, d1, d2), lifted], dim=1)
-        if self.padding != 0:
-            c5 = c5[..., :-margin, :-margin]
-        return self.fc2(F.gelu(self.fc1(c5.permute(0, 2, 3, 1))))
+        out = channel_mix(F.gelu(channel_mix(c5, self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
+        return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)

@@ -76,6 +76,20 @@ class _SpectralConv2dFn(torch.autograd.Function):
         return gx, gw1, gw2, None, None
 
 
+def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """1x1 convolution of a channels-first tensor as one batched GEMM  y[b] = W . x[b] (+ bias)  on the
+    (B, C, pixels) view - no layout change, no im2col, rocBLAS strided-batched underneath.  `weight` is a
+    Conv (Co, Ci, 1, ...) or Linear (Co, Ci) weight."""
+    B, Ci = x.shape[0], x.shape[1]
+    w = weight.reshape(weight.shape[0], Ci)
+    xv = x.reshape(B, Ci, -1)
+    if bias is not None:
+        y = torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xv)
+    else:
+        y = torch.matmul(w, xv)
+    return y.view(B, w.shape[0], *x.shape[2:])
+
+
 def spectral_conv2d(x, weights1, weights2, dim1, dim2):
     """Functional form of SpectralConv2d_Uno.forward (reference integral_operators.py:181-207)."""
     return _SpectralConv2dFn.apply(x, weights1, weights2, dim1, dim2)
@@ -135,8 +149,8 @@ class pointwise_op_2D(nn.Module):
         # so the convolution runs on whichever side has fewer pixels.
         from .resample import resample2d_bicubic_aa
         if dim1 * dim2 < x.shape[-2] * x.shape[-1]:
-            return self.conv(resample2d_bicubic_aa(x, dim1, dim2))
-        return resample2d_bicubic_aa(self.conv(x), dim1, dim2)
+            return channel_mix(resample2d_bicubic_aa(x, dim1, dim2), self.conv.weight, self.conv.bias)
+        return resample2d_bicubic_aa(channel_mix(x.contiguous(), self.conv.weight, self.conv.bias), dim1, dim2)
 
 
 class OperatorBlock_2D(nn.Module):
