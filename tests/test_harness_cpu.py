@@ -52,7 +52,8 @@ def test_uno9_forward_loss_grads_match_reference():
         # floor: a conv bias in front of an InstanceNorm has a zero true gradient (what is stored is rounding residue)
         assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-4 * ref + 1e-6 * gmax, k
     for k, g in c.sub("grad").items():
-        assert rel_err(dict(model.named_parameters())[k].grad.numpy(), g) < 2e-4, k
+        got = dict(model.named_parameters())[k].grad.numpy()
+        assert np.linalg.norm((got - g).ravel()) <= 2e-4 * np.linalg.norm(g.ravel()) + 1e-6 * gmax, k
 
 
 def test_three_training_steps_match_reference_adam():
