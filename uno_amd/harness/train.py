@@ -48,8 +48,8 @@ class FlatGradients:
     def zero_(self):
         self.flat.zero_()
 
-    def all_reduce_sum(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def all_reduce_sum(self, group=None, force=False):
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 
@@ -58,15 +58,16 @@ class DarcyTrainer:
     backward, gradient all-reduce and the optimiser update; it returns the (device) loss tensor and
     never synchronises with the host."""
 
-    def __init__(self, model, lr=1e-3, weight_decay=1e-3, group=None):
+    def __init__(self, model, lr=1e-3, weight_decay=1e-3, group=None, force_collectives=False):
         self.model = model
         self.group = group
+        self.force_collectives = force_collectives      # tests: run the collectives even in a 1-rank group
         self.grads = FlatGradients(model.parameters())
         self.opt = ComplexAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (self.force_collectives or dist.get_world_size(self.group) > 1):
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(torch.view_as_real(t.data) if t.is_complex() else t.data, src=0, group=self.group)
 
@@ -76,6 +77,6 @@ class DarcyTrainer:
         pred = self.model(a).reshape(B, S, S)
         loss = lp_loss_rel_sum(pred.view(B, -1), u.view(B, -1))
         loss.backward()
-        self.grads.all_reduce_sum(self.group)
+        self.grads.all_reduce_sum(self.group, self.force_collectives)
         self.opt.step()
         return loss.detach()
