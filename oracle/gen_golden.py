@@ -168,6 +168,65 @@ def uno9_case(ref_dir):
     return out
 
 
+def _checksums(model):
+    out = {}
+    for k, p in model.named_parameters():
+        out[k] = np.array([float(p.detach().abs().sum()), float(torch.linalg.vector_norm(p.detach()))])
+    return out
+
+
+def ns2d_case():
+    """UNO(14, 4) (navier_stokes_uno2d.py:145-238), S=64, 2 autoregressive steps (ns_train_2d.py:46-67): loss and
+    gradient norms.  Weights are NOT stored (1.9 MB): they come from torch.manual_seed(21) + constructor order,
+    verified in the test through per-parameter checksums."""
+    import navier_stokes_uno2d as n2
+    from utilities3 import LpLoss
+    torch.manual_seed(21)
+    model = n2.UNO(14, 4)
+    out = {f"ns2d.ck.{k}": v for k, v in _checksums(model).items()}
+    g = torch.Generator().manual_seed(22)
+    xx = torch.randn(1, 64, 64, 10, generator=g)
+    yy = torch.randn(1, 64, 64, 2, generator=g)
+    out["ns2d.xx"], out["ns2d.yy"] = _np(xx), _np(yy)
+    myloss = LpLoss(size_average=False)
+    loss = 0
+    x = xx
+    preds = []
+    for t in range(2):
+        im = model(x)
+        preds.append(im)
+        loss = loss + myloss(im.reshape(1, -1), yy[..., t:t + 1].reshape(1, -1))
+        x = torch.cat((x[..., 1:], im), dim=-1)
+    loss.backward()
+    out["ns2d.loss"] = np.array(float(loss))
+    out["ns2d.pred"] = _np(torch.cat(preds, -1))
+    for k, p in model.named_parameters():
+        out[f"ns2d.gradnorm.{k}"] = np.array(float(torch.linalg.vector_norm(p.grad)))
+    return out
+
+
+def ns3d_case():
+    """Uno3D_T20(6, 2, pad=3) (navier_stokes_uno3d.py:239-409), S=32, T 10 -> 20 (ns_train_3d.py:53-65).  Seeded
+    weights (torch.manual_seed(31)) verified by checksums; input/target stored."""
+    import navier_stokes_uno3d as n3
+    from utilities3 import LpLoss
+    torch.manual_seed(31)
+    model = n3.Uno3D_T20(6, 2, pad=3)
+    out = {f"ns3d.ck.{k}": v for k, v in _checksums(model).items()}
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(1, 32, 32, 10, 1, generator=g)
+    y = torch.randn(1, 32, 32, 20, generator=g)
+    out["ns3d.x"], out["ns3d.y"] = _np(x), _np(y)
+    pred = model(x).view(1, 32, 32, 20)
+    loss = LpLoss(size_average=False)(pred.reshape(1, -1), y.reshape(1, -1))
+    loss.backward()
+    out["ns3d.loss"] = np.array(float(loss))
+    out["ns3d.pred"] = _np(pred)
+    for k, p in model.named_parameters():
+        out[f"ns3d.gradnorm.{k}"] = np.array(float(torch.linalg.vector_norm(p.grad)))
+    return out
+
+
 def adam_case():
     """3 reference-Adam steps on a complex and a real tensor with fixed grads."""
     from Adam import Adam
@@ -252,6 +311,10 @@ def main():
     har.update(uno9_case(args.ref))
     har.update(adam_case())
     np.savez_compressed(os.path.join(args.out, "harness.npz"), **har)
+    ns = {}
+    ns.update(ns2d_case())
+    ns.update(ns3d_case())
+    np.savez_compressed(os.path.join(args.out, "harness_ns.npz"), **ns)
 
     for f in sorted(os.listdir(args.out)):
         print(f, os.path.getsize(os.path.join(args.out, f)))

@@ -1,0 +1,78 @@
+"""NS-2D (`UNO`) and NS-3D (`Uno3D_T20`) harness models + their training losses vs reference-generated golden
+values (tests/golden/harness_ns.npz).  The golden weights are seeded, not stored (3-D spectral weights are tens of
+MB); every test first verifies per-parameter checksums, i.e. that the constructor reproduced the reference's
+initialisation bit for bit.  CPU tests use the oracle blocks as test doubles; -m gpu tests use the product path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Case, load_cases, rel_err
+from oracle import spectral_oracle as so
+from uno_amd.harness import UNO, Uno3D_T20, ns2d_rollout_loss, ns3d_loss
+
+Z, _ = load_cases("harness_ns.npz")
+
+
+def _check_init(model, c):
+    for k, p in model.named_parameters():
+        ck = getattr(c, f"ck.{k}")
+        got = np.array([float(p.detach().abs().sum()), float(torch.linalg.vector_norm(p.detach()))])
+        assert np.allclose(got, ck, rtol=1e-6), f"seeded init of {k} differs from the reference's"
+
+
+def _check_grads(model, c, rtol):
+    gmax = max(float(getattr(c, f"gradnorm.{k}")) for k, _ in model.named_parameters())
+    for k, p in model.named_parameters():
+        ref = float(getattr(c, f"gradnorm.{k}"))
+        assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= rtol * ref + 1e-5 * gmax, k
+
+
+def _ns2d(block_cls, dev, tol_pred, tol_grad):
+    c = Case(Z, "ns2d")
+    torch.manual_seed(21)
+    model = UNO(14, 4, block_cls=block_cls) if block_cls else UNO(14, 4)
+    _check_init(model, c)
+    model = model.to(dev)
+    xx, yy = torch.from_numpy(c.xx).to(dev), torch.from_numpy(c.yy).to(dev)
+    with torch.no_grad():
+        p0 = model(xx)
+    assert rel_err(p0.cpu().numpy()[..., 0], c.pred[..., 0]) < tol_pred
+    loss = ns2d_rollout_loss(model, xx, yy, T_f=2, step=1)
+    loss.backward()
+    assert abs(float(loss) - float(c.loss)) < tol_pred * abs(float(c.loss))
+    _check_grads(model, c, tol_grad)
+
+
+def _ns3d(block_cls, dev, tol_pred, tol_grad):
+    c = Case(Z, "ns3d")
+    torch.manual_seed(31)
+    model = Uno3D_T20(6, 2, pad=3, block_cls=block_cls) if block_cls else Uno3D_T20(6, 2, pad=3)
+    _check_init(model, c)
+    model = model.to(dev)
+    x, y = torch.from_numpy(c.x).to(dev), torch.from_numpy(c.y).to(dev)
+    loss = ns3d_loss(model, x, y)
+    loss.backward()
+    with torch.no_grad():
+        pred = model(x).view(1, 32, 32, 20)
+    assert rel_err(pred.cpu().numpy(), c.pred) < tol_pred
+    assert abs(float(loss) - float(c.loss)) < tol_pred * abs(float(c.loss))
+    _check_grads(model, c, tol_grad)
+
+
+def test_ns2d_cpu_oracle_blocks():
+    _ns2d(so.OracleOperatorBlock2d, "cpu", 1e-5, 5e-4)
+
+
+def test_ns3d_cpu_oracle_blocks():
+    _ns3d(so.OracleOperatorBlock3d, "cpu", 1e-5, 5e-4)
+
+
+@pytest.mark.gpu
+def test_ns2d_gpu_product():
+    _ns2d(None, torch.device("cuda:0"), 1e-4, 5e-3)
+
+
+@pytest.mark.gpu
+def test_ns3d_gpu_product():
+    # gradient tolerance: three InstanceNorm3d layers through MIOpen
+    _ns3d(None, torch.device("cuda:0"), 1e-3, 2e-2)

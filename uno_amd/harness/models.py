@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import OperatorBlock_2D, channel_mix
+from ..integral_operators import OperatorBlock_2D, OperatorBlock_3D, channel_mix
 
 
 class UNO_9(nn.Module):
@@ -67,3 +67,122 @@ class UNO_9(nn.Module):
         c5 = torch.cat([self.conv5(c4, d1, d2), lifted], dim=1)
         out = channel_mix(F.gelu(channel_mix(c5, self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
         return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)
+
+
+def _cached(cache: dict, key, build):
+    grid = cache.get(key)
+    if grid is None:
+        grid = build()
+        cache.clear()
+        cache[key] = grid
+    return grid
+
+
+class UNO(nn.Module):
+    """Navier-Stokes 2-D U-NO (7 blocks, channel growth factor 3/4) - own counterpart of the reference's
+    `UNO` (navier_stokes_uno2d.py:145-238): one autoregressive step (B, S, S, T_in) -> (B, S, S, 1).  Input
+    channels = T_in + 4 positional features (sin/cos of the two coordinates, :229-238).  Sub-module names and
+    registration order follow the reference (state_dict compatible).  Channels-first lift/projection as in UNO_9."""
+
+    def __init__(self, in_width, width, pad=0, factor=3 / 4, block_cls=OperatorBlock_2D):
+        super().__init__()
+        self.in_width, self.width, self.factor, self.padding = in_width, width, factor, pad
+        w, f = width, factor
+        self.fc = nn.Linear(in_width, w // 2)
+        self.fc0 = nn.Linear(w // 2, w)
+        self.L0 = block_cls(w, 2 * f * w, 48, 48, 22, 22)
+        self.L1 = block_cls(2 * f * w, 4 * f * w, 32, 32, 14, 14)
+        self.L2 = block_cls(4 * f * w, 8 * f * w, 16, 16, 6, 6)
+        self.L3 = block_cls(8 * f * w, 8 * f * w, 16, 16, 6, 6)
+        self.L4 = block_cls(8 * f * w, 4 * f * w, 32, 32, 6, 6)
+        self.L5 = block_cls(8 * f * w, 2 * f * w, 48, 48, 14, 14)
+        self.L6 = block_cls(4 * f * w, w, 64, 64, 22, 22)
+        self.fc1 = nn.Linear(2 * w, 4 * w)
+        self.fc2 = nn.Linear(4 * w, 1)
+        self._grid_cache = {}
+
+    def get_grid(self, shape, device):
+        def build():
+            b, sx, sy = shape[0], shape[1], shape[2]
+            gx = torch.linspace(0, 2 * math.pi, sx, dtype=torch.float64).to(torch.float32).reshape(1, sx, 1, 1).expand(b, sx, sy, 1)
+            gy = torch.linspace(0, 2 * math.pi, sy, dtype=torch.float64).to(torch.float32).reshape(1, 1, sy, 1).expand(b, sx, sy, 1)
+            return torch.cat((torch.sin(gx), torch.sin(gy), torch.cos(gx), torch.cos(gy)), dim=-1).contiguous().to(device)
+        return _cached(self._grid_cache, (tuple(shape[:3]), str(device)), build)
+
+    def forward(self, x):
+        S1, S2 = x.shape[1], x.shape[2]
+        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()
+        lifted = F.gelu(channel_mix(F.gelu(channel_mix(x, self.fc.weight, self.fc.bias)), self.fc0.weight, self.fc0.bias))
+        p = self.padding
+        lifted = F.pad(lifted, [p, p, p, p])
+        d1, d2 = lifted.shape[-2], lifted.shape[-1]
+        c0 = self.L0(lifted, int(d1 * self.factor), int(d2 * self.factor))
+        c1 = self.L1(c0, d1 // 2, d2 // 2)
+        c2 = self.L2(c1, d1 // 4, d2 // 4)
+        c3 = self.L3(c2, d1 // 4, d2 // 4)
+        c4 = torch.cat([self.L4(c3, d1 // 2, d2 // 2), c1], dim=1)
+        c5 = torch.cat([self.L5(c4, int(d1 * self.factor), int(d2 * self.factor)), c0], dim=1)
+        c6 = torch.cat([self.L6(c5, d1, d2), lifted], dim=1)
+        if p != 0:      # the reference pads both sides but crops one (navier_stokes_uno2d.py:201,217-218); kept
+            c6 = c6[..., :-p, :-p]
+        out = channel_mix(F.gelu(channel_mix(c6.contiguous(), self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
+        return out.permute(0, 2, 3, 1).contiguous()
+
+
+class Uno3D_T20(nn.Module):
+    """Navier-Stokes 3-D (space-time) U-NO mapping 10 input steps to 20 output steps - own counterpart of the
+    reference's `Uno3D_T20` (navier_stokes_uno3d.py:239-409): 7 OperatorBlock_3D that also stretch the time axis,
+    skip connections through (identity) trilinear resizes, time-axis padding int(pad * 0.1 * T).
+    Input (B, S, S, T, 1) -> output (B, S, S, 2T, 1); in_width = 1 + 5 positional features."""
+
+    def __init__(self, in_width, width, pad=2, factor=1, pad_both=False, block_cls=OperatorBlock_3D):
+        super().__init__()
+        self.in_width, self.width, self.pad, self.pad_both = in_width, width, pad, pad_both
+        w, f = width, factor
+        self.fc = nn.Linear(in_width, in_width * 2)
+        self.fc0 = nn.Linear(in_width * 2, w)
+        self.conv0 = block_cls(w, 2 * f * w, 48, 48, 10, 22, 22, 5, Normalize=True)
+        self.conv1 = block_cls(2 * f * w, 4 * f * w, 32, 32, 10, 14, 14, 5)
+        self.conv2 = block_cls(4 * f * w, 8 * f * w, 16, 16, 12, 6, 6, 5)
+        self.conv3 = block_cls(8 * f * w, 16 * f * w, 16, 16, 12, 6, 6, 6, Normalize=True)
+        self.conv6 = block_cls(16 * f * w, 4 * f * w, 32, 32, 18, 6, 6, 6)
+        self.conv7 = block_cls(8 * f * w, 2 * f * w, 48, 48, 20, 14, 14, 8, Normalize=True)
+        self.conv8 = block_cls(4 * f * w, 2 * w, 64, 64, 20, 22, 22, 8)
+        self.fc1 = nn.Linear(3 * w, 4 * w)
+        self.fc2 = nn.Linear(4 * w, 1)
+        self._grid_cache = {}
+
+    def get_grid(self, shape, device):
+        def build():
+            b, sx, sy, sz = shape[0], shape[1], shape[2], shape[3]
+            lin = lambda hi, n: torch.linspace(0, hi, n, dtype=torch.float64).to(torch.float32)
+            gx = lin(2 * math.pi, sx).reshape(1, sx, 1, 1, 1).expand(b, sx, sy, sz, 1)
+            gy = lin(2 * math.pi, sy).reshape(1, 1, sy, 1, 1).expand(b, sx, sy, sz, 1)
+            gz = lin(1, sz).reshape(1, 1, 1, sz, 1).expand(b, sx, sy, sz, 1)
+            return torch.cat((torch.sin(gx), torch.sin(gy), torch.cos(gx), torch.cos(gy), gz), dim=-1).contiguous().to(device)
+        return _cached(self._grid_cache, (tuple(shape[:4]), str(device)), build)
+
+    @staticmethod
+    def _resize(t, like):
+        return F.interpolate(t, size=tuple(like.shape[2:]), mode="trilinear", align_corners=True)
+
+    def forward(self, x):
+        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 4, 1, 2, 3).contiguous()
+        lifted = F.gelu(channel_mix(F.gelu(channel_mix(x, self.fc.weight, self.fc.bias)), self.fc0.weight, self.fc0.bias))
+        self.padding = int(self.pad * 0.1 * lifted.shape[-1])
+        lifted = F.pad(lifted, [self.padding, self.padding, 0, 0, 0, 0] if self.pad_both else [0, self.padding, 0, 0, 0, 0])
+        d1, d2, d3 = lifted.shape[-3:]
+        c0 = self.conv0(lifted, int(3 * d1 / 4), int(3 * d2 / 4), d3)
+        c1 = self.conv1(c0, d1 // 2, d2 // 2, d3)
+        c2 = self.conv2(c1, d1 // 4, d2 // 4, int(d3 * 1.2))
+        c3 = self.conv3(c2, d1 // 4, d2 // 4, int(d3 * 1.2))
+        c6 = self.conv6(c3, d1 // 2, d2 // 2, int(d3 * 1.8))
+        c6 = torch.cat([c6, self._resize(c1, c6)], dim=1)
+        c7 = self.conv7(c6, int(3 * d1 / 4), int(3 * d2 / 4), int(2.0 * d3))
+        c7 = torch.cat([c7, self._resize(c0, c7)], dim=1)
+        c8 = self.conv8(c7, d1, d2, 2 * d3)
+        c8 = torch.cat([c8, self._resize(lifted, c8)], dim=1)
+        if self.padding != 0:
+            c8 = c8[..., 2 * self.padding:-2 * self.padding] if self.pad_both else c8[..., :-2 * self.padding]
+        out = channel_mix(F.gelu(channel_mix(c8.contiguous(), self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
+        return out.permute(0, 2, 3, 4, 1).contiguous()

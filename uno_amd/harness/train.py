@@ -53,6 +53,26 @@ class FlatGradients:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 
+def ns2d_rollout_loss(model, xx, yy, T_f, step=1):
+    """Autoregressive loss of the NS-2D training step (reference ns_train_2d.py:46-62): the model predicts
+    `step` frames from the last T_in, the prediction is appended to the input window, the per-step relative
+    L2 losses are summed; ONE backward runs through the whole unrolled chain."""
+    loss = 0
+    B = yy.shape[0]
+    for t in range(0, T_f, step):
+        im = model(xx)
+        loss = loss + lp_loss_rel_sum(im.reshape(B, -1), yy[..., t:t + step].reshape(B, -1))
+        xx = torch.cat((xx[..., step:], im), dim=-1)
+    return loss
+
+
+def ns3d_loss(model, x, y):
+    """Space-time loss of the NS-3D training step (reference ns_train_3d.py:53,64): one forward, global relative L2."""
+    B, S, T_f = x.shape[0], x.shape[1], y.shape[-1]
+    out = model(x).view(B, S, S, T_f)
+    return lp_loss_rel_sum(out.reshape(B, -1), y.reshape(B, -1))
+
+
 class DarcyTrainer:
     """model + ComplexAdam + flat-gradient data parallelism.  step(a, u) runs forward, relative-L2 loss,
     backward, gradient all-reduce and the optimiser update; it returns the (device) loss tensor and
@@ -71,12 +91,15 @@ class DarcyTrainer:
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(torch.view_as_real(t.data) if t.is_complex() else t.data, src=0, group=self.group)
 
-    def step(self, a, u):
+    def step_with(self, loss_closure):
+        """zero grads -> loss_closure() -> backward -> gradient all-reduce -> optimiser update."""
         self.grads.zero_()
-        B, S = a.shape[0], a.shape[1]
-        pred = self.model(a).reshape(B, S, S)
-        loss = lp_loss_rel_sum(pred.view(B, -1), u.view(B, -1))
+        loss = loss_closure()
         loss.backward()
         self.grads.all_reduce_sum(self.group, self.force_collectives)
         self.opt.step()
         return loss.detach()
+
+    def step(self, a, u):
+        B, S = a.shape[0], a.shape[1]
+        return self.step_with(lambda: lp_loss_rel_sum(self.model(a).reshape(B, -1), u.reshape(B, -1)))
