@@ -103,10 +103,13 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
 /* Separable banded resampling out = A . in . B^T of n_img images (H, W) -> (Ho, Wo): the resampling half of
  * pointwise_op_2D (reference integral_operators.py:240-242, bicubic / align_corners / antialias) and, with the
  * transposed band tables, its adjoint.  Row i of A has its first nonzero at column startH[i] and KH weights
- * wtH[i*KH .. i*KH+KH-1] (zero padded); likewise B.  tmp: scratch of 4*n_img*min(Ho*W, H*Wo) bytes. */
+ * wtH[i*KH .. i*KH+KH-1] (zero padded); likewise B.  tmp: scratch of 4*n_img*min(Ho*W, H*Wo) bytes.
+ * Optional dense row-tile form of A for the fused single-pass kernel (NULL / 0 to use the two-pass kernels):
+ * tile k covers output rows 16k..16k+15, reads input rows tile_p0[k] .. tile_p0[k]+NP-1 and has weights
+ * tile_w[(k*NP + u)*16 + r] = A[16k + r][tile_p0[k] + u]. */
 int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo,
                    const int* startH, const float* wtH, int KH, const int* startW, const float* wtW, int KW,
-                   void* stream);
+                   const int* tile_p0, const float* tile_w, int NP, void* stream);
 
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.

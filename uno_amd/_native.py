@@ -37,7 +37,7 @@ _SIGNATURES = {
     "uno_spectral_conv3d_forward": (C.c_int, [_fp, C.POINTER(_fp), _fp, _fp, _fp] + [_i] * 12 + [_fp]),
     "uno_spectral_conv3d_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp), _fp] + [_i] * 12 + [_fp]),
     "uno_cdft_axis": (C.c_int, [_fp, _fp] + [_i] * 6 + [C.c_float, _i, _fp]),
-    "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp]),
+    "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -245,8 +245,9 @@ def spectral_conv3d_backward(gy, xt, ws_, H: int, W: int, T: int, need_gx=True, 
     return gx, gws
 
 
-def resample2d(x, Ho: int, Wo: int, tabH, tabW):
-    """x (..., H, W) f32 -> (..., Ho, Wo); tabX = (start int32 [out], weights f32 [out, K]) band tables on x.device."""
+def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None):
+    """x (..., H, W) f32 -> (..., Ho, Wo); tabX = (start int32 [out], weights f32 [out, K]) band tables on x.device;
+    tilesH = (p0 int32 [ntiles], dense weights f32 [ntiles, NP, 16]) enables the fused single-pass kernel."""
     _require(x, torch.float32, "x")
     *lead, H, W = x.shape
     n = 1
@@ -257,8 +258,13 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW):
     out = torch.empty((*lead, Ho, Wo), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         tmp = torch.empty(max(1, n * min(Ho * W, H * Wo)), dtype=torch.float32, device=x.device)
+        if tilesH is not None:
+            tp0, tw = tilesH
+            targs = (_ptr(tp0), _ptr(tw), tw.shape[1])
+        else:
+            targs = (C.c_void_p(0), C.c_void_p(0), 0)
         rc = lib().uno_resample2d(_ptr(x), _ptr(out), _ptr(tmp), n, H, W, Ho, Wo, _ptr(sH), _ptr(wH), wH.shape[1],
-                                  _ptr(sW), _ptr(wW), wW.shape[1], _stream(x))
+                                  _ptr(sW), _ptr(wW), wW.shape[1], *targs, _stream(x))
     _check(rc, "uno_resample2d")
     return out
 

@@ -241,11 +241,12 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
 }
 
 int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
-                   const float* wtH, int KH, const int* startW, const float* wtW, int KW, void* stream) {
+                   const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                   const float* tile_w, int NP, void* stream) {
     if (n_img < 0 || H < 1 || W < 1 || Ho < 1 || Wo < 1) { set_error("uno_resample2d: bad sizes"); return -1; }
     if (n_img == 0) return 0;
     if (!in || !out || !tmp || !startH || !wtH || !startW || !wtW) { set_error("uno_resample2d: null pointer"); return -1; }
-    return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, (hipStream_t)stream);
+    return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, (hipStream_t)stream);
 }
 
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,

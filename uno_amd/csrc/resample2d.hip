@@ -61,9 +61,73 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restr
     }
 }
 
+// Fused form: one workgroup = (image, tile of TR = 16 output rows).
+//   phase 1 (rows): every thread owns one image column.  It streams the NP input rows the tile depends on - each
+//     element loaded exactly once, unit-stride across the wave, all loads independent - and accumulates the 16
+//     outputs as a DENSE 16 x NP tile of the banded row operator whose weights are wave-uniform (scalar registers):
+//     16 v_fmac per loaded element instead of a gather per tap.  Result V[16][W] goes to LDS.
+//   phase 2 (columns): banded column operator from LDS, TR x Wo outputs written unit-stride.
+// The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
+constexpr int RS_TR = 16;
+
+__global__ __launch_bounds__(256) void resample_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
+                                                             const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
+                                                             int H, int W, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][W]
+    const int n = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int i0 = tile * RS_TR;
+    const int tid = threadIdx.x;
+    const int p0 = tile_p0[tile];
+    const float* wd = tile_w + (size_t)tile * NP * RS_TR;           // [NP][16], zero outside the band
+    const float* src = in + (size_t)n * H * W;
+    for (int q = tid; q < W; q += 256) {
+        float acc[RS_TR];
+#pragma unroll
+        for (int r = 0; r < RS_TR; ++r) acc[r] = 0.f;
+        for (int u = 0; u < NP; ++u) {
+            const float x = src[(size_t)min(p0 + u, H - 1) * W + q];
+            const float* w = wd + u * RS_TR;
+#pragma unroll
+            for (int r = 0; r < RS_TR; ++r) acc[r] = fmaf(w[r], x, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RS_TR; ++r) V[r * W + q] = acc[r];
+    }
+    __syncthreads();
+    float* dst = out + ((size_t)n * Ho + i0) * Wo;
+    const int nr = min(RS_TR, Ho - i0);
+    for (int j = tid; j < Wo; j += 256) {
+        const int s = startW[j];
+        float w[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = t < KW ? wtW[(size_t)j * KW + t] : 0.f;
+        for (int r = 0; r < nr; ++r) {
+            const float* v = V + r * W;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < KW) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
+            dst[(size_t)r * Wo + j] = acc;
+        }
+    }
+}
+
 int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
-                      const float* wtH, int KH, const int* startW, const float* wtW, int KW, hipStream_t s) {
+                      const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                      const float* tile_w, int NP, hipStream_t s) {
     if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
+    if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
+        // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
+        const size_t lds = (size_t)RS_TR * W * sizeof(float);
+        ProfScope prof("uno::resample_fused_kernel", 4.0 * n_img * ((double)H * W + (double)Ho * Wo), s);
+        hipLaunchKernelGGL(resample_fused_kernel, dim3((Ho + RS_TR - 1) / RS_TR, n_img), dim3(256), lds, s, in, out, tile_p0, tile_w, NP,
+                           startW, wtW, KW, H, W, Ho, Wo);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
+        return 0;
+    }
     const int RPB = 16;
     // rows first when that shrinks the intermediate (Ho*W <= H*Wo), columns first otherwise
     const bool rows_first = (long long)Ho * W <= (long long)H * Wo;

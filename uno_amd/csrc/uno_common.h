@@ -109,6 +109,7 @@ int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
-                      const float* wtH, int KH, const int* startW, const float* wtW, int KW, hipStream_t s);
+                      const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                      const float* tile_w, int NP, hipStream_t s);
 
 }  // namespace uno

@@ -38,14 +38,47 @@ def _band(mat: torch.Tensor):
     return first.to(torch.int32), w.to(torch.float32), K
 
 
+TILE_ROWS = 16
+
+
+def _row_tiles(mat: torch.Tensor):
+    """Dense 16-output-row tiles of a banded operator: (first input row p0 [ntiles], weights [ntiles, NP, 16])
+    with weights[k, u, r] = mat[16 k + r, p0[k] + u] - the form the fused kernel's row phase consumes."""
+    n_out, n_in = mat.shape
+    first, w, K = _band(mat)
+    ntiles = (n_out + TILE_ROWS - 1) // TILE_ROWS
+    p0 = torch.zeros(ntiles, dtype=torch.int32)
+    spans = []
+    for k in range(ntiles):
+        rows = range(TILE_ROWS * k, min(TILE_ROWS * (k + 1), n_out))
+        lo = min(int(first[i]) for i in rows)
+        hi = max(min(int(first[i]) + K, n_in) for i in rows)
+        p0[k] = lo
+        spans.append(hi - lo)
+    NP = max(spans)
+    tw = torch.zeros(ntiles, NP, TILE_ROWS, dtype=torch.float32)
+    for k in range(ntiles):
+        for r in range(TILE_ROWS):
+            i = TILE_ROWS * k + r
+            if i >= n_out:
+                break
+            lo = int(p0[k])
+            seg = mat[i, lo:min(lo + NP, n_in)].to(torch.float32)
+            tw[k, :seg.numel(), r] = seg
+    return p0, tw
+
+
 @functools.lru_cache(maxsize=None)
 def _tables(n_in: int, n_out: int, device_str: str):
-    """((start, weights) of R, (start, weights) of R^T) on the device."""
+    """per direction (forward R, adjoint R^T): ((start, weights) band table, (p0, dense tile weights)) on the device."""
     R = _matrix(n_in, n_out)
     dev = torch.device(device_str)
-    s, w, _ = _band(R)
-    st, wt, _ = _band(R.t().contiguous())
-    return (s.to(dev), w.contiguous().to(dev)), (st.to(dev), wt.contiguous().to(dev))
+    out = []
+    for M in (R, R.t().contiguous()):
+        s, w, _ = _band(M)
+        p0, tw = _row_tiles(M)
+        out.append(((s.to(dev), w.contiguous().to(dev)), (p0.to(dev), tw.contiguous().to(dev))))
+    return tuple(out)
 
 
 class _Resample2dFn(torch.autograd.Function):
@@ -54,17 +87,17 @@ class _Resample2dFn(torch.autograd.Function):
         x = x.contiguous()
         H, W = x.shape[-2:]
         ctx.sizes = (H, W, Ho, Wo)
-        fh, _ = _tables(H, Ho, str(x.device))
-        fw, _ = _tables(W, Wo, str(x.device))
-        return _native.resample2d(x, Ho, Wo, fh, fw)
+        (fh, th), _ = _tables(H, Ho, str(x.device))
+        (fw, _), _ = _tables(W, Wo, str(x.device))
+        return _native.resample2d(x, Ho, Wo, fh, fw, th)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         H, W, Ho, Wo = ctx.sizes
-        _, bh = _tables(H, Ho, str(gy.device))
-        _, bw = _tables(W, Wo, str(gy.device))
-        return _native.resample2d(gy.contiguous(), H, W, bh, bw), None, None
+        _, (bh, th) = _tables(H, Ho, str(gy.device))
+        _, (bw, _) = _tables(W, Wo, str(gy.device))
+        return _native.resample2d(gy.contiguous(), H, W, bh, bw, th), None, None
 
 
 def resample2d_bicubic_aa(x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
