@@ -70,27 +70,35 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restr
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
 
-__global__ __launch_bounds__(256) void resample_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(512) void resample_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
                                                              int H, int W, int Ho, int Wo) {
-    extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][W]
+    extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][W] then the tile's dense weights [NP][16]
     const int n = blockIdx.y;
     const int tile = blockIdx.x;
     const int i0 = tile * RS_TR;
     const int tid = threadIdx.x;
     const int p0 = tile_p0[tile];
-    const float* wd = tile_w + (size_t)tile * NP * RS_TR;           // [NP][16], zero outside the band
+    float* sWd = V + RS_TR * ((W + 3) & ~3);
+    const int nthreads = blockDim.x;
+    for (int e = tid; e < NP * RS_TR; e += nthreads) sWd[e] = tile_w[(size_t)tile * NP * RS_TR + e];   // [NP][16], zero outside the band
+    __syncthreads();
     const float* src = in + (size_t)n * H * W;
-    for (int q = tid; q < W; q += 256) {
+    for (int q = tid; q < W; q += nthreads) {
         float acc[RS_TR];
 #pragma unroll
         for (int r = 0; r < RS_TR; ++r) acc[r] = 0.f;
+#pragma unroll 4
         for (int u = 0; u < NP; ++u) {
             const float x = src[(size_t)min(p0 + u, H - 1) * W + q];
-            const float* w = wd + u * RS_TR;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(sWd + u * RS_TR);      // wave-uniform address: LDS broadcast
 #pragma unroll
-            for (int r = 0; r < RS_TR; ++r) acc[r] = fmaf(w[r], x, acc[r]);
+            for (int r4 = 0; r4 < RS_TR / 4; ++r4) {
+                const f32x4 w = w4[r4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * r4 + e] = fmaf(w[e], x, acc[4 * r4 + e]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < RS_TR; ++r) V[r * W + q] = acc[r];
@@ -98,18 +106,25 @@ __global__ __launch_bounds__(256) void resample_fused_kernel(const float* __rest
     __syncthreads();
     float* dst = out + ((size_t)n * Ho + i0) * Wo;
     const int nr = min(RS_TR, Ho - i0);
-    for (int j = tid; j < Wo; j += 256) {
-        const int s = startW[j];
-        float w[16];
+    // phase 2: thread -> (row group g, column j): when the workgroup is wider than a row, groups take rows round-robin
+    const int WoP = (Wo + 63) & ~63;
+    const int G = max(1, nthreads / WoP);
+    const int g = tid / WoP;
+    const int jstride = G == 1 ? nthreads : WoP;
+    if (g < G) {
+        for (int j = tid - g * WoP; j < Wo; j += jstride) {
+            const int s = startW[j];
+            float w[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) w[t] = t < KW ? wtW[(size_t)j * KW + t] : 0.f;
-        for (int r = 0; r < nr; ++r) {
-            const float* v = V + r * W;
-            float acc = 0.f;
+            for (int t = 0; t < 16; ++t) w[t] = t < KW ? wtW[(size_t)j * KW + t] : 0.f;
+            for (int r = g; r < nr; r += G) {
+                const float* v = V + r * W;
+                float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
-                if (t < KW) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
-            dst[(size_t)r * Wo + j] = acc;
+                for (int t = 0; t < 16; ++t)
+                    if (t < KW) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
+                dst[(size_t)r * Wo + j] = acc;
+            }
         }
     }
 }
@@ -120,9 +135,12 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
     if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
     if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
-        const size_t lds = (size_t)RS_TR * W * sizeof(float);
+        const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)NP * RS_TR * sizeof(float);
         ProfScope prof("uno::resample_fused_kernel", 4.0 * n_img * ((double)H * W + (double)Ho * Wo), s);
-        hipLaunchKernelGGL(resample_fused_kernel, dim3((Ho + RS_TR - 1) / RS_TR, n_img), dim3(256), lds, s, in, out, tile_p0, tile_w, NP,
+        // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
+        const int sweeps = (W + 511) / 512;
+        const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
+        hipLaunchKernelGGL(resample_fused_kernel, dim3((Ho + RS_TR - 1) / RS_TR, n_img), dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP,
                            startW, wtW, KW, H, W, Ho, Wo);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
