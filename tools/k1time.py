@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from uno_amd import _native
-B, C, S, m = 16, 64, 421, 20
+B, C, S, m = 16, 64, int(os.environ.get('S', 421)), 20
 dev = torch.device("cuda:0")
 x = torch.randn(B, C, S, S, device=dev)
 O = torch.randn(B, C, 2 * m, m, dtype=torch.cfloat, device=dev)
@@ -16,4 +16,5 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 t1 = timeit(lambda: _native.dft2d_forward(x, m, m))
 t3 = timeit(lambda: _native.dft2d_inverse(O, S, S))
-print(f"{os.environ.get('UNO_AMD_LIB','product'):50s} K1 {t1:7.1f} us   K3 {t3:7.1f} us")
+gb = B * C * S * S * 4 / 1e9
+print(f"{os.environ.get('UNO_AMD_LIB','product'):50s} S={S} K1 {t1:7.1f} us ({gb/t1*1e3:5.2f} TB/s)   K3 {t3:7.1f} us ({gb/t3*1e3:5.2f} TB/s)")

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
                     if (h < H) {
                         float* rowp = img + (size_t)h * W;
                         const int cl = c0 + 4 * r16;        // first of this lane's four left columns
-                        if (cl + 3 <= Wh) {
+                        if ((UNO_ABLATE & 4) && cl + 3 <= Wh) {     // timing probe only: 16-byte aligned (wrong) destination
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<uintptr_t>(rowp + cl) & ~uintptr_t(15)) = vl;
+                        } else if (cl + 3 <= Wh) {
                             *reinterpret_cast<f4u*>(rowp + cl) = f4u{{vl[0], vl[1], vl[2], vl[3]}};
                         } else {
 #pragma unroll
@@ -187,7 +189,9 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
                                 if (cl + e <= Wh) rowp[cl + e] = vl[e];
                         }
                         const int cr = cr0 + 4 * r16;       // mirrored columns must stay in (Wh, W-1]
-                        if (cr > Wh && cr + 3 < W) {
+                        if ((UNO_ABLATE & 4) && cr > Wh && cr + 3 < W) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<uintptr_t>(rowp + cr) & ~uintptr_t(15)) = vr;
+                        } else if (cr > Wh && cr + 3 < W) {
                             *reinterpret_cast<f4u*>(rowp + cr) = f4u{{vr[0], vr[1], vr[2], vr[3]}};
                         } else {
 #pragma unroll
