@@ -30,15 +30,19 @@ namespace uno {
 constexpr int STG_COLS = 64;            // columns per staged chunk (4 MFMA column tiles)
 constexpr int STG_RS = STG_COLS + 4;    // LDS row stride in floats: 16-byte aligned, 4-bank skew per row
 
-template <int NT, int JT>
+// KS = ceil(modes2 / 4): k-steps of the row stage (compile-time, so the MFMA chains are straight-line code);
+// JT = ceil(2 modes1 / 16): 16-row tiles of corner rows.
+template <int KS, int JT>
 constexpr int inv_waves_per_simd() {
-    // resident O operand (8 NT JT) + U accumulators and twiddle walk state (36 NT) + addressing etc.
-    constexpr int regs = 8 * NT * JT + 36 * NT + 40;
+    constexpr int NT = (KS + 3) / 4;
+    // resident P/M operand (4 NT (2 JT + 1)) + U accumulators (8 NT) + twiddle walk state (7 KS) + addressing etc.
+    constexpr int regs = 4 * NT * (2 * JT + 1) + 8 * NT + 7 * KS + 44;
     return regs <= 120 ? 4 : (regs <= 160 ? 3 : (regs <= 230 ? 2 : 1));
 }
 
-template <int NT, int JT>
-__global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv_kernel(Dft2dParams p) {
+template <int KS, int JT>
+__global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv_kernel(Dft2dParams p) {
+    constexpr int NT = (KS + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, W = p.W, m1 = p.m1, m2 = p.m2;
     float* sStage = reinterpret_cast<float*>(smem);                       // [NW][2][16][STG_RS]
@@ -47,34 +51,39 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
     const int NW = nthreads >> 6;
     float2* sTwW = reinterpret_cast<float2*>(sStage + NW * 2 * 16 * STG_RS);
     float2* sTwH = sTwW + W;
-    unsigned* sIdxA0 = reinterpret_cast<unsigned*>(sTwH + H);          // [4 NT][64]: start of the stage-A' twiddle walk
+    unsigned* sIdxA0 = reinterpret_cast<unsigned*>(sTwH + H);          // [KS][64]: start of the stage-A' twiddle walk
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int r16 = lane & 15;
     const int kk = lane >> 4;
     const unsigned W8 = 8u * W, H8 = 8u * H;
-    constexpr int KSJ = 4 * JT;                 // k-steps over corner rows
-    constexpr int KSA = 4 * NT;                 // upper bound of k-steps over modes
-    const int ksa = (m2 + 3) >> 2;              // k-steps actually needed
+    constexpr int KSA = KS;                     // k-steps over modes
 
     for (int n = tid; n < W; n += nthreads) sTwW[n] = p.twW[n];
     for (int n = tid; n < H; n += nthreads) sTwH[n] = p.twH[n];
 
-    // stage-B' A operand: O[mode(rho)][j = 4 ks + kk], rho = r16, mode = 16 t + 4 (rho & 3) + (rho >> 2)
+    // stage-B' A operand.  The corner rows come in +-k pairs (lo corner row k <-> frequency +k, hi corner row
+    // 2 m1 - k <-> frequency -k), so with P_k = O[+k] + O[-k], M_k = O[+k] - O[-k]:
+    //     U[h] = sum_{k=0}^{m1} cos(theta_k h) P_k + i sin(theta_k h) M_k          (theta_k = 2 pi k / H)
+    // i.e. m1 + 1 real twiddle pairs instead of 2 m1 complex ones - 40 % fewer MFMAs in this stage.
+    // Operand lane (rho = r16 -> mode 16 t + 4 (rho & 3) + (rho >> 2), k-slot kk -> k = 4 ks + kk).
+    constexpr int KSK = 2 * JT + 1;                       // >= ceil((m1 + 1) / 4)
+    const int ksk = (m1 + 4) >> 2;                        // k-steps actually needed
     const float2* O = reinterpret_cast<const float2*>(p.in) + (size_t)blockIdx.x * 2 * m1 * m2;
-    float Or[NT][KSJ], Oi[NT][KSJ];
+    float Pr[NT][KSK], Pi[NT][KSK], Mr[NT][KSK], Mi[NT][KSK];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int l = 16 * t + 4 * (r16 & 3) + (r16 >> 2);
         const float cs = p.scale * ((p.herm && l < m2) ? herm_weight(l, W) : 1.0f);
 #pragma unroll
-        for (int ks = 0; ks < KSJ; ++ks) {
-            const int j = 4 * ks + kk;
-            float2 v = make_float2(0.f, 0.f);
-            if (l < m2 && j < 2 * m1 && !(p.mask && !row_survives(j, m1, H))) v = O[(size_t)j * m2 + l];
-            Or[t][ks] = v.x * cs;
-            Oi[t][ks] = v.y * cs;
+        for (int ks = 0; ks < KSK; ++ks) {
+            const int k = 4 * ks + kk;
+            float2 vp = make_float2(0.f, 0.f), vm = make_float2(0.f, 0.f);
+            if (l < m2 && k < m1 && !(p.mask && !row_survives(k, m1, H))) vp = O[(size_t)k * m2 + l];                 // +k: lo corner row k
+            if (l < m2 && k >= 1 && k <= m1) vm = O[(size_t)(2 * m1 - k) * m2 + l];                                      // -k: hi corner row 2 m1 - k
+            Pr[t][ks] = (vp.x + vm.x) * cs; Pi[t][ks] = (vp.y + vm.y) * cs;
+            Mr[t][ks] = (vp.x - vm.x) * cs; Mi[t][ks] = (vp.y - vm.y) * cs;
         }
     }
     // stage-A' twiddle walk (A operand): lane (i = r16 -> column w = 16 wt + r16, k-slot kk -> mode 4 sp + kk)
@@ -99,28 +108,27 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
     float* stR = stL + 16 * STG_RS;                            // mirrored-half chunk
 
     for (int rt = wave; rt < nrt; rt += NW) {
-        // ---- stage B': B operand = exp(+i theta), theta = 2 pi K_j h / H, lane: k-slot kk (j = 4ks+kk), col = h
+        // ---- stage B': B operand = (cos, sin)(2 pi k h / H), lane: k-slot kk (k = 4 ks + kk), column = row h of the tile
         const unsigned hB = (unsigned)min(16 * rt + r16, H - 1);
-        const unsigned a4 = 8u * ((4u * hB) % (unsigned)H);               // advance of (j h mod H) per k-step
-        const unsigned b2 = 8u * ((2u * (unsigned)m1 * hB) % (unsigned)H);  // (2 m1 h) mod H
-        unsigned aj = 8u * (((unsigned)kk * hB) % (unsigned)H);          // (j h) mod H, j = kk
+        const unsigned a4 = 8u * ((4u * hB) % (unsigned)H);               // advance of (k h mod H) per k-step
+        unsigned aj = 8u * (((unsigned)kk * hB) % (unsigned)H);          // (k h) mod H, k = kk
         f32x4 Ur[NT], Ui[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Ur[t] = f32x4{0, 0, 0, 0}; Ui[t] = f32x4{0, 0, 0, 0}; }
-        float2 twb = lds_tw(sTwH, (kk >= m1) ? wrap_sub(aj, b2, H8) : aj);
+        float2 twb = lds_tw(sTwH, aj);
 #pragma unroll
-        for (int ks = 0; ks < KSJ; ++ks) {
-            // prefetch the next k-step's twiddle: K_j = j (lo corner) or j - 2 m1 mod H (hi corner)
+        for (int ks = 0; ks < KSK; ++ks) {
             aj = wrap_add(aj, a4, H8);
-            const int jn = 4 * (ks + 1) + kk;
-            const float2 twn = lds_tw(sTwH, (jn >= m1) ? wrap_sub(aj, b2, H8) : aj);
-            const float ns = -twb.y;
+            const float2 twn = lds_tw(sTwH, aj);        // next k-step's twiddle (LDS latency hides behind the MFMAs)
+            if (ks < ksk) {
+                const float ns = -twb.y;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                Ur[t] = mfma16(Or[t][ks], twb.x, Ur[t]);
-                Ui[t] = mfma16(Or[t][ks], twb.y, Ui[t]);
-                Ur[t] = mfma16(Oi[t][ks], ns, Ur[t]);
-                Ui[t] = mfma16(Oi[t][ks], twb.x, Ui[t]);
+                for (int t = 0; t < NT; ++t) {
+                    Ur[t] = mfma16(Pr[t][ks], twb.x, Ur[t]);
+                    Ui[t] = mfma16(Pi[t][ks], twb.x, Ui[t]);
+                    Ur[t] = mfma16(Mi[t][ks], ns, Ur[t]);
+                    Ui[t] = mfma16(Mr[t][ks], twb.y, Ui[t]);
+                }
             }
             twb = twn;
         }
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
                     float2 twn[KSA];
 #pragma unroll
                     for (int sp = 0; sp < KSA; ++sp) {
-                        if (sp < ksa) {
+                        if (true) {
                             twn[sp] = (UNO_ABLATE & 1) ? twa[sp] : lds_tw(sTwW, idxA[sp]);
                             idxA[sp] = wrap_add(idxA[sp], stepA[sp], W8);
                         }
@@ -151,14 +159,14 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
                     f32x4 Ey = f32x4{0, 0, 0, 0}, Dy = f32x4{0, 0, 0, 0};
 #pragma unroll
                     for (int sp = 0; sp < KSA; ++sp) {
-                        if (sp < ksa) {
+                        if (true) {
                             Ey = mfma16(twa[sp].x, Ur[sp >> 2][sp & 3], Ey);
                             Dy = mfma16(twa[sp].y, Ui[sp >> 2][sp & 3], Dy);
                         }
                     }
 #pragma unroll
                     for (int sp = 0; sp < KSA; ++sp)
-                        if (sp < ksa) twa[sp] = twn[sp];
+                        twa[sp] = twn[sp];
                     // stage: left columns ascending, mirrored columns (W - w) ascending == w descending
                     const f32x4 yl = Ey - Dy;
                     const f32x4 yr = Ey + Dy;
@@ -169,18 +177,45 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
             // write the chunk out: pass q covers rows 4q..4q+3, each 16-lane group one 256-byte row segment
             const int c0 = STG_COLS * ch;                   // left chunk = columns c0 .. c0+63
             const int cr0 = W - c0 - (STG_COLS - 1);        // mirrored chunk = columns cr0 .. cr0+63  (= W - w)
-            if (!(UNO_ABLATE & 2)) {
+            // fast path (wave-uniform): all 16 rows exist and both 64-column windows lie strictly inside their halves
+            const bool rows_full = 16 * rt + 15 < H;
+            const bool left_full = c0 + STG_COLS - 1 <= Wh;
+            const bool right_full = cr0 > Wh && cr0 + STG_COLS - 1 < W;
+            if (!(UNO_ABLATE & 2) && rows_full && (left_full || right_full)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 4 * q + kk;
+                    float* rowp = img + (size_t)(16 * rt + row) * W;
+                    if (left_full) {
+                        const f32x4 vl = *reinterpret_cast<const f32x4*>(stL + row * STG_RS + 4 * r16);
+                        if (UNO_ABLATE & 4)      // timing probe: the row segment snapped to a 64-byte boundary (wrong place)
+                            *reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(rowp + c0) & ~uintptr_t(63)) + 16 * r16) = vl;
+                        else
+                        *reinterpret_cast<f4u*>(rowp + c0 + 4 * r16) = f4u{{vl[0], vl[1], vl[2], vl[3]}};
+                    }
+                    if (right_full) {
+                        const f32x4 vr = *reinterpret_cast<const f32x4*>(stR + row * STG_RS + 4 * r16);
+                        if (UNO_ABLATE & 4)
+                            *reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(rowp + cr0) & ~uintptr_t(63)) + 16 * r16) = vr;
+                        else
+                        *reinterpret_cast<f4u*>(rowp + cr0 + 4 * r16) = f4u{{vr[0], vr[1], vr[2], vr[3]}};
+                    }
+                }
+            }
+            const bool do_left = !(rows_full && left_full), do_right = !(rows_full && right_full);
+            if (!(UNO_ABLATE & 2) && (do_left || do_right)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = 4 * q + kk;
                     const int h = 16 * rt + row;
                     const f32x4 vl = *reinterpret_cast<const f32x4*>(stL + row * STG_RS + 4 * r16);
                     const f32x4 vr = *reinterpret_cast<const f32x4*>(stR + row * STG_RS + 4 * r16);
-                    if (h < H) {
+                    if (UNO_ABLATE & 32) {      // timing probe: LDS read-back kept, global stores dropped
+                        asm volatile("" ::"v"(vl[0]), "v"(vl[3]), "v"(vr[0]), "v"(vr[3]));
+                    } else if (h < H) {
                         float* rowp = img + (size_t)h * W;
                         const int cl = c0 + 4 * r16;        // first of this lane's four left columns
-                        if ((UNO_ABLATE & 4) && cl + 3 <= Wh) {     // timing probe only: 16-byte aligned (wrong) destination
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<uintptr_t>(rowp + cl) & ~uintptr_t(15)) = vl;
+                        if (!do_left) {
                         } else if (cl + 3 <= Wh) {
                             *reinterpret_cast<f4u*>(rowp + cl) = f4u{{vl[0], vl[1], vl[2], vl[3]}};
                         } else {
@@ -189,8 +224,7 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
                                 if (cl + e <= Wh) rowp[cl + e] = vl[e];
                         }
                         const int cr = cr0 + 4 * r16;       // mirrored columns must stay in (Wh, W-1]
-                        if ((UNO_ABLATE & 4) && cr > Wh && cr + 3 < W) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<uintptr_t>(rowp + cr) & ~uintptr_t(15)) = vr;
+                        if (!do_right) {
                         } else if (cr > Wh && cr + 3 < W) {
                             *reinterpret_cast<f4u*>(rowp + cr) = f4u{{vr[0], vr[1], vr[2], vr[3]}};
                         } else {
@@ -205,13 +239,13 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<NT, JT>())) void dft2d_inv
     }
 }
 
-template <int NT, int JT>
+template <int KS, int JT>
 static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
     const int nrt = (p.H + 15) / 16;
     const int NW = pick_waves_per_image(nrt);
-    const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)NW * 2 * 16 * STG_RS * sizeof(float) + (size_t)4 * NT * 64 * 4;
+    const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)NW * 2 * 16 * STG_RS * sizeof(float) + (size_t)KS * 64 * 4;
     if (lds > 160 * 1024) { set_error("dft2d_inv: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
-    auto k = dft2d_inv_kernel<NT, JT>;
+    auto k = dft2d_inv_kernel<KS, JT>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("dft2d_inv: cannot raise dynamic LDS to %zu", lds);
@@ -219,7 +253,7 @@ static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
         }
     }
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d>", NT, JT);
+    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d>", KS, JT);
     {
         ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
@@ -229,12 +263,20 @@ static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
     return 0;
 }
 
-int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s) {
-    const int NT = (p.m2 + 15) / 16, JT = (2 * p.m1 + 15) / 16;
-#define UNO_CASE(nt, jt) if (NT == nt && JT == jt) return launch_inv_t<nt, jt>(p, s);
-    UNO_CASE(1, 1) UNO_CASE(1, 2) UNO_CASE(1, 3) UNO_CASE(1, 4) UNO_CASE(1, 5)
-    UNO_CASE(2, 1) UNO_CASE(2, 2) UNO_CASE(2, 3) UNO_CASE(2, 4) UNO_CASE(2, 5)
-    UNO_CASE(3, 1) UNO_CASE(3, 2) UNO_CASE(3, 3) UNO_CASE(3, 4) UNO_CASE(3, 5)
+#ifndef UNO_INV_KS_LO
+#define UNO_INV_KS_LO 1
+#define UNO_INV_KS_HI 12
+#define UNO_INV_DISPATCH launch_dft2d_inv
+#endif
+
+// one translation unit instantiates a range of KS (the build compiles dft2d_inv.hip twice with different ranges)
+int UNO_INV_DISPATCH(const Dft2dParams& p, hipStream_t s) {
+    const int KS = (p.m2 + 3) / 4, JT = (2 * p.m1 + 15) / 16;
+#define UNO_CASE(ks, jt) if (ks >= UNO_INV_KS_LO && ks <= UNO_INV_KS_HI && KS == ks && JT == jt) return launch_inv_t<ks, jt>(p, s);
+#define UNO_ROW(ks) UNO_CASE(ks, 1) UNO_CASE(ks, 2) UNO_CASE(ks, 3) UNO_CASE(ks, 4) UNO_CASE(ks, 5)
+    UNO_ROW(1) UNO_ROW(2) UNO_ROW(3) UNO_ROW(4) UNO_ROW(5) UNO_ROW(6)
+    UNO_ROW(7) UNO_ROW(8) UNO_ROW(9) UNO_ROW(10) UNO_ROW(11) UNO_ROW(12)
+#undef UNO_ROW
 #undef UNO_CASE
     set_error("dft2d_inv: modes (%d, %d) exceed the compiled range (modes1 <= 40, modes2 <= 48)", p.m1, p.m2);
     return -2;
