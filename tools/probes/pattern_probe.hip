@@ -39,15 +39,17 @@ __global__ __launch_bounds__(256) void wr(float* out, int H, int W, int P, int n
 }
 int main() {
     const int nimg = 1024, H = 416, W = 448;        // aligned stand-in for 421 x 421 (row = 1792 B)
-    float *a, *b; hipMalloc(&a, (size_t)nimg * H * W * 4); hipMalloc(&b, 1 << 20);
-    hipMemset(a, 0, (size_t)nimg * H * W * 4);
+    // four buffers used round-robin: 3 GB >> 256 MB Infinity Cache, so every pass is cold
+    float *bufs[4], *b; hipMalloc(&b, 1 << 20);
+    for (int i = 0; i < 4; ++i) { hipMalloc(&bufs[i], (size_t)nimg * H * W * 4); hipMemset(bufs[i], 0, (size_t)nimg * H * W * 4); }
     const int waves = nimg * ((H + 15) / 16);
     const int blocks = (waves * 64 + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int P : {16, 32, 64, 128, 256}) {
         for (int pass = 0; pass < 2; ++pass) {
             float best = 1e9;
-            for (int it = 0; it < 5; ++it) {
+            for (int it = 0; it < 8; ++it) {
+                float* a = bufs[it & 3];
                 hipEventRecord(e0);
                 if (pass == 0) hipLaunchKernelGGL(rd, dim3(blocks), dim3(256), 0, 0, a, b, H, W, P, nimg);
                 else hipLaunchKernelGGL(wr, dim3(blocks), dim3(256), 0, 0, a, H, W, P, nimg);
