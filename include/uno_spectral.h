@@ -111,6 +111,22 @@ int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, in
                    const int* startH, const float* wtH, int KH, const int* startW, const float* wtW, int KW,
                    const int* tile_p0, const float* tile_w, int NP, void* stream);
 
+/* Channel mixing of a channels-first tensor, y[b][o][p] = sum_i Wm(o,i) x[b][i][p] (+ bias[o]): the 1x1
+ * convolution of pointwise_op_2D / pointwise_op_3D (reference integral_operators.py:219, 439: nn.Conv2d/3d(in,
+ * out, 1)) and the lift / projection nn.Linear layers of the U-NO models (navier_stokes_uno2d.py fc0/fc1/fc2)
+ * applied without the channels-last permute.  x (B, Ci, P), y (B, Co, P), P = pixels per sample (contiguous).
+ * transpose_w = 0: w is (Co, Ci) row-major; transpose_w = 1: w is (Ci, Co) row-major and Wm = w^T (this is
+ * the input-gradient call: x := grad_y, Ci := forward Co).  bias may be NULL. */
+int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co,
+                    long long P, int transpose_w, void* stream);
+
+/* Weight / bias gradient of uno_channel_mix: gw[o][i] = sum_{b,p} gy[b][o][p] x[b][i][p], gb[o] = sum gy[b][o][p]
+ * (gb may be NULL).  ws: scratch of uno_channel_wgrad_ws_bytes() bytes; partial sums are combined in a fixed
+ * order (bit-reproducible run to run). */
+long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P);
+int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co,
+                      long long P, void* stream);
+
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.
  *   uno_profile_begin(max_records): start recording (drops records beyond max_records).

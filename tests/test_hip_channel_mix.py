@@ -1,0 +1,103 @@
+"""K8 / K9 (csrc/channel_mix.hip) against torch in float64: the 1x1 convolution of pointwise_op_2D/3D (reference
+integral_operators.py:219, 439) and the channels-first lift / projection layers - forward, input gradient,
+weight and bias gradient.  f32 accumulation: tolerance 2e-6 (l2-relative) for the channel sums, 2e-5 for the
+pixel-long reductions of the weight / bias gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # B, Ci, Co, P
+    (1, 1, 1, 1),
+    (2, 3, 5, 17),
+    (2, 16, 16, 128),
+    (3, 64, 64, 1000),
+    (2, 3, 32, 431 * 431),        # lift of the Darcy model (fc0)
+    (2, 64, 128, 215 * 215),
+    (2, 256, 256, 2500),
+    (4, 100, 36, 4097),
+    (1, 128, 1, 777),             # final projection
+    (5, 20, 70, 33),
+]
+
+
+def rel(a, b):
+    d = (a.double() - b).norm().item()
+    n = b.norm().item()
+    return d / n if n > 0 else d
+
+
+def _ref(x, w, b):
+    y = torch.matmul(w.double(), x.double())
+    if b is not None:
+        y = y + b.double().view(1, -1, 1)
+    return y
+
+
+@pytest.mark.parametrize("B,Ci,Co,P", SHAPES)
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_forward(B, Ci, Co, P, with_bias):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(B * 1000 + Ci * 10 + Co)
+    x = torch.randn(B, Ci, P, generator=g).cuda()
+    w = torch.randn(Co, Ci, generator=g).cuda()
+    b = torch.randn(Co, generator=g).cuda() if with_bias else None
+    y = _native.channel_mix(x, w, b)
+    assert rel(y, _ref(x, w, b)) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,P", SHAPES)
+def test_transposed(B, Ci, Co, P):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(7 + Ci)
+    gy = torch.randn(B, Co, P, generator=g).cuda()
+    w = torch.randn(Co, Ci, generator=g).cuda()
+    gx = _native.channel_mix(gy, w, None, transpose_w=True)
+    assert gx.shape == (B, Ci, P)
+    assert rel(gx, torch.matmul(w.double().t(), gy.double())) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,P", SHAPES)
+def test_wgrad(B, Ci, Co, P):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(11 + Co)
+    gy = torch.randn(B, Co, P, generator=g).cuda()
+    x = torch.randn(B, Ci, P, generator=g).cuda()
+    gw, gb = _native.channel_wgrad(gy, x)
+    ref_w = torch.einsum("bop,bip->oi", gy.double(), x.double())
+    ref_b = gy.double().sum(dim=(0, 2))
+    assert rel(gw, ref_w) < 2e-5
+    assert rel(gb, ref_b) < 2e-5
+    gw2, none = _native.channel_wgrad(gy, x, need_bias=False)
+    assert none is None and torch.equal(gw, gw2)          # fixed-order reduction: bit-reproducible
+
+
+def test_autograd_matches_conv2d():
+    from uno_amd.integral_operators import channel_mix
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(24, 40, 1).cuda()
+    x = torch.randn(3, 24, 37, 41, device="cuda", requires_grad=True)
+    y = channel_mix(x, conv.weight, conv.bias)
+    gy = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, (x, conv.weight, conv.bias), gy)
+    x2 = x.detach().double().requires_grad_(True)
+    conv2 = torch.nn.Conv2d(24, 40, 1).cuda().double()
+    conv2.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    y2 = conv2(x2)
+    gx2, gw2, gb2 = torch.autograd.grad(y2, (x2, conv2.weight, conv2.bias), gy.double())
+    assert gw.shape == conv.weight.shape
+    for a, b in ((y, y2), (gx, gx2), (gw, gw2), (gb, gb2)):
+        assert rel(a, b) < 1e-5
+
+
+def test_empty_batch_and_errors():
+    from uno_amd import _native
+    y = _native.channel_mix(torch.zeros(0, 4, 9, device="cuda"), torch.zeros(6, 4, device="cuda"))
+    assert y.shape == (0, 6, 9)
+    gw, gb = _native.channel_wgrad(torch.zeros(0, 6, 9, device="cuda"), torch.zeros(0, 4, 9, device="cuda"))
+    assert gw.abs().sum() == 0 and gb.abs().sum() == 0
+    with pytest.raises(RuntimeError):
+        _native.channel_mix(torch.zeros(1, 4, 9), torch.zeros(6, 4))               # CPU tensors
+    with pytest.raises(RuntimeError):
+        _native.channel_mix(torch.zeros(1, 5, 9, device="cuda"), torch.zeros(6, 4, device="cuda"))

@@ -38,6 +38,9 @@ _SIGNATURES = {
     "uno_spectral_conv3d_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp), _fp] + [_i] * 12 + [_fp]),
     "uno_cdft_axis": (C.c_int, [_fp, _fp] + [_i] * 6 + [C.c_float, _i, _fp]),
     "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp]),
+    "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
+    "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -267,6 +270,43 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None):
                                   _ptr(sW), _ptr(wW), wW.shape[1], *targs, _stream(x))
     _check(rc, "uno_resample2d")
     return out
+
+
+def channel_mix(x, w, bias=None, transpose_w: bool = False):
+    """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias."""
+    _require(x, torch.float32, "x")
+    _require(w, torch.float32, "weight")
+    if bias is not None:
+        _require(bias, torch.float32, "bias")
+    B, Ci, P = x.shape
+    Co = w.shape[1] if transpose_w else w.shape[0]
+    if (w.shape[0] if transpose_w else w.shape[1]) != Ci:
+        raise RuntimeError(f"uno_amd: weight {tuple(w.shape)} does not match {Ci} input channels")
+    y = torch.empty((B, Co, P), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().uno_channel_mix(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y),
+                                   B, Ci, Co, P, 1 if transpose_w else 0, _stream(x))
+    _check(rc, "uno_channel_mix")
+    return y
+
+
+def channel_wgrad(gy, x, need_bias: bool = True):
+    """gy (B, Co, P), x (B, Ci, P) -> gw (Co, Ci), gb (Co) or None."""
+    _require(gy, torch.float32, "grad_output")
+    _require(x, torch.float32, "x")
+    B, Co, P = gy.shape
+    B2, Ci, P2 = x.shape
+    if (B2, P2) != (B, P):
+        raise RuntimeError("uno_amd: grad_output and x disagree in batch / pixel count")
+    L = lib()
+    gw = torch.empty((Co, Ci), dtype=torch.float32, device=x.device)
+    gb = torch.empty((Co,), dtype=torch.float32, device=x.device) if need_bias else None
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, P)), dtype=torch.uint8, device=x.device)
+        rc = L.uno_channel_wgrad(_ptr(gy), _ptr(x), _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws),
+                                 B, Ci, Co, P, _stream(x))
+    _check(rc, "uno_channel_wgrad")
+    return gw, gb
 
 
 def profile_begin(max_records: int = 100000):

@@ -249,6 +249,32 @@ int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, in
     return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, (hipStream_t)stream);
 }
 
+int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
+                    int transpose_w, void* stream) {
+    if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
+    if (B == 0 || P == 0) return 0;
+    if (!x || !w || !y) { set_error("uno_channel_mix: null pointer"); return -1; }
+    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, (hipStream_t)stream);
+}
+
+long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
+    if (B < 1 || Ci < 1 || Co < 1 || P < 1) return 0;
+    return 4LL * channel_wgrad_ws_floats(B, Ci, Co, P, nullptr);
+}
+
+int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
+                      void* stream) {
+    if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
+    if (!gw) { set_error("uno_channel_wgrad: null pointer"); return -1; }
+    if (B == 0 || P == 0) {
+        hipMemsetAsync(gw, 0, sizeof(float) * Co * Ci, (hipStream_t)stream);
+        if (gb) hipMemsetAsync(gb, 0, sizeof(float) * Co, (hipStream_t)stream);
+        return 0;
+    }
+    if (!gy || !x || !ws) { set_error("uno_channel_wgrad: null pointer"); return -1; }
+    return launch_channel_wgrad(gy, x, gw, gb, (float*)ws, B, Ci, Co, P, (hipStream_t)stream);
+}
+
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
                   int mask_overlap, void* stream) {
     if (n_img < 0 || H < 1 || m1 < 1 || m1 > H || m2 < 1 || m3 < 1) {

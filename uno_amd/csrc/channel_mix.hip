@@ -1,0 +1,427 @@
+// K8 / K9 - channel mixing of channels-first tensors: the 1x1 convolution of pointwise_op_2D/3D (reference
+// integral_operators.py:210-243, 430-468: nn.Conv2d/3d(in, out, 1)) and the lift / projection Linear layers of the
+// U-NO models applied channels-first.
+//
+//   K8  Y[b][o][p] = sum_i Wm(o, i) * X[b][i][p] (+ bias[o])      forward, and - with Wm = W^T - the input gradient
+//   K9  gW[o][i]   = sum_{b,p} gY[b][o][p] * X[b][i][p],  gb[o] = sum_{b,p} gY[b][o][p]      weight / bias gradient
+//
+// X, Y are (B, C, P) with the pixel axis contiguous (no layout change for NCHW tensors).  rocBLAS runs these
+// skinny shapes (M = K = 64..256 channels, N = 12k..200k pixels) at ~30 % of what their memory traffic allows;
+// here both operands are staged through LDS with unit-stride loads along the pixel axis and consumed as
+// v_mfma_f32_16x16x4_f32 fragments (exact f32, same arithmetic as an fmaf chain).
+#include "uno_common.h"
+#include <cstdio>
+
+namespace uno {
+
+// ------------------------------------------------------------------------------------------------ K8
+constexpr int CM_PT = 128;          // pixels per workgroup
+constexpr int CM_MT = 64;           // output channels per workgroup (4 waves x 16)
+constexpr int CM_KC = 16;           // input channels per staged chunk
+constexpr int CM_XS = CM_PT + 16;   // LDS row stride of the X chunk  [KC][PT]: 4 consecutive rows hit disjoint bank groups
+constexpr int CM_WS = CM_MT + 16;   // LDS row stride of the W chunk  [KC][MT] (k-major)
+
+// four consecutive floats starting at row[px] with zeros past the row end (row has P >= 4 valid floats):
+// one unconditional 16-byte load from a clamped address, then a select network (no branches -> the load
+// stays in flight across the MFMA block)
+__device__ __forceinline__ float4 load4_tail(const float* row, int px, int P) {
+    const int pc = min(px, P - 4);
+    const f4u v = *reinterpret_cast<const f4u*>(row + pc);
+    const int sh = px - pc;
+    float t0 = v.v[0], t1 = v.v[1], t2 = v.v[2], t3 = v.v[3];
+    if (sh & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
+    if (sh & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
+    if (sh >= 4) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
+    return make_float4(t0, t1, t2, t3);
+}
+
+struct ChannelMixParams {
+    const float* x;         // (B, Ci, P)
+    const float* w;         // Wm(o, i) = w[o * w_so + i * w_si]
+    const float* bias;      // (Co) or nullptr
+    float* y;               // (B, Co, P)
+    int B, Ci, Co, P;
+    long long w_so, w_si;
+    int ncot;               // channel tiles per pixel tile
+    int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
+};
+
+// One short-lived workgroup per (pixel tile, channel tile, batch entry).  Measured alternatives that lost:
+// persistent workgroups with the chunk pipeline running across tiles (2x slower: with 4 resident workgroups per
+// CU nothing hides the per-chunk load -> LDS -> barrier chain, the hardware dispatcher does that better), and
+// 32-channel chunks with 16-byte loads and an LDS-transposed 512-byte-row epilogue (10-18 % slower).
+template <bool VEC>
+__global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
+    __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * CM_XS];
+    __shared__ float sW[2][CM_KC * CM_WS];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
+    // the k-th contiguous eighth of the tile list.  Neighbouring pixel tiles share the 128-byte lines at their
+    // boundary in every row (rows are only 4-byte aligned); on the same XCD they meet in one L2.
+    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntile) return;
+    const int p0 = (tile / p.ncot) * CM_PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
+    const float* xb = p.x + (size_t)b * p.Ci * p.P;
+
+    // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (VEC: row e / 32, px 4 (e % 32)) or
+    //               8 single elements (row e / 128, px e % 128);  W chunk = 16 k x 64 o -> 4 elements (k e % 16, o e / 16)
+    float4 rx[2];
+    float rw[4];
+    auto load_chunk = [&](int k0) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + 256 * u;
+                const int ci = k0 + (e >> 5);
+                float4 v = load4_tail(xb + (size_t)min(ci, p.Ci - 1) * p.P, p0 + (e & 31) * 4, p.P);
+                if (ci >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                rx[u] = v;
+            }
+        } else {
+            float* r = reinterpret_cast<float*>(rx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                const int ci = k0 + (e >> 7), pp = p0 + (e & 127);
+                r[u] = (ci < p.Ci && pp < p.P) ? xb[(size_t)ci * p.P + pp] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            const int k = e & 15, o = e >> 4;
+            const int ci = k0 + k, oo = o0 + o;
+            rw[u] = (ci < p.Ci && oo < p.Co) ? p.w[oo * p.w_so + ci * p.w_si] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + 256 * u;
+                *reinterpret_cast<float4*>(&sX[buf][(e >> 5) * CM_XS + (e & 31) * 4]) = rx[u];
+            }
+        } else {
+            const float* r = reinterpret_cast<const float*>(rx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                sX[buf][(e >> 7) * CM_XS + (e & 127)] = r[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            sW[buf][(e & 15) * CM_WS + (e >> 4)] = rw[u];
+        }
+    };
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+
+    const int nchunk = (p.Ci + CM_KC - 1) / CM_KC;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) load_chunk((c + 1) * CM_KC);        // global -> registers while this chunk is multiplied
+#pragma unroll
+        for (int ks = 0; ks < CM_KC / 4; ++ks) {
+            // D^T = X^T W^T: A[i = px][k] = X[k][16 mt + r16], B[k][j = o] = Wm(16 wave + r16, k): a lane ends up with
+            // 4 consecutive pixels of one output channel -> one 16-byte store
+            const float wv = sW[buf][(4 * ks + kk) * CM_WS + 16 * wave + r16];
+            const float* xrow = sX[buf] + (4 * ks + kk) * CM_XS + r16;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc[mt] = mfma16(xrow[16 * mt], wv, acc[mt]);
+        }
+        if (c + 1 < nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[px = 16 mt + 4 kk + r][o = 16 wave + r16]
+    const int o = o0 + 16 * wave + r16;
+    if (o < p.Co) {
+        const float bv = p.bias ? p.bias[o] : 0.f;
+        float* yrow = p.y + ((size_t)b * p.Co + o) * p.P;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int px = p0 + 16 * mt + 4 * kk;
+            if (px + 3 < p.P) {
+                f4u w4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4.v[r] = acc[mt][r] + bv;
+                *reinterpret_cast<f4u*>(yrow + px) = w4;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (px + r < p.P) yrow[px + r] = acc[mt][r] + bv;
+            }
+        }
+    }
+}
+
+int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
+                       int transpose_w, hipStream_t s) {
+    ChannelMixParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
+    // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
+    p.w_so = transpose_w ? 1 : Ci;
+    p.w_si = transpose_w ? Co : 1;
+    const long long npt = (P + CM_PT - 1) / CM_PT, ncot = (Co + CM_MT - 1) / CM_MT;
+    if (P > 0x7fffffffLL || npt * ncot > 0x7fffffffLL || B > 65535) { set_error("channel_mix: tensor too large"); return -2; }
+    p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
+    {
+        ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
+        if (P >= 4) hipLaunchKernelGGL(channel_mix_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(channel_mix_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("channel_mix launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K9
+constexpr int CW_T = 64;            // tile of output channels x tile of input channels per workgroup
+constexpr int CW_PK = 32;           // pixels per staged chunk
+constexpr int CW_S = CW_PK + 2;     // LDS row stride: 2 r16 + kk hits 32 distinct banks per half-wave
+
+struct ChannelWgradParams {
+    const float* gy;        // (B, Co, P)
+    const float* x;         // (B, Ci, P)
+    float* part;            // (nsplit, Co, Ci + 1) partial sums; column Ci holds the bias gradient
+    int B, Ci, Co, P, nsplit;
+    long long span;         // pixels per split (informational)
+};
+
+__global__ __launch_bounds__(256) void channel_wgrad_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    __shared__ float sG[2][CW_T * CW_S];
+    __shared__ float sXc[2][CW_T * CW_S];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile_i = (p.Ci + CW_T - 1) / CW_T;
+    const int o0 = (blockIdx.x / ntile_i) * CW_T, i0 = (blockIdx.x % ntile_i) * CW_T;
+    const int split = blockIdx.y;
+    const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, p.B * npc);
+
+    // staging: each operand chunk = 64 rows x 32 px of one batch entry -> 8 elements per thread (row e / 32, px e % 32)
+    float rg[8], rxv[8];
+    auto load_chunk = [&](int idx) {
+        const int b = idx / npc, pp0 = (idx - b * npc) * CW_PK;
+        const float* gb = p.gy + (size_t)b * p.Co * p.P;
+        const float* xb = p.x + (size_t)b * p.Ci * p.P;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            const int row = e >> 5, px = pp0 + (e & 31);
+            rg[u] = (px < p.P && o0 + row < p.Co) ? gb[(size_t)(o0 + row) * p.P + px] : 0.f;
+            rxv[u] = (px < p.P && i0 + row < p.Ci) ? xb[(size_t)(i0 + row) * p.P + px] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            sG[buf][(e >> 5) * CW_S + (e & 31)] = rg[u];
+            sXc[buf][(e >> 5) * CW_S + (e & 31)] = rxv[u];
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+    float bsum = 0.f;                                   // bias gradient: threads 0..63 own one output channel each (i-tile 0 only)
+
+    if (c_begin < c_end) { load_chunk(c_begin); store_chunk(0); }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < CW_PK / 4; ++ks) {
+            const float a = sG[buf][(16 * wave + r16) * CW_S + 4 * ks + kk];          // A[o][k = px]
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[nt] = mfma16(a, sXc[buf][(16 * nt + r16) * CW_S + 4 * ks + kk], acc[nt]);   // B[k = px][i]
+        }
+        if (i0 == 0 && tid < CW_T) {
+            const float* g = sG[buf] + tid * CW_S;
+#pragma unroll
+            for (int k = 0; k < CW_PK; ++k) bsum += g[k];
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[o = 16 wave + 4 kk + r][i = 16 nt + r16]
+    float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wave + 4 * kk + r;
+        if (o < p.Co) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int i = i0 + 16 * nt + r16;
+                if (i < p.Ci) part[(size_t)o * (p.Ci + 1) + i] = acc[nt][r];
+            }
+        }
+    }
+    if (i0 == 0 && tid < CW_T && o0 + tid < p.Co) part[(size_t)(o0 + tid) * (p.Ci + 1) + p.Ci] = bsum;
+}
+
+// Vector variant (P >= 64): 64-pixel chunks enumerated per batch entry, 16-byte loads, next chunk in registers
+// (32 dwords per thread in flight), bias partial sums taken from the registers on their way to LDS.
+constexpr int CWV_PK = 64;
+constexpr int CWV_S = CWV_PK + 2;       // 264-byte rows: 8-byte aligned for ds_write_b64, banks 2 r16 + kk on read
+
+__global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) float sG[CW_T * CWV_S];
+    __shared__ __attribute__((aligned(16))) float sXc[CW_T * CWV_S];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile_i = (p.Ci + CW_T - 1) / CW_T;
+    const int o0 = (blockIdx.x / ntile_i) * CW_T, i0 = (blockIdx.x % ntile_i) * CW_T;
+    const int split = blockIdx.y;
+    const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, p.B * npc);
+
+    float4 rg[4], rxv[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c4 = (tid & 15) * 4, row0 = tid >> 4;
+    auto load_chunk = [&](int idx) {
+        const int b = idx / npc, pp = (idx - b * npc) * CWV_PK;
+        const float* gb = p.gy + (size_t)b * p.Co * p.P;
+        const float* xb = p.x + (size_t)b * p.Ci * p.P;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 16 * u;
+            float4 g = load4_tail(gb + (size_t)min(o0 + row, p.Co - 1) * p.P, pp + c4, p.P);
+            float4 v = load4_tail(xb + (size_t)min(i0 + row, p.Ci - 1) * p.P, pp + c4, p.P);
+            if (o0 + row >= p.Co) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 + row >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            rg[u] = g; rxv[u] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 16 * u;
+            float2* dg = reinterpret_cast<float2*>(sG + row * CWV_S + c4);
+            float2* dx = reinterpret_cast<float2*>(sXc + row * CWV_S + c4);
+            dg[0] = make_float2(rg[u].x, rg[u].y); dg[1] = make_float2(rg[u].z, rg[u].w);
+            dx[0] = make_float2(rxv[u].x, rxv[u].y); dx[1] = make_float2(rxv[u].z, rxv[u].w);
+            bs[u] += (rg[u].x + rg[u].y) + (rg[u].z + rg[u].w);
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        store_chunk();
+        __syncthreads();
+        load_chunk(min(c + 1, c_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < CWV_PK / 4; ++ks) {
+            const float a = sG[(16 * wave + r16) * CWV_S + 4 * ks + kk];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[nt] = mfma16(a, sXc[(16 * nt + r16) * CWV_S + 4 * ks + kk], acc[nt]);
+        }
+        __syncthreads();
+    }
+
+    float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wave + 4 * kk + r;
+        if (o < p.Co) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int i = i0 + 16 * nt + r16;
+                if (i < p.Ci) part[(size_t)o * (p.Ci + 1) + i] = acc[nt][r];
+            }
+        }
+    }
+    if (i0 == 0) {          // bias gradient: the 16 threads that share a row hold its partial sums
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = bs[u];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            const int o = o0 + row0 + 16 * u;
+            if ((tid & 15) == 0 && o < p.Co) part[(size_t)o * (p.Ci + 1) + p.Ci] = v;
+        }
+    }
+}
+
+// fixed-order sum of the split-K partials (deterministic): gw (Co, Ci), gb (Co).  32 consecutive elements x 8
+// interleaved groups of splits per workgroup, the 8 group sums combined in order through LDS.
+__global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* part, float* gw, float* gb, int Co, int Ci, int nsplit) {
+    __shared__ float sh[8][33];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const int n = Co * (Ci + 1);
+    float acc = 0.f;
+    if (e < n)
+        for (int s = grp; s < nsplit; s += 8) acc += part[(size_t)s * n + e];
+    sh[grp][el] = acc;
+    __syncthreads();
+    if (grp == 0 && e < n) {
+        float t = sh[0][el];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += sh[g][el];
+        const int o = e / (Ci + 1), i = e % (Ci + 1);
+        if (i < Ci) gw[(size_t)o * Ci + i] = t;
+        else if (gb) gb[o] = t;
+    }
+}
+
+// split-K plan: ~1024 workgroups, each at least 4 chunks long; splits are whole chunks of one batch entry
+static void wgrad_plan(int B, int Ci, int Co, long long P, int* nsplit, int* npc, int* cps, int* pk) {
+    const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
+    *pk = P >= 64 ? CWV_PK : CW_PK;
+    *npc = (int)((P + *pk - 1) / *pk);
+    const long long nchunks = (long long)B * *npc;
+    long long want = (1024 + tiles - 1) / tiles;
+    long long per = (nchunks + want - 1) / want;
+    if (per < 4) per = 4;
+    *cps = (int)per;
+    *nsplit = (int)((nchunks + per - 1) / per);
+}
+
+long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out) {
+    int nsplit, npc, cps, pk;
+    wgrad_plan(B, Ci, Co, P, &nsplit, &npc, &cps, &pk);
+    if (nsplit_out) *nsplit_out = nsplit;
+    return (long long)nsplit * Co * (long long)(Ci + 1);
+}
+
+int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
+                         hipStream_t s) {
+    if (P > 0x7fffffffLL || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) { set_error("channel_wgrad: pixel count too large"); return -2; }
+    ChannelWgradParams p;
+    p.gy = gy; p.x = x; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
+    int npc, cps, pk;
+    wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
+    p.span = (long long)cps * pk;
+    const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
+    {
+        ProfScope prof("uno::channel_wgrad_kernel", 4.0 * B * (double)P * (Ci + Co), s);
+        if (pk == CWV_PK)
+            hipLaunchKernelGGL(channel_wgrad_vec_kernel, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
+        else
+            hipLaunchKernelGGL(channel_wgrad_kernel, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
+    }
+    const int n = Co * (Ci + 1);
+    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+}  // namespace uno

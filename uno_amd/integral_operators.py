@@ -76,14 +76,40 @@ class _SpectralConv2dFn(torch.autograd.Function):
         return gx, gw1, gw2, None, None
 
 
+class _ChannelMixFn(torch.autograd.Function):
+    """y[b] = W . x[b] + bias on (B, C, pixels) views with the K8 / K9 kernels (csrc/channel_mix.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = _plain(x), _plain(w)
+        y = _native.channel_mix(x, w, None if bias is None else _plain(bias))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _plain(gy)
+        gx = _native.channel_mix(gy, w, None, transpose_w=True) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _native.channel_wgrad(gy, x, need_bias=ctx.has_bias)
+        return gx, gw, gb
+
+
 def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
-    """1x1 convolution of a channels-first tensor as one batched GEMM  y[b] = W . x[b] (+ bias)  on the
-    (B, C, pixels) view - no layout change, no im2col, rocBLAS strided-batched underneath.  `weight` is a
-    Conv (Co, Ci, 1, ...) or Linear (Co, Ci) weight."""
+    """1x1 convolution of a channels-first tensor, y[b] = W . x[b] (+ bias) on the (B, C, pixels) view - no
+    layout change, no im2col.  `weight` is a Conv (Co, Ci, 1, ...) or Linear (Co, Ci) weight.  float32 tensors on
+    a HIP device run the K8 / K9 kernels; anything else (the CPU-side harness tests, other dtypes) is a stock
+    batched matmul - this helper is not part of the spectral path and keeps torch semantics there."""
     B, Ci = x.shape[0], x.shape[1]
     w = weight.reshape(weight.shape[0], Ci)
     xv = x.reshape(B, Ci, -1)
-    if bias is not None:
+    if x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
+        y = _ChannelMixFn.apply(xv, w, bias)
+    elif bias is not None:
         y = torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xv)
     else:
         y = torch.matmul(w, xv)
