@@ -106,19 +106,22 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
  * wtH[i*KH .. i*KH+KH-1] (zero padded); likewise B.  tmp: scratch of 4*n_img*min(Ho*W, H*Wo) bytes.
  * Optional dense row-tile form of A for the fused single-pass kernel (NULL / 0 to use the two-pass kernels):
  * tile k covers output rows 16k..16k+15, reads input rows tile_p0[k] .. tile_p0[k]+NP-1 and has weights
- * tile_w[(k*NP + u)*16 + r] = A[16k + r][tile_p0[k] + u]. */
+ * tile_w[(k*NP + u)*16 + r] = A[16k + r][tile_p0[k] + u].
+ * accumulate != 0: out += A . in . B^T (the spectral and the point-wise branch of an operator block write one
+ * buffer: reference integral_operators.py:273 `x1_out + x2_out`, and the sum of their input gradients). */
 int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo,
                    const int* startH, const float* wtH, int KH, const int* startW, const float* wtW, int KW,
-                   const int* tile_p0, const float* tile_w, int NP, void* stream);
+                   const int* tile_p0, const float* tile_w, int NP, int accumulate, void* stream);
 
 /* Channel mixing of a channels-first tensor, y[b][o][p] = sum_i Wm(o,i) x[b][i][p] (+ bias[o]): the 1x1
  * convolution of pointwise_op_2D / pointwise_op_3D (reference integral_operators.py:219, 439: nn.Conv2d/3d(in,
  * out, 1)) and the lift / projection nn.Linear layers of the U-NO models (navier_stokes_uno2d.py fc0/fc1/fc2)
  * applied without the channels-last permute.  x (B, Ci, P), y (B, Co, P), P = pixels per sample (contiguous).
  * transpose_w = 0: w is (Co, Ci) row-major; transpose_w = 1: w is (Ci, Co) row-major and Wm = w^T (this is
- * the input-gradient call: x := grad_y, Ci := forward Co).  bias may be NULL. */
+ * the input-gradient call: x := grad_y, Ci := forward Co).  bias may be NULL.  accumulate != 0: y += (as in
+ * uno_resample2d). */
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co,
-                    long long P, int transpose_w, void* stream);
+                    long long P, int transpose_w, int accumulate, void* stream);
 
 /* Weight / bias gradient of uno_channel_mix: gw[o][i] = sum_{b,p} gy[b][o][p] x[b][i][p], gb[o] = sum gy[b][o][p]
  * (gb may be NULL).  ws: scratch of uno_channel_wgrad_ws_bytes() bytes; partial sums are combined in a fixed

@@ -109,3 +109,33 @@ def test_model_product_vs_oracle_blocks_same_weights():
         g, gr = p.grad.cpu(), pr[k].grad
         n = float(torch.linalg.vector_norm(gr))
         assert float(torch.linalg.vector_norm(g - gr)) <= 2e-2 * n + 1e-5 * gmax, k
+
+
+@pytest.mark.parametrize("hw,out_hw", [((40, 36), (20, 18)), ((24, 28), (24, 28)), ((20, 18), (41, 37))])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_fused_block_equals_branch_sum(hw, out_hw, normalize):
+    """The one-buffer block (point-wise branch accumulating into the spectral branch's output, and likewise for
+    grad_x) against the plain sum of the two branch modules - down-sampling, same-size and up-sampling blocks."""
+    from uno_amd.integral_operators import OperatorBlock_2D
+    torch.manual_seed(3)
+    blk = OperatorBlock_2D(6, 10, out_hw[0], out_hw[1], 5, 4, Normalize=normalize).cuda()
+    x = torch.randn(3, 6, *hw, device="cuda", requires_grad=True)
+    params = [p for p in blk.parameters()]
+
+    y = blk(x)
+    gy = torch.randn_like(y)
+    got = torch.autograd.grad(y, [x] + params, gy)
+
+    s = blk.conv(x) + blk.w(x)                 # unfused composition of the same kernels
+    if normalize:
+        s = blk.normalize_layer(s)
+    y2 = torch.nn.functional.gelu(s)
+    ref = torch.autograd.grad(y2, [x] + params, gy)
+
+    def rel(a, b):
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    assert rel(y, y2) < 2e-6
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        assert rel(a, b) < 2e-5

@@ -101,3 +101,23 @@ def test_empty_batch_and_errors():
         _native.channel_mix(torch.zeros(1, 4, 9), torch.zeros(6, 4))               # CPU tensors
     with pytest.raises(RuntimeError):
         _native.channel_mix(torch.zeros(1, 5, 9, device="cuda"), torch.zeros(6, 4, device="cuda"))
+
+
+def test_accumulate():
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 20, 1000, generator=g).cuda()
+    w = torch.randn(12, 20, generator=g).cuda()
+    b = torch.randn(12, generator=g).cuda()
+    base = torch.randn(3, 12, 1000, generator=g).cuda()
+    out = base.clone()
+    ret = _native.channel_mix(x, w, b, out=out)
+    assert ret.data_ptr() == out.data_ptr()
+    assert rel(out, base.double() + _ref(x, w, b)) < 2e-6
+    gbase = torch.randn(3, 20, 1000, generator=g).cuda()
+    gout = gbase.clone()
+    gy = torch.randn(3, 12, 1000, generator=g).cuda()
+    _native.channel_mix(gy, w, None, transpose_w=True, out=gout)
+    assert rel(gout, gbase.double() + torch.matmul(w.double().t(), gy.double())) < 2e-6
+    with pytest.raises(RuntimeError):
+        _native.channel_mix(x, w, b, out=torch.zeros(3, 11, 1000, device="cuda"))

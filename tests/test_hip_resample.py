@@ -57,3 +57,24 @@ def test_pointwise_op_commuted_order_matches_reference_order():
         ref = so.pointwise2d(x, pw.conv.weight, pw.conv.bias, Ho, Ho)
         got = pw.to(dev)(x.to(dev))
         assert rel_err(got.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [((40, 36), (20, 18)), ((20, 18), (41, 37)), ((30, 1100), (15, 600))])
+def test_resample_accumulates_into_out(sizes):
+    """out= form (fused kernel and the two-pass fallback for rows too long for LDS): out += R x R^T."""
+    from uno_amd.resample import resample_forward, resample_adjoint
+    (H, W), (Ho, Wo) = sizes
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, H, W, generator=g).to(dev)
+    base = torch.randn(2, 3, Ho, Wo, generator=g).to(dev)
+    plain = resample_forward(x, Ho, Wo)
+    out = base.clone()
+    ret = resample_forward(x, Ho, Wo, out=out)
+    assert ret.data_ptr() == out.data_ptr()
+    assert rel_err(out.cpu().numpy(), (base + plain).cpu().numpy()) < 1e-6
+    gbase = torch.randn(2, 3, H, W, generator=g).to(dev)
+    gout = gbase.clone()
+    resample_adjoint(base, H, W, out=gout)
+    assert rel_err(gout.cpu().numpy(), (gbase + resample_adjoint(base, H, W)).cpu().numpy()) < 1e-6

@@ -37,8 +37,8 @@ _SIGNATURES = {
     "uno_spectral_conv3d_forward": (C.c_int, [_fp, C.POINTER(_fp), _fp, _fp, _fp] + [_i] * 12 + [_fp]),
     "uno_spectral_conv3d_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp), _fp] + [_i] * 12 + [_fp]),
     "uno_cdft_axis": (C.c_int, [_fp, _fp] + [_i] * 6 + [C.c_float, _i, _fp]),
-    "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _fp]),
-    "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _fp]),
+    "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
@@ -248,9 +248,10 @@ def spectral_conv3d_backward(gy, xt, ws_, H: int, W: int, T: int, need_gx=True, 
     return gx, gws
 
 
-def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None):
+def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
     """x (..., H, W) f32 -> (..., Ho, Wo); tabX = (start int32 [out], weights f32 [out, K]) band tables on x.device;
-    tilesH = (p0 int32 [ntiles], dense weights f32 [ntiles, NP, 16]) enables the fused single-pass kernel."""
+    tilesH = (p0 int32 [ntiles], dense weights f32 [ntiles, NP, 16]) enables the fused single-pass kernel.
+    out: accumulate into this (..., Ho, Wo) tensor instead of allocating the result."""
     _require(x, torch.float32, "x")
     *lead, H, W = x.shape
     n = 1
@@ -258,7 +259,13 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None):
         n *= d
     sH, wH = tabH
     sW, wW = tabW
-    out = torch.empty((*lead, Ho, Wo), dtype=torch.float32, device=x.device)
+    accumulate = out is not None
+    if accumulate:
+        _require(out, torch.float32, "out")
+        if tuple(out.shape) != (*lead, Ho, Wo):
+            raise RuntimeError(f"uno_amd: out has shape {tuple(out.shape)}, expected {(*lead, Ho, Wo)}")
+    else:
+        out = torch.empty((*lead, Ho, Wo), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         tmp = torch.empty(max(1, n * min(Ho * W, H * Wo)), dtype=torch.float32, device=x.device)
         if tilesH is not None:
@@ -267,13 +274,14 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None):
         else:
             targs = (C.c_void_p(0), C.c_void_p(0), 0)
         rc = lib().uno_resample2d(_ptr(x), _ptr(out), _ptr(tmp), n, H, W, Ho, Wo, _ptr(sH), _ptr(wH), wH.shape[1],
-                                  _ptr(sW), _ptr(wW), wW.shape[1], *targs, _stream(x))
+                                  _ptr(sW), _ptr(wW), wW.shape[1], *targs, 1 if accumulate else 0, _stream(x))
     _check(rc, "uno_resample2d")
     return out
 
 
-def channel_mix(x, w, bias=None, transpose_w: bool = False):
-    """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias."""
+def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None):
+    """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias;
+    out: accumulate into this (B, Co, P) tensor instead."""
     _require(x, torch.float32, "x")
     _require(w, torch.float32, "weight")
     if bias is not None:
@@ -282,10 +290,17 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False):
     Co = w.shape[1] if transpose_w else w.shape[0]
     if (w.shape[0] if transpose_w else w.shape[1]) != Ci:
         raise RuntimeError(f"uno_amd: weight {tuple(w.shape)} does not match {Ci} input channels")
-    y = torch.empty((B, Co, P), dtype=torch.float32, device=x.device)
+    accumulate = out is not None
+    if accumulate:
+        _require(out, torch.float32, "out")
+        if tuple(out.shape) != (B, Co, P):
+            raise RuntimeError(f"uno_amd: out has shape {tuple(out.shape)}, expected {(B, Co, P)}")
+        y = out
+    else:
+        y = torch.empty((B, Co, P), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = lib().uno_channel_mix(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y),
-                                   B, Ci, Co, P, 1 if transpose_w else 0, _stream(x))
+                                   B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, _stream(x))
     _check(rc, "uno_channel_mix")
     return y
 

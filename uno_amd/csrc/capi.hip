@@ -242,19 +242,19 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
 
 int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                    const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
-                   const float* tile_w, int NP, void* stream) {
+                   const float* tile_w, int NP, int accumulate, void* stream) {
     if (n_img < 0 || H < 1 || W < 1 || Ho < 1 || Wo < 1) { set_error("uno_resample2d: bad sizes"); return -1; }
     if (n_img == 0) return 0;
     if (!in || !out || !tmp || !startH || !wtH || !startW || !wtW) { set_error("uno_resample2d: null pointer"); return -1; }
-    return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, (hipStream_t)stream);
+    return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, accumulate, (hipStream_t)stream);
 }
 
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                    int transpose_w, void* stream) {
+                    int transpose_w, int accumulate, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (B == 0 || P == 0) return 0;
     if (!x || !w || !y) { set_error("uno_channel_mix: null pointer"); return -1; }
-    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, (hipStream_t)stream);
+    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, (hipStream_t)stream);
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {

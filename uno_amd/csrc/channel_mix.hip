@@ -44,6 +44,7 @@ struct ChannelMixParams {
     long long w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
+    int accumulate;         // y += instead of y =
 };
 
 // One short-lived workgroup per (pixel tile, channel tile, batch entry).  Measured alternatives that lost:
@@ -151,21 +152,24 @@ __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
             const int px = p0 + 16 * mt + 4 * kk;
             if (px + 3 < p.P) {
                 f4u w4;
+                if (p.accumulate) w4 = *reinterpret_cast<const f4u*>(yrow + px);
+                else w4.v[0] = w4.v[1] = w4.v[2] = w4.v[3] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w4.v[r] = acc[mt][r] + bv;
+                for (int r = 0; r < 4; ++r) w4.v[r] += acc[mt][r] + bv;
                 *reinterpret_cast<f4u*>(yrow + px) = w4;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (px + r < p.P) yrow[px + r] = acc[mt][r] + bv;
+                    if (px + r < p.P) yrow[px + r] = (p.accumulate ? yrow[px + r] : 0.f) + (acc[mt][r] + bv);
             }
         }
     }
 }
 
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, hipStream_t s) {
+                       int transpose_w, int accumulate, hipStream_t s) {
     ChannelMixParams p;
+    p.accumulate = accumulate ? 1 : 0;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
     // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
     p.w_so = transpose_w ? 1 : Ci;

@@ -18,7 +18,7 @@ namespace uno {
 // out[n][i][q] = sum_t wt[i][t] * in[n][start[i] + t][q]      (rows of length W)
 __global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             const int* __restrict__ start, const float* __restrict__ wt,
-                                                            int K, int H, int Ho, int W, int rows_per_block) {
+                                                            int K, int H, int Ho, int W, int rows_per_block, int accumulate) {
     const int n = blockIdx.z;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= W) return;
@@ -34,14 +34,14 @@ __global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restr
             const int p = min(s + t, H - 1);            // taps beyond the band carry weight 0
             acc = fmaf(w[t], src[(size_t)p * W], acc);
         }
-        dst[(size_t)i * W] = acc;
+        dst[(size_t)i * W] = accumulate ? dst[(size_t)i * W] + acc : acc;
     }
 }
 
 // out[n][r][j] = sum_t wt[j][t] * in[n][r][start[j] + t]
 __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             const int* __restrict__ start, const float* __restrict__ wt,
-                                                            int K, int R, int W, int Wo, int rows_per_block) {
+                                                            int K, int R, int W, int Wo, int rows_per_block, int accumulate) {
     const int n = blockIdx.z;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Wo) return;
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t < 16; ++t)
             if (t < K) acc = fmaf(w[t], src[min(s + t, W - 1)], acc);
-        out[((size_t)n * R + r) * Wo + j] = acc;
+        float* o = out + ((size_t)n * R + r) * Wo + j;
+        *o = accumulate ? *o + acc : acc;
     }
 }
 
@@ -73,7 +74,7 @@ constexpr int RS_TR = 16;
 __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
-                                                             int H, int W, int Ho, int Wo) {
+                                                             int H, int W, int Ho, int Wo, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][W] then the tile's dense weights [NP][16]
     const int n = blockIdx.y;
     const int tile = blockIdx.x;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     if (t < KW) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
-                dst[(size_t)r * Wo + j] = acc;
+                dst[(size_t)r * Wo + j] = accumulate ? dst[(size_t)r * Wo + j] + acc : acc;
             }
         }
     }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
 
 int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
-                      const float* tile_w, int NP, hipStream_t s) {
+                      const float* tile_w, int NP, int accumulate, hipStream_t s) {
     if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
     if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
@@ -141,7 +142,7 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
         const int sweeps = (W + 511) / 512;
         const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
         hipLaunchKernelGGL(resample_fused_kernel, dim3((Ho + RS_TR - 1) / RS_TR, n_img), dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP,
-                           startW, wtW, KW, H, W, Ho, Wo);
+                           startW, wtW, KW, H, W, Ho, Wo, accumulate);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
@@ -153,20 +154,20 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
     if (rows_first) {
         {
             ProfScope prof("uno::resample_rows_kernel", img_bytes * ((double)H * W + (double)Ho * W), s);
-            hipLaunchKernelGGL(resample_rows_kernel, dim3((W + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startH, wtH, KH, H, Ho, W, RPB);
+            hipLaunchKernelGGL(resample_rows_kernel, dim3((W + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startH, wtH, KH, H, Ho, W, RPB, 0);
         }
         {
             ProfScope prof("uno::resample_cols_kernel", img_bytes * ((double)Ho * W + (double)Ho * Wo), s);
-            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startW, wtW, KW, Ho, W, Wo, RPB);
+            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
         }
     } else {
         {
             ProfScope prof("uno::resample_cols_kernel", img_bytes * ((double)H * W + (double)H * Wo), s);
-            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (H + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB);
+            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (H + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
         }
         {
             ProfScope prof("uno::resample_rows_kernel", img_bytes * ((double)H * Wo + (double)Ho * Wo), s);
-            hipLaunchKernelGGL(resample_rows_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startH, wtH, KH, H, Ho, Wo, RPB);
+            hipLaunchKernelGGL(resample_rows_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startH, wtH, KH, H, Ho, Wo, RPB, accumulate);
         }
     }
     const hipError_t e = hipGetLastError();

@@ -110,9 +110,9 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
-                      const float* tile_w, int NP, hipStream_t s);
+                      const float* tile_w, int NP, int accumulate, hipStream_t s);
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, hipStream_t s);
+                       int transpose_w, int accumulate, hipStream_t s);
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          hipStream_t s);

@@ -116,6 +116,73 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     return y.view(B, w.shape[0], *x.shape[2:])
 
 
+class _OperatorBlock2dFn(torch.autograd.Function):
+    """s = SpectralConv2d_Uno(x) + pointwise_op_2D(x) in ONE buffer (reference integral_operators.py:270-273:
+    `x1_out = self.conv(x, ...); x2_out = self.w(x, ...); x_out = x1_out + x2_out`).
+
+    The spectral branch's inverse DFT writes s; the last kernel of the point-wise branch (the channel mix when the
+    block does not up-sample, the resampling otherwise) accumulates into it.  In the backward pass the spectral
+    branch writes grad_x and the point-wise branch's last kernel accumulates into that.  Neither sum exists as a
+    separate element-wise pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo):
+        from .resample import resample_forward
+        x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
+        B, Ci, H, W = x.shape
+        Co = cw.shape[0]
+        cwm = _plain(cw).reshape(Co, Ci)
+        cb = None if cb is None else _plain(cb)
+        s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo)
+        same = (H, W) == (Ho, Wo)
+        mix_last = same or Ho * Wo < H * W          # the 1x1 convolution runs on whichever side has fewer pixels
+        if mix_last:
+            act = x if same else resample_forward(x, Ho, Wo)
+            _native.channel_mix(act.view(B, Ci, -1), cwm, cb, out=s.view(B, Co, -1))
+        else:
+            act = x
+            t = _native.channel_mix(x.view(B, Ci, -1), cwm, cb)
+            resample_forward(t.view(B, Co, H, W), Ho, Wo, out=s)
+        ctx.save_for_backward(xt, w1, w2, cwm, act)
+        ctx.geom = (H, W, same, mix_last, cb is not None, tuple(cw.shape))
+        return s
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gs):
+        from .resample import resample_adjoint
+        xt, w1, w2, cwm, act = ctx.saved_tensors
+        H, W, same, mix_last, has_bias, cw_shape = ctx.geom
+        gs = _plain(gs)
+        B, Co, Ho, Wo = gs.shape
+        Ci = cwm.shape[1]
+        need_gx = ctx.needs_input_grad[0]
+        need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_gc = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
+        gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw)
+        gcw = gcb = None
+        if mix_last:
+            # forward: act = R x;  s += Wm act + b
+            if need_gx:
+                if same:
+                    _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True, out=gx.view(B, Ci, -1))
+                else:
+                    g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True)
+                    resample_adjoint(g_act.view(B, Ci, Ho, Wo), H, W, out=gx)
+            if need_gc:
+                gcw, gcb = _native.channel_wgrad(gs.view(B, Co, -1), act.view(B, Ci, -1), need_bias=has_bias)
+        else:
+            # forward: t = Wm x + b;  s += R t
+            g_t = resample_adjoint(gs, H, W).view(B, Co, -1)
+            if need_gx:
+                _native.channel_mix(g_t, cwm, None, transpose_w=True, out=gx.view(B, Ci, -1))
+            if need_gc:
+                gcw, gcb = _native.channel_wgrad(g_t, act.view(B, Ci, -1), need_bias=has_bias)
+        if gcw is not None:
+            gcw = gcw.view(cw_shape)
+        return gx, gw1, gw2, gcw, gcb, None, None
+
+
 def spectral_conv2d(x, weights1, weights2, dim1, dim2):
     """Functional form of SpectralConv2d_Uno.forward (reference integral_operators.py:181-207)."""
     return _SpectralConv2dFn.apply(x, weights1, weights2, dim1, dim2)
@@ -192,12 +259,25 @@ class OperatorBlock_2D(nn.Module):
             self.normalize_layer = nn.InstanceNorm2d(int(out_codim), affine=True)
 
     def forward(self, x, dim1=None, dim2=None):
-        out = self.conv(x, dim1, dim2) + self.w(x, dim1, dim2)
+        out = self._branches(x, dim1, dim2)
         if self.normalize:
             out = self.normalize_layer(out)
         if self.non_lin:
             out = F.gelu(out)
         return out
+
+    def _branches(self, x, dim1, dim2):
+        conv, w = self.conv, self.w
+        if dim1 is not None:        # the spectral layer keeps a call-time override, the point-wise one does not (:182-184, :236-238)
+            conv.dim1, conv.dim2 = dim1, dim2
+            d1, d2 = dim1, dim2
+        else:
+            d1, d2 = w.dim1, w.dim2
+        fused = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (conv.dim1, conv.dim2) == (d1, d2)
+                 and x.shape[1] == conv.in_channels and w.conv.weight.dtype == torch.float32)
+        if not fused:               # CPU tensors raise inside the spectral layer; mismatched grids raise at the sum
+            return conv(x) + w(x, d1, d2)
+        return _OperatorBlock2dFn.apply(x, conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2))
 
 
 # --------------------------------------------------------------------------------------------- 3-D

@@ -81,23 +81,33 @@ def _tables(n_in: int, n_out: int, device_str: str):
     return tuple(out)
 
 
+def resample_forward(x: torch.Tensor, Ho: int, Wo: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """R_h x R_w^T on the device (no autograd); with `out`, accumulates into it."""
+    H, W = x.shape[-2:]
+    (fh, th), _ = _tables(H, Ho, str(x.device))
+    (fw, _), _ = _tables(W, Wo, str(x.device))
+    return _native.resample2d(x, Ho, Wo, fh, fw, th, out=out)
+
+
+def resample_adjoint(gy: torch.Tensor, H: int, W: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Adjoint of resample_forward for an (H, W) input grid: R_h^T gy R_w; with `out`, accumulates into it."""
+    Ho, Wo = gy.shape[-2:]
+    _, (bh, th) = _tables(H, Ho, str(gy.device))
+    _, (bw, _) = _tables(W, Wo, str(gy.device))
+    return _native.resample2d(gy, H, W, bh, bw, th, out=out)
+
+
 class _Resample2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo):
         x = x.contiguous()
-        H, W = x.shape[-2:]
-        ctx.sizes = (H, W, Ho, Wo)
-        (fh, th), _ = _tables(H, Ho, str(x.device))
-        (fw, _), _ = _tables(W, Wo, str(x.device))
-        return _native.resample2d(x, Ho, Wo, fh, fw, th)
+        ctx.in_hw = tuple(x.shape[-2:])
+        return resample_forward(x, Ho, Wo)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        H, W, Ho, Wo = ctx.sizes
-        _, (bh, th) = _tables(H, Ho, str(gy.device))
-        _, (bw, _) = _tables(W, Wo, str(gy.device))
-        return _native.resample2d(gy.contiguous(), H, W, bh, bw, th), None, None
+        return resample_adjoint(gy.contiguous(), *ctx.in_hw), None, None
 
 
 def resample2d_bicubic_aa(x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
