@@ -41,36 +41,42 @@ struct ChannelMixParams {
     const float* bias;      // (Co) or nullptr
     float* y;               // (B, Co, P)
     int B, Ci, Co, P;
-    long long w_so, w_si;
+    int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
     int accumulate;         // y += instead of y =
 };
 
-// One short-lived workgroup per (pixel tile, channel tile, batch entry).  Measured alternatives that lost:
-// persistent workgroups with the chunk pipeline running across tiles (2x slower: with 4 resident workgroups per
-// CU nothing hides the per-chunk load -> LDS -> barrier chain, the hardware dispatcher does that better), and
-// 32-channel chunks with 16-byte loads and an LDS-transposed 512-byte-row epilogue (10-18 % slower).
-template <bool VEC>
-__global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
-    __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * CM_XS];
-    __shared__ float sW[2][CM_KC * CM_WS];
+// MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
+//         32-bit offsets from a uniform base - the per-element clamps and selects of the guarded path cost more
+//         VALU issue slots than the tile has MFMAs;  MODE 1: guarded 16-byte loads (P >= 4);  MODE 0: guarded scalars.
+template <int MODE>
+__device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, float (*sX)[CM_KC * CM_XS], float (*sW)[CM_KC * CM_WS],
+                                                 int p0, int o0, int b) {
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
-    // the k-th contiguous eighth of the tile list.  Neighbouring pixel tiles share the 128-byte lines at their
-    // boundary in every row (rows are only 4-byte aligned); on the same XCD they meet in one L2.
-    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
-    if (tile >= p.ntile) return;
-    const int p0 = (tile / p.ncot) * CM_PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
     const float* xb = p.x + (size_t)b * p.Ci * p.P;
 
-    // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (VEC: row e / 32, px 4 (e % 32)) or
+    // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
     //               8 single elements (row e / 128, px e % 128);  W chunk = 16 k x 64 o -> 4 elements (k e % 16, o e / 16)
     float4 rx[2];
     float rw[4];
     auto load_chunk = [&](int k0) {
-        if constexpr (VEC) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + 256 * u;
+                const f4u v = *reinterpret_cast<const f4u*>(xb + (unsigned)((k0 + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+                rx[u] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + 256 * u;
+                rw[u] = p.w[(unsigned)((o0 + (e >> 4)) * p.w_so + (k0 + (e & 15)) * p.w_si)];
+            }
+            return;
+        }
+        if constexpr (MODE == 1) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + 256 * u;
@@ -79,7 +85,8 @@ __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
                 if (ci >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 rx[u] = v;
             }
-        } else {
+        }
+        if constexpr (MODE == 0) {
             float* r = reinterpret_cast<float*>(rx);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
         }
     };
     auto store_chunk = [&](int buf) {
-        if constexpr (VEC) {
+        if constexpr (MODE != 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + 256 * u;
@@ -144,13 +151,13 @@ __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
 
     // D[px = 16 mt + 4 kk + r][o = 16 wave + r16]
     const int o = o0 + 16 * wave + r16;
-    if (o < p.Co) {
+    if (MODE == 2 || o < p.Co) {
         const float bv = p.bias ? p.bias[o] : 0.f;
         float* yrow = p.y + ((size_t)b * p.Co + o) * p.P;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk;
-            if (px + 3 < p.P) {
+            if (MODE == 2 || px + 3 < p.P) {
                 f4u w4;
                 if (p.accumulate) w4 = *reinterpret_cast<const f4u*>(yrow + px);
                 else w4.v[0] = w4.v[1] = w4.v[2] = w4.v[3] = 0.f;
@@ -166,6 +173,24 @@ __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
     }
 }
 
+// One short-lived workgroup per (pixel tile, channel tile, batch entry).  Measured alternatives that lost:
+// persistent workgroups with the chunk pipeline running across tiles (2x slower), 32-channel chunks, an
+// LDS-transposed epilogue writing whole 512-byte rows (same time), and X straight from global memory in MFMA
+// operand layout with only W in LDS (waves independent between barriers; 10-20 % slower).
+__global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
+    __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * CM_XS];
+    __shared__ float sW[2][CM_KC * CM_WS];
+    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
+    // the k-th contiguous eighth of the tile list.  Neighbouring pixel tiles share the 128-byte lines at their
+    // boundary in every row (rows are only 4-byte aligned); on the same XCD they meet in one L2.
+    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntile) return;
+    const int p0 = (tile / p.ncot) * CM_PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
+    if (p0 + CM_PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2>(p, sX, sW, p0, o0, b);
+    else if (p.P >= 4) channel_mix_tile<1>(p, sX, sW, p0, o0, b);
+    else channel_mix_tile<0>(p, sX, sW, p0, o0, b);
+}
+
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, hipStream_t s) {
     ChannelMixParams p;
@@ -175,12 +200,14 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     p.w_so = transpose_w ? 1 : Ci;
     p.w_si = transpose_w ? Co : 1;
     const long long npt = (P + CM_PT - 1) / CM_PT, ncot = (Co + CM_MT - 1) / CM_MT;
-    if (P > 0x7fffffffLL || npt * ncot > 0x7fffffffLL || B > 65535) { set_error("channel_mix: tensor too large"); return -2; }
+    if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
+        set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
+        return -2;
+    }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
         ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
-        if (P >= 4) hipLaunchKernelGGL(channel_mix_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(channel_mix_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(channel_mix_kernel, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_mix launch: %s", hipGetErrorString(e)); return -5; }
