@@ -130,6 +130,13 @@ long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P);
 int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co,
                       long long P, void* stream);
 
+/* One Adam update of one parameter tensor with the reference optimiser's semantics (Adam.py:27-52): coupled L2
+ * weight decay (g += wd p) and, for complex tensors, the second moment from g conj(g) (one real entry per complex
+ * entry).  p, g, m: float views (interleaved re/im when is_complex), v: n floats; n = entries (complex entries when
+ * is_complex); step = 1-based step count for the bias corrections.  Updates p, m, v in place. */
+int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step, void* stream);
+
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.
  *   uno_profile_begin(max_records): start recording (drops records beyond max_records).

@@ -101,13 +101,15 @@ def _free_port():
     return port
 
 
-def _dp_worker(rank, world, port, out_path):
+def _dp_worker(rank, world, port, out_path, bucket_mb):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
         model = UNO_9(3, 4, pad=5, block_cls=so.OracleOperatorBlock2d)
-        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3, bucket_mb=bucket_mb)
+        if rank == 0:
+            torch.save(len(tr.grads.buckets), out_path + ".nbuckets")
         a, u = synthetic_darcy_batch(4, 72, seed=7, device="cpu")      # global batch, identical on all ranks
         sl = slice(rank * 2, rank * 2 + 2)
         for _ in range(2):
@@ -119,12 +121,16 @@ def _dp_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_data_parallel_equals_single_process_global_batch(tmp_path):
+@pytest.mark.parametrize("bucket_mb", [32.0, 0.002])
+def test_data_parallel_equals_single_process_global_batch(tmp_path, bucket_mb):
     """world_size=2 gloo: two ranks on half batches == one process on the concatenated batch
-    (gradients are SUMMED across ranks because the reference loss is a sum over samples)."""
+    (gradients are SUMMED across ranks because the reference loss is a sum over samples) - with one
+    bucket and with many small buckets all-reduced while the backward pass runs."""
     out_path = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, _free_port(), out_path, bucket_mb), nprocs=2, join=True)
     dp = torch.load(out_path)
+    nb = torch.load(out_path + ".nbuckets")
+    assert (nb == 1) if bucket_mb > 1 else (nb > 4)
 
     torch.manual_seed(100)                            # rank 0's init is what gets broadcast
     model = UNO_9(3, 4, pad=5, block_cls=so.OracleOperatorBlock2d)
@@ -135,3 +141,48 @@ def test_data_parallel_equals_single_process_global_batch(tmp_path):
     for k, v in model.state_dict().items():
         assert rel_err(torch.view_as_real(dp[k]).numpy() if v.is_complex() else dp[k].numpy(),
                        torch.view_as_real(v).numpy() if v.is_complex() else v.numpy()) < 2e-4, k
+
+
+def _unused_param_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from uno_amd.harness.train import FlatGradients
+        torch.manual_seed(rank)
+        used = torch.nn.Linear(5, 3)
+        unused = torch.nn.Linear(7, 2)                    # takes no part in the backward: its bucket never completes by hooks
+        tail = torch.nn.Linear(3, 1)
+        params = list(used.parameters()) + list(unused.parameters()) + list(tail.parameters())
+        fg = FlatGradients(params, bucket_mb=1e-5)        # one bucket per parameter
+        assert len(fg.buckets) >= 4
+        x = torch.full((4, 5), float(rank + 1))
+        for _ in range(2):                                # hooks must re-arm every step
+            fg.zero_()
+            loss = tail(used(x)).sum()
+            fg.arm()
+            loss.backward()
+            fg.finish()
+        if rank == 0:
+            torch.save(fg.flat.clone(), out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_with_unused_parameters(tmp_path):
+    out_path = str(tmp_path / "flat.pt")
+    mp.spawn(_unused_param_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    flat = torch.load(out_path)
+    # both ranks: same weights? no - seeds differ, so compute the expected sum directly
+    exp = 0
+    for rank in range(2):
+        torch.manual_seed(rank)
+        used = torch.nn.Linear(5, 3)
+        unused = torch.nn.Linear(7, 2)
+        tail = torch.nn.Linear(3, 1)
+        x = torch.full((4, 5), float(rank + 1))
+        tail(used(x)).sum().backward()
+        g = [p.grad if p.grad is not None else torch.zeros_like(p)
+             for p in list(used.parameters()) + list(unused.parameters()) + list(tail.parameters())]
+        exp = exp + torch.cat([t.reshape(-1) for t in g])
+    assert torch.allclose(flat, exp, rtol=1e-6, atol=1e-7)

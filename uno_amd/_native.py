@@ -41,6 +41,7 @@ _SIGNATURES = {
     "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _fp]),
+    "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -322,6 +323,21 @@ def channel_wgrad(gy, x, need_bias: bool = True):
                                  B, Ci, Co, P, _stream(x))
     _check(rc, "uno_channel_wgrad")
     return gw, gb
+
+
+def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
+    """In-place Adam update of one parameter tensor p (float32 or complex64) with gradient g, first moment m (real
+    view shape) and second moment v (p.shape, real)."""
+    cplx = p.is_complex()
+    pr, gr = (torch.view_as_real(p), torch.view_as_real(g)) if cplx else (p, g)
+    for t, name in ((pr, "param"), (gr, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+        _require(t, torch.float32, name)
+    if gr.numel() != pr.numel() or m.numel() != pr.numel() or v.numel() != p.numel():
+        raise RuntimeError("uno_amd: Adam state shapes do not match the parameter")
+    with torch.cuda.device(p.device):
+        rc = lib().uno_adam_step(_ptr(pr), _ptr(gr), _ptr(m), _ptr(v), p.numel(), 1 if cplx else 0, lr, beta1, beta2, eps,
+                                 weight_decay, int(step), _stream(pr))
+    _check(rc, "uno_adam_step")
 
 
 def profile_begin(max_records: int = 100000):

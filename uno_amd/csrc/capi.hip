@@ -275,6 +275,17 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
     return launch_channel_wgrad(gy, x, gw, gb, (float*)ws, B, Ci, Co, P, (hipStream_t)stream);
 }
 
+int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, void* stream) {
+    if (n < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) {
+        set_error("uno_adam_step: bad arguments n=%lld step=%d betas=(%g, %g)", n, step, beta1, beta2);
+        return -1;
+    }
+    if (n == 0) return 0;
+    if (!p || !g || !m || !v) { set_error("uno_adam_step: null pointer"); return -1; }
+    return launch_adam(p, g, m, v, n, is_complex, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
                   int mask_overlap, void* stream) {
     if (n_img < 0 || H < 1 || m1 < 1 || m1 > H || m2 < 1 || m3 < 1) {

@@ -113,6 +113,8 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
                       const float* tile_w, int NP, int accumulate, hipStream_t s);
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
+                double eps, double wd, int step, hipStream_t s);
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          hipStream_t s);

@@ -2,7 +2,8 @@
 torch.optim.Adam on complex parameters: the second moment is built from g * conj(g) (the squared
 complex modulus, one real number per complex entry), weight decay is the coupled L2 form
 (g += wd * p).  Implemented with multi-tensor (_foreach) ops over real views so a step is a handful
-of launches instead of a Python loop of complex sqrt/addcdiv per parameter."""
+of launches instead of a Python loop of complex sqrt/addcdiv per parameter.  Parameters on a HIP device are
+updated by the one-pass K10 kernel (csrc/adam.hip), one launch per tensor."""
 from __future__ import annotations
 
 import math
@@ -42,6 +43,10 @@ class ComplexAdam(Optimizer):
                     # one real second-moment entry per (possibly complex) parameter entry
                     st["exp_avg_sq"] = torch.zeros(p.shape, dtype=st["exp_avg"].dtype, device=p.device)
                 st["step"] += 1
+                if p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous() and p.grad.is_contiguous():
+                    from .. import _native
+                    _native.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, beta1, beta2, eps, wd)
+                    continue
                 steps.add(st["step"])
                 ps.append(self._real(p))
                 gs.append(self._real(p.grad))

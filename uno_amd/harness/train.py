@@ -28,13 +28,21 @@ def synthetic_darcy_batch(batch, S, seed, device, dtype=torch.float32):
 
 
 class FlatGradients:
-    """Backs every parameter's .grad with a view into one flat float32 buffer."""
+    """Backs every parameter's .grad with a view into one flat float32 buffer, and sums that buffer across the
+    data-parallel group in a few large buckets while the backward pass is still running.
 
-    def __init__(self, params):
+    Buckets are contiguous slices of the flat buffer (~`bucket_mb` each), numbered in the order the backward pass
+    completes them (last-registered parameters first).  A post-accumulate hook on every parameter counts its
+    bucket down; a complete bucket is all-reduced asynchronously (RCCL runs it on its own stream, overlapping the
+    rest of the backward), always in bucket order so that every rank issues the same sequence of collectives.
+    finish() issues whatever is left (parameters that took no part in this backward) and waits."""
+
+    def __init__(self, params, bucket_mb: float = 32.0):
         self.params = [p for p in params if p.requires_grad]
         sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
         dev = self.params[0].device
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        offsets = []
         off = 0
         for p, n in zip(self.params, sizes):
             seg = self.flat[off:off + n]
@@ -43,12 +51,82 @@ class FlatGradients:
             else:
                 assert p.dtype == torch.float32
                 p.grad = seg.view(p.shape)
+            offsets.append(off)
             off += n
+        # buckets: walk the parameters backwards, close a bucket once it holds bucket_mb
+        limit = int(bucket_mb * (1 << 20) / 4)
+        self.buckets = []               # (start, end) element ranges, in issue order
+        self._bucket_of = {}
+        end = off
+        count = 0
+        members = []
+        for i in range(len(self.params) - 1, -1, -1):
+            members.append(i)
+            count += sizes[i]
+            if count >= limit or i == 0:
+                for j in members:
+                    self._bucket_of[j] = len(self.buckets)
+                self.buckets.append((offsets[i], end))
+                end = offsets[i]
+                count = 0
+                members = []
+        self._bucket_params = [sum(1 for b in self._bucket_of.values() if b == k) for k in range(len(self.buckets))]
+        self._pending = list(self._bucket_params)
+        self._next = 0                  # next bucket to issue
+        self._works = []
+        self._group = None
+        self._armed = False
+        self._hooks = []
 
     def zero_(self):
         self.flat.zero_()
 
+    # ------------------------------------------------------------------ overlapped all-reduce
+    def arm(self, group=None, force=False):
+        """Call before backward(): enables the bucket hooks for this backward if the group has more than one rank."""
+        self._armed = bool(dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1))
+        if not self._armed:
+            return
+        self._group = group
+        self._pending = list(self._bucket_params)
+        self._next = 0
+        self._works = []
+        if not self._hooks:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        k = self._bucket_of[i]
+
+        def hook(_param):
+            if self._armed:
+                self._pending[k] -= 1
+                self._issue_ready()
+        return hook
+
+    def _issue(self, k):
+        a, b = self.buckets[k]
+        self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+
+    def _issue_ready(self):
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            self._issue(self._next)
+            self._next += 1
+
+    def finish(self):
+        """Call after backward(): issues the buckets that are still open and waits for all of them."""
+        if not self._armed:
+            return
+        while self._next < len(self.buckets):
+            self._issue(self._next)
+            self._next += 1
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._armed = False
+
     def all_reduce_sum(self, group=None, force=False):
+        """One blocking SUM over the whole buffer (no overlap)."""
         if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
@@ -78,11 +156,11 @@ class DarcyTrainer:
     backward, gradient all-reduce and the optimiser update; it returns the (device) loss tensor and
     never synchronises with the host."""
 
-    def __init__(self, model, lr=1e-3, weight_decay=1e-3, group=None, force_collectives=False):
+    def __init__(self, model, lr=1e-3, weight_decay=1e-3, group=None, force_collectives=False, bucket_mb=32.0):
         self.model = model
         self.group = group
         self.force_collectives = force_collectives      # tests: run the collectives even in a 1-rank group
-        self.grads = FlatGradients(model.parameters())
+        self.grads = FlatGradients(model.parameters(), bucket_mb=bucket_mb)
         self.opt = ComplexAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.broadcast_parameters()
 
@@ -92,11 +170,12 @@ class DarcyTrainer:
                 dist.broadcast(torch.view_as_real(t.data) if t.is_complex() else t.data, src=0, group=self.group)
 
     def step_with(self, loss_closure):
-        """zero grads -> loss_closure() -> backward -> gradient all-reduce -> optimiser update."""
+        """zero grads -> loss_closure() -> backward with bucketed gradient all-reduce overlapped -> optimiser update."""
         self.grads.zero_()
         loss = loss_closure()
+        self.grads.arm(self.group, self.force_collectives)
         loss.backward()
-        self.grads.all_reduce_sum(self.group, self.force_collectives)
+        self.grads.finish()
         self.opt.step()
         return loss.detach()
 
