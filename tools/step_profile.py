@@ -5,8 +5,8 @@ db = sorted(glob.glob(sys.argv[1] + '/*/*.db'))[-1]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5       # warmup + steps
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end from kernels order by start"))
-idx = [i for i, r in enumerate(rows) if 'multi_tensor_apply_kernel' in r[0]]
-# the optimiser's first multi-tensor launch delimits steps: count launches per step
+idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+# the optimiser's first launch delimits steps: count launches per step
 per = len(idx) // (nsteps) if nsteps else 1
 marks = idx[::per][:nsteps + 1]
 t0, t1 = rows[marks[-2]][1], rows[marks[-1]][1]
