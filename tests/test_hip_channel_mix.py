@@ -121,3 +121,19 @@ def test_accumulate():
     assert rel(gout, gbase.double() + torch.matmul(w.double().t(), gy.double())) < 2e-6
     with pytest.raises(RuntimeError):
         _native.channel_mix(x, w, b, out=torch.zeros(3, 11, 1000, device="cuda"))
+
+
+def test_channel_mix_cat_equals_mix_of_cat():
+    from uno_amd.integral_operators import channel_mix, channel_mix_cat
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(24 + 40, 36).cuda()
+    a = torch.randn(3, 24, 19, 23, device="cuda", requires_grad=True)
+    b = torch.randn(3, 40, 19, 23, device="cuda", requires_grad=True)
+    y = channel_mix_cat([a, b], lin.weight, lin.bias)
+    gy = torch.randn_like(y)
+    got = torch.autograd.grad(y, (a, b, lin.weight, lin.bias), gy)
+    y2 = channel_mix(torch.cat([a, b], dim=1), lin.weight, lin.bias)
+    ref = torch.autograd.grad(y2, (a, b, lin.weight, lin.bias), gy)
+    assert rel(y, y2.double()) < 2e-6
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and rel(g, r.double()) < 2e-5

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import OperatorBlock_2D, OperatorBlock_3D, channel_mix
+from ..integral_operators import OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat
 
 
 class UNO_9(nn.Module):
@@ -64,8 +64,9 @@ class UNO_9(nn.Module):
         c1 = self.conv1(c0, d1 // 4, d2 // 4)
         c2 = self.conv2(c1, d1 // 4, d2 // 4)
         c4 = torch.cat([self.conv4(c2, d1 // 2, d2 // 2), c0], dim=1)
-        c5 = torch.cat([self.conv5(c4, d1, d2), lifted], dim=1)
-        out = channel_mix(F.gelu(channel_mix(c5, self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
+        # fc1 on cat([conv5 output, lifted]) without building the concatenation
+        c5 = channel_mix_cat([self.conv5(c4, d1, d2), lifted], self.fc1.weight, self.fc1.bias)
+        out = channel_mix(F.gelu(c5), self.fc2.weight, self.fc2.bias)
         return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)
 
 

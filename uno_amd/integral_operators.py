@@ -116,6 +116,49 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     return y.view(B, w.shape[0], *x.shape[2:])
 
 
+class _ChannelMixCatFn(torch.autograd.Function):
+    """y[b] = W . cat(x1[b], x2[b]) + bias without the concatenation: W[:, :C1] . x1 writes y, W[:, C1:] . x2
+    accumulates into it; the input gradients come out as two contiguous tensors (no strided slices of a joint one)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias):
+        x1, x2 = _plain(x1), _plain(x2)
+        C1 = x1.shape[1]
+        w1, w2 = w[:, :C1].contiguous(), w[:, C1:].contiguous()
+        y = _native.channel_mix(x1, w1, None if bias is None else _plain(bias))
+        _native.channel_mix(x2, w2, None, out=y)
+        ctx.save_for_backward(x1, x2, w1, w2)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x1, x2, w1, w2 = ctx.saved_tensors
+        gy = _plain(gy)
+        g1 = _native.channel_mix(gy, w1, None, transpose_w=True) if ctx.needs_input_grad[0] else None
+        g2 = _native.channel_mix(gy, w2, None, transpose_w=True) if ctx.needs_input_grad[1] else None
+        gw = gb = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw1, gb = _native.channel_wgrad(gy, x1, need_bias=ctx.has_bias)
+            gw2, _ = _native.channel_wgrad(gy, x2, need_bias=False)
+            gw = torch.cat([gw1, gw2], dim=1)
+        return g1, g2, gw, gb
+
+
+def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """channel_mix(torch.cat(xs, dim=1), weight, bias) - the projection after a skip connection (reference
+    darcy_flow_uno2d.py:122-127: `torch.cat([x_c5, x_fc0], dim=1)` then `fc1`) - without materialising the
+    concatenation when there are two float32 device tensors."""
+    if len(xs) == 2 and all(x.is_cuda and x.dtype == torch.float32 for x in xs) and weight.dtype == torch.float32:
+        x1, x2 = xs
+        B = x1.shape[0]
+        w = weight.reshape(weight.shape[0], -1)
+        y = _ChannelMixCatFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias)
+        return y.view(B, w.shape[0], *x1.shape[2:])
+    return channel_mix(torch.cat(list(xs), dim=1), weight, bias)
+
+
 class _OperatorBlock2dFn(torch.autograd.Function):
     """s = SpectralConv2d_Uno(x) + pointwise_op_2D(x) in ONE buffer (reference integral_operators.py:270-273:
     `x1_out = self.conv(x, ...); x2_out = self.w(x, ...); x_out = x1_out + x2_out`).
