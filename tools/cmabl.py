@@ -1,7 +1,7 @@
 import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) == 1:
-    for fl in (0,):
+    for fl in (0, 32):
         env = dict(os.environ, UNO_CM_FLAGS=str(fl))
         subprocess.run([sys.executable, __file__, str(fl)], env=env)
     sys.exit(0)

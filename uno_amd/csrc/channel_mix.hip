@@ -18,7 +18,6 @@ namespace uno {
 constexpr int CM_PT = 128;          // pixels per workgroup
 constexpr int CM_MT = 64;           // output channels per workgroup (4 waves x 16)
 constexpr int CM_KC = 16;           // input channels per staged chunk
-constexpr int CM_XS = CM_PT + 16;   // LDS row stride of the X chunk  [KC][PT]: 4 consecutive rows hit disjoint bank groups
 constexpr int CM_WS = CM_MT + 16;   // LDS row stride of the W chunk  [KC][MT] (k-major)
 
 // four consecutive floats starting at row[px] with zeros past the row end (row has P >= 4 valid floats):
@@ -50,38 +49,46 @@ struct ChannelMixParams {
 // MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
 //         32-bit offsets from a uniform base - the per-element clamps and selects of the guarded path cost more
 //         VALU issue slots than the tile has MFMAs;  MODE 1: guarded 16-byte loads (P >= 4);  MODE 0: guarded scalars.
-template <int MODE>
-__device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, float (*sX)[CM_KC * CM_XS], float (*sW)[CM_KC * CM_WS],
+template <int MODE, int PT>
+__device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, float (*sX)[CM_KC * (PT + 16)], float (*sW)[CM_KC * CM_WS],
                                                  int p0, int o0, int b) {
+    constexpr int XS = PT + 16;         // LDS row stride of the X chunk [KC][PT]: 4 consecutive rows hit disjoint bank groups
+    constexpr int F4R = PT / 4;         // 16-byte pieces per row
+    constexpr int NV = PT / 64;         // 16-byte pieces per thread per chunk
+    constexpr int NM = PT / 16;         // pixel tiles of 16 = accumulators per wave
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* xb = p.x + (size_t)b * p.Ci * p.P;
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
     //               8 single elements (row e / 128, px e % 128);  W chunk = 16 k x 64 o -> 4 elements (k e % 16, o e / 16)
-    float4 rx[2];
+    float4 rx[2];      // NV used in the vector modes, all 8 floats in MODE 0
     float rw[4];
+    const bool tr = p.w_so == 1 && p.w_si != 1;        // W contiguous along the output channel (input-gradient call)
     auto load_chunk = [&](int k0) {
         if constexpr (MODE == 2) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                const f4u v = *reinterpret_cast<const f4u*>(xb + (unsigned)((k0 + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+                const f4u v = *reinterpret_cast<const f4u*>(xb + (unsigned)((k0 + (e / F4R)) * p.P + p0 + (e % F4R) * 4));
                 rx[u] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
             }
+            // W chunk as ONE 16-byte load per thread along whichever index is contiguous in memory (4 dword loads
+            // per thread made W the most numerous vector-memory instruction of the tile; the address unit was the
+            // busiest block of the CU)
+            const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + (tid & 15) * 4)
+                                     : (unsigned)((o0 + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
+            const f4u wv = *reinterpret_cast<const f4u*>(p.w + woff);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = tid + 256 * u;
-                rw[u] = p.w[(unsigned)((o0 + (e >> 4)) * p.w_so + (k0 + (e & 15)) * p.w_si)];
-            }
+            for (int j = 0; j < 4; ++j) rw[j] = wv.v[j];
             return;
         }
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                const int ci = k0 + (e >> 5);
-                float4 v = load4_tail(xb + (size_t)min(ci, p.Ci - 1) * p.P, p0 + (e & 31) * 4, p.P);
+                const int ci = k0 + (e / F4R);
+                float4 v = load4_tail(xb + (size_t)min(ci, p.Ci - 1) * p.P, p0 + (e % F4R) * 4, p.P);
                 if (ci >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 rx[u] = v;
             }
@@ -89,9 +96,9 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         if constexpr (MODE == 0) {
             float* r = reinterpret_cast<float*>(rx);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
-                const int ci = k0 + (e >> 7), pp = p0 + (e & 127);
+                const int ci = k0 + e / PT, pp = p0 + e % PT;
                 r[u] = (ci < p.Ci && pp < p.P) ? xb[(size_t)ci * p.P + pp] : 0.f;
             }
         }
@@ -106,17 +113,24 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     auto store_chunk = [&](int buf) {
         if constexpr (MODE != 0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                *reinterpret_cast<float4*>(&sX[buf][(e >> 5) * CM_XS + (e & 31) * 4]) = rx[u];
+                *reinterpret_cast<float4*>(&sX[buf][(e / F4R) * XS + (e % F4R) * 4]) = rx[u];
             }
         } else {
             const float* r = reinterpret_cast<const float*>(rx);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
-                sX[buf][(e >> 7) * CM_XS + (e & 127)] = r[u];
+                sX[buf][(e / PT) * XS + e % PT] = r[u];
             }
+        }
+        if constexpr (MODE == 2) {
+            float* d = sW[buf] + (tr ? (tid >> 4) * CM_WS + (tid & 15) * 4 : (tid & 3) * 4 * CM_WS + (tid >> 2));
+            const int st = tr ? 1 : CM_WS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j * st] = rw[j];
+            return;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -125,9 +139,9 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         }
     };
 
-    f32x4 acc[8];
+    f32x4 acc[NM];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+    for (int nt = 0; nt < NM; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
 
     const int nchunk = (p.Ci + CM_KC - 1) / CM_KC;
     load_chunk(0);
@@ -141,21 +155,53 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             // D^T = X^T W^T: A[i = px][k] = X[k][16 mt + r16], B[k][j = o] = Wm(16 wave + r16, k): a lane ends up with
             // 4 consecutive pixels of one output channel -> one 16-byte store
             const float wv = sW[buf][(4 * ks + kk) * CM_WS + 16 * wave + r16];
-            const float* xrow = sX[buf] + (4 * ks + kk) * CM_XS + r16;
+            const float* xrow = sX[buf] + (4 * ks + kk) * XS + r16;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) acc[mt] = mfma16(xrow[16 * mt], wv, acc[mt]);
+            for (int mt = 0; mt < NM; ++mt) acc[mt] = mfma16(xrow[16 * mt], wv, acc[mt]);
         }
         if (c + 1 < nchunk) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
     // D[px = 16 mt + 4 kk + r][o = 16 wave + r16]
+    if constexpr (MODE == 2 && PT == 128) {
+        // rows of 128 pixels leave as contiguous 512-byte stores - 2 rows per instruction instead of 16 rows x 64 B,
+        // a third of the cache-line requests (measured -7..13 % kernel time once W no longer dominated the address
+        // unit): the wave's 16 x 128 tile goes through LDS in two halves of 8 channels (staging buffers are free now)
+        constexpr int OS = PT + 4;
+        float* sO = &sX[0][0] + wave * (8 * OS);
+        const int c4 = (lane & 31) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((r16 >> 3) == h) {
+#pragma unroll
+                for (int mt = 0; mt < NM; ++mt)
+                    *reinterpret_cast<float4*>(sO + (r16 & 7) * OS + 16 * mt + 4 * kk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = 2 * it + (lane >> 5);
+                const int o = o0 + 16 * wave + 8 * h + row;
+                const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
+                const float bv = p.bias ? p.bias[o] : 0.f;
+                float* dst = p.y + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                f4u w4;
+                if (p.accumulate) w4 = *reinterpret_cast<const f4u*>(dst);
+                else w4.v[0] = w4.v[1] = w4.v[2] = w4.v[3] = 0.f;
+                w4.v[0] += v.x + bv; w4.v[1] += v.y + bv; w4.v[2] += v.z + bv; w4.v[3] += v.w + bv;
+                *reinterpret_cast<f4u*>(dst) = w4;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int o = o0 + 16 * wave + r16;
     if (MODE == 2 || o < p.Co) {
         const float bv = p.bias ? p.bias[o] : 0.f;
         float* yrow = p.y + ((size_t)b * p.Co + o) * p.P;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk;
             if (MODE == 2 || px + 3 < p.P) {
                 f4u w4;
@@ -174,21 +220,24 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 }
 
 // One short-lived workgroup per (pixel tile, channel tile, batch entry).  Measured alternatives that lost:
-// persistent workgroups with the chunk pipeline running across tiles (2x slower), 32-channel chunks, an
-// LDS-transposed epilogue writing whole 512-byte rows (same time), and X straight from global memory in MFMA
-// operand layout with only W in LDS (waves independent between barriers; 10-20 % slower).
+// persistent workgroups with the chunk pipeline running across tiles (2x slower), 32-channel chunks, 64-pixel
+// tiles at 7 waves/SIMD (10 % slower: W is staged twice as often), staggered workgroup starts (no effect), and X
+// straight from global memory in MFMA operand layout with only W in LDS (10-20 % slower).  What did pay: fewer and
+// wider vector-memory instructions covering fewer cache lines each (W as one 16-byte load per thread, whole-row
+// stores) - the address unit (TA) was the busiest block of the CU at 63 %.
+template <int PT>
 __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
-    __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * CM_XS];
+    __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * (PT + 16)];
     __shared__ float sW[2][CM_KC * CM_WS];
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
     // the k-th contiguous eighth of the tile list.  Neighbouring pixel tiles share the 128-byte lines at their
     // boundary in every row (rows are only 4-byte aligned); on the same XCD they meet in one L2.
     const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntile) return;
-    const int p0 = (tile / p.ncot) * CM_PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
-    if (p0 + CM_PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2>(p, sX, sW, p0, o0, b);
-    else if (p.P >= 4) channel_mix_tile<1>(p, sX, sW, p0, o0, b);
-    else channel_mix_tile<0>(p, sX, sW, p0, o0, b);
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
+    if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT>(p, sX, sW, p0, o0, b);
+    else if (p.P >= 4) channel_mix_tile<1, PT>(p, sX, sW, p0, o0, b);
+    else channel_mix_tile<0, PT>(p, sX, sW, p0, o0, b);
 }
 
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
@@ -199,7 +248,8 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
     p.w_so = transpose_w ? 1 : Ci;
     p.w_si = transpose_w ? Co : 1;
-    const long long npt = (P + CM_PT - 1) / CM_PT, ncot = (Co + CM_MT - 1) / CM_MT;
+    constexpr int PT = CM_PT;
+    const long long npt = (P + PT - 1) / PT, ncot = (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
@@ -207,7 +257,7 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
         ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
-        hipLaunchKernelGGL(channel_mix_kernel, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(channel_mix_kernel<CM_PT>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_mix launch: %s", hipGetErrorString(e)); return -5; }
