@@ -256,7 +256,7 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
-        ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
+        ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0)) + 4.0 * Ci * Co, s);
         hipLaunchKernelGGL(channel_mix_kernel<CM_PT>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
     }
     const hipError_t e = hipGetLastError();
@@ -492,7 +492,7 @@ int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, 
     p.span = (long long)cps * pk;
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
     {
-        ProfScope prof("uno::channel_wgrad_kernel", 4.0 * B * (double)P * (Ci + Co), s);
+        ProfScope prof(pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel", 4.0 * B * (double)P * (Ci + Co), s);
         if (pk == CWV_PK)
             hipLaunchKernelGGL(channel_wgrad_vec_kernel, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
         else

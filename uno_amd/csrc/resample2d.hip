@@ -137,7 +137,7 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
     if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
         const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)NP * RS_TR * sizeof(float);
-        ProfScope prof("uno::resample_fused_kernel", 4.0 * n_img * ((double)H * W + (double)Ho * Wo), s);
+        ProfScope prof("uno::resample_fused_kernel", 4.0 * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
         // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
         const int sweeps = (W + 511) / 512;
         const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
