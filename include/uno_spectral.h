@@ -137,6 +137,12 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
 int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, void* stream);
 
+/* The same update for a list of parameter tensors (host arrays of device pointers / sizes / flags): one call per
+ * optimiser step instead of one per tensor. */
+int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                        const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int step, void* stream);
+
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.
  *   uno_profile_begin(max_records): start recording (drops records beyond max_records).

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _fp]),
     "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
+    "uno_adam_step_multi": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
+                                      C.POINTER(_i)] + [C.c_double] * 5 + [_i, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -338,6 +340,39 @@ def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float, eps:
         rc = lib().uno_adam_step(_ptr(pr), _ptr(gr), _ptr(m), _ptr(v), p.numel(), 1 if cplx else 0, lr, beta1, beta2, eps,
                                  weight_decay, int(step), _stream(pr))
     _check(rc, "uno_adam_step")
+
+
+class AdamPlan:
+    """Pointer tables of a fixed set of parameter tensors (params, grads, moments must not be re-allocated): one
+    native call per optimiser step."""
+
+    def __init__(self, params, grads, ms, vs):
+        self.device = params[0].device
+        self.n = len(params)
+        reals = []
+        for p, g, m, v in zip(params, grads, ms, vs):
+            cplx = p.is_complex()
+            pr, gr = (torch.view_as_real(p), torch.view_as_real(g)) if cplx else (p, g)
+            for t, name in ((pr, "param"), (gr, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                _require(t, torch.float32, name)
+            if gr.numel() != pr.numel() or m.numel() != pr.numel() or v.numel() != p.numel():
+                raise RuntimeError("uno_amd: Adam state shapes do not match the parameter")
+            reals.append((pr, gr, m, v, p.numel(), 1 if cplx else 0))
+        self._keep = reals                                   # keeps the views (and their storage) alive
+        arr = _fp * self.n
+        self.p = arr(*[r[0].data_ptr() for r in reals])
+        self.g = arr(*[r[1].data_ptr() for r in reals])
+        self.m = arr(*[r[2].data_ptr() for r in reals])
+        self.v = arr(*[r[3].data_ptr() for r in reals])
+        self.sizes = (C.c_longlong * self.n)(*[r[4] for r in reals])
+        self.cplx = (_i * self.n)(*[r[5] for r in reals])
+        self.key = tuple((r[0].data_ptr(), r[1].data_ptr()) for r in reals)
+
+    def step(self, step: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
+        with torch.cuda.device(self.device):
+            rc = lib().uno_adam_step_multi(self.n, self.p, self.g, self.m, self.v, self.sizes, self.cplx, lr, beta1, beta2, eps,
+                                           weight_decay, int(step), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        _check(rc, "uno_adam_step_multi")
 
 
 def profile_begin(max_records: int = 100000):

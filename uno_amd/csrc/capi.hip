@@ -286,6 +286,20 @@ int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int
     return launch_adam(p, g, m, v, n, is_complex, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
+int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                        const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int step, void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!p || !g || !m || !v || !n || !is_complex))) {
+        set_error("uno_adam_step_multi: bad arguments");
+        return -1;
+    }
+    for (int t = 0; t < n_tensors; ++t) {
+        const int rc = uno_adam_step(p[t], g[t], m[t], v[t], n[t], is_complex[t], lr, beta1, beta2, eps, weight_decay, step, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
                   int mask_overlap, void* stream) {
     if (n_img < 0 || H < 1 || m1 < 1 || m1 > H || m2 < 1 || m3 < 1) {

@@ -17,6 +17,20 @@ class ComplexAdam(Optimizer):
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._plans = {}            # per param group: pointer tables of the device tensors (not part of state_dict)
+
+    def _device_step(self, group, params, step, lr, beta1, beta2, eps, wd):
+        """K10 over all device tensors of the group in one native call; the pointer tables are rebuilt only when a
+        parameter or gradient buffer moved (FlatGradients keeps them fixed)."""
+        from .. import _native
+        gid = next(i for i, g in enumerate(self.param_groups) if g is group)
+        plan = self._plans.get(gid)
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+        if plan is None or plan.key != key:
+            plan = _native.AdamPlan([p.data for p in params], [p.grad for p in params],
+                                    [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params])
+            self._plans[gid] = plan
+        plan.step(step, lr, beta1, beta2, eps, wd)
 
     @staticmethod
     def _real(t):
@@ -33,6 +47,7 @@ class ComplexAdam(Optimizer):
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
             ps, gs, ms, vs, steps = [], [], [], [], set()
             cplx = []
+            dev_p, dev_steps = [], set()
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -44,8 +59,8 @@ class ComplexAdam(Optimizer):
                     st["exp_avg_sq"] = torch.zeros(p.shape, dtype=st["exp_avg"].dtype, device=p.device)
                 st["step"] += 1
                 if p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous() and p.grad.is_contiguous():
-                    from .. import _native
-                    _native.adam_step(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, beta1, beta2, eps, wd)
+                    dev_p.append(p)
+                    dev_steps.add(st["step"])
                     continue
                 steps.add(st["step"])
                 ps.append(self._real(p))
@@ -53,6 +68,9 @@ class ComplexAdam(Optimizer):
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
                 cplx.append(p.is_complex())
+            if dev_p:
+                assert len(dev_steps) == 1, "parameters of one group must be stepped together"
+                self._device_step(group, dev_p, dev_steps.pop(), lr, beta1, beta2, eps, wd)
             if not ps:
                 continue
             assert len(steps) == 1, "parameters of one group must be stepped together"
