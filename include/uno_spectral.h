@@ -130,6 +130,23 @@ long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P);
 int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co,
                       long long P, void* stream);
 
+/* Final projection of the U-NO models fused with the GELU in front of it (reference darcy_flow_uno2d.py:128-131:
+ * `x_fc1 = F.gelu(self.fc1(x)); x_out = self.fc2(x_fc1)` with fc2 = Linear(C, 1)), channels-first:
+ *   out[b][p] = bias[0] + sum_c w[c] * gelu(pre[b][c][p])          pre (B, C, P), out (B, P), exact-erf GELU, bias may be NULL
+ * backward: gpre = gelu'(pre) * w[c] * gout,  gw[c] = sum gout * gelu(pre),  gb[0] = sum gout  (gb may be NULL);
+ * ws: scratch of uno_gelu_project_bwd_ws_bytes() bytes (fixed-order partial sums). */
+int uno_gelu_project_forward(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P,
+                             void* stream);
+long long uno_gelu_project_bwd_ws_bytes(int B, int C, long long P);
+int uno_gelu_project_backward(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb,
+                              void* ws, int B, int C, long long P, void* stream);
+
+/* GELU followed by zero padding at the end of both axes (the lift's last activation + domain padding, reference
+ * darcy_flow_uno2d.py:103-107): backward = 0: out (n_img, Hp, Wp) = pad(gelu(s (n_img, H, W))), gy ignored;
+ * backward = 1: out (n_img, H, W) = gelu'(s) * gy[:, :H, :W] with gy (n_img, Hp, Wp). */
+int uno_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward,
+                 void* stream);
+
 /* One Adam update of one parameter tensor with the reference optimiser's semantics (Adam.py:27-52): coupled L2
  * weight decay (g += wd p) and, for complex tensors, the second moment from g conj(g) (one real entry per complex
  * entry).  p, g, m: float views (interleaved re/im when is_complex), v: n floats; n = entries (complex entries when

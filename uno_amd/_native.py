@@ -41,6 +41,10 @@ _SIGNATURES = {
     "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _fp]),
+    "uno_gelu_project_forward": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
+    "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
+    "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
+    "uno_gelu_pad": (C.c_int, [_fp, _fp, _fp] + [_i] * 6 + [_fp]),
     "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
     "uno_adam_step_multi": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
                                       C.POINTER(_i)] + [C.c_double] * 5 + [_i, _fp]),
@@ -340,6 +344,73 @@ def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float, eps:
         rc = lib().uno_adam_step(_ptr(pr), _ptr(gr), _ptr(m), _ptr(v), p.numel(), 1 if cplx else 0, lr, beta1, beta2, eps,
                                  weight_decay, int(step), _stream(pr))
     _check(rc, "uno_adam_step")
+
+
+def gelu_project_forward(pre, w, bias=None):
+    """pre (B, C, P) f32, w (C,), bias (1,) or None -> out (B, P) = bias + sum_c w[c] gelu(pre[:, c])."""
+    _require(pre, torch.float32, "pre")
+    _require(w, torch.float32, "weight")
+    if bias is not None:
+        _require(bias, torch.float32, "bias")
+    B, Cc, P = pre.shape
+    if w.numel() != Cc:
+        raise RuntimeError(f"uno_amd: weight has {w.numel()} entries for {Cc} channels")
+    out = torch.empty((B, P), dtype=torch.float32, device=pre.device)
+    with torch.cuda.device(pre.device):
+        rc = lib().uno_gelu_project_forward(_ptr(pre), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(out),
+                                            B, Cc, P, _stream(pre))
+    _check(rc, "uno_gelu_project_forward")
+    return out
+
+
+def gelu_project_backward(pre, w, gout, need_bias=True):
+    """-> gpre (B, C, P), gw (C,), gb (1,) or None."""
+    _require(pre, torch.float32, "pre")
+    _require(w, torch.float32, "weight")
+    _require(gout, torch.float32, "grad_output")
+    B, Cc, P = pre.shape
+    if tuple(gout.shape) != (B, P):
+        raise RuntimeError("uno_amd: grad_output shape does not match (batch, pixels)")
+    L = lib()
+    gpre = torch.empty_like(pre)
+    gw = torch.empty((Cc,), dtype=torch.float32, device=pre.device)
+    gb = torch.empty((1,), dtype=torch.float32, device=pre.device) if need_bias else None
+    with torch.cuda.device(pre.device):
+        ws = torch.empty(max(1, L.uno_gelu_project_bwd_ws_bytes(B, Cc, P)), dtype=torch.uint8, device=pre.device)
+        rc = L.uno_gelu_project_backward(_ptr(pre), _ptr(w), _ptr(gout), _ptr(gpre), _ptr(gw),
+                                         _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws), B, Cc, P, _stream(pre))
+    _check(rc, "uno_gelu_project_backward")
+    return gpre, gw, gb
+
+
+def gelu_pad(s, Hp: int, Wp: int):
+    """s (..., H, W) f32 -> (..., Hp, Wp) = zero-pad(gelu(s)) at the end of both axes."""
+    _require(s, torch.float32, "s")
+    *lead, H, W = s.shape
+    n = 1
+    for d in lead:
+        n *= d
+    out = torch.empty((*lead, Hp, Wp), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        rc = lib().uno_gelu_pad(_ptr(s), C.c_void_p(0), _ptr(out), n, H, W, Hp, Wp, 0, _stream(s))
+    _check(rc, "uno_gelu_pad")
+    return out
+
+
+def gelu_pad_backward(s, gy):
+    """gs (..., H, W) = gelu'(s) * gy[..., :H, :W]."""
+    _require(s, torch.float32, "s")
+    _require(gy, torch.float32, "grad_output")
+    *lead, H, W = s.shape
+    Hp, Wp = gy.shape[-2:]
+    n = 1
+    for d in lead:
+        n *= d
+    out = torch.empty_like(s)
+    with torch.cuda.device(s.device):
+        rc = lib().uno_gelu_pad(_ptr(s), _ptr(gy), _ptr(out), n, H, W, Hp, Wp, 1, _stream(s))
+    _check(rc, "uno_gelu_pad")
+    return out
 
 
 class AdamPlan:

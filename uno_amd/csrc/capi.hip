@@ -300,6 +300,38 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
     return 0;
 }
 
+int uno_gelu_project_forward(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, void* stream) {
+    if (B < 0 || C < 1 || P < 0) { set_error("uno_gelu_project_forward: bad sizes B=%d C=%d P=%lld", B, C, P); return -1; }
+    if (B == 0 || P == 0) return 0;
+    if (!pre || !w || !out) { set_error("uno_gelu_project_forward: null pointer"); return -1; }
+    return launch_gelu_project_fwd(pre, w, bias, out, B, C, P, (hipStream_t)stream);
+}
+
+long long uno_gelu_project_bwd_ws_bytes(int B, int C, long long P) {
+    if (B < 1 || C < 1 || P < 1) return 0;
+    return 4LL * gelu_project_ws_floats(B, C, P);
+}
+
+int uno_gelu_project_backward(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws, int B,
+                              int C, long long P, void* stream) {
+    if (B < 0 || C < 1 || P < 0) { set_error("uno_gelu_project_backward: bad sizes B=%d C=%d P=%lld", B, C, P); return -1; }
+    if (!gw) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
+    if (B == 0 || P == 0) {
+        hipMemsetAsync(gw, 0, sizeof(float) * C, (hipStream_t)stream);
+        if (gb) hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream);
+        return 0;
+    }
+    if (!pre || !w || !gout || !gpre || !ws) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
+    return launch_gelu_project_bwd(pre, w, gout, gpre, gw, gb, (float*)ws, B, C, P, (hipStream_t)stream);
+}
+
+int uno_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, void* stream) {
+    if (n_img < 0 || H < 1 || W < 1 || Hp < H || Wp < W) { set_error("uno_gelu_pad: bad sizes (%d, %d) -> (%d, %d)", H, W, Hp, Wp); return -1; }
+    if (n_img == 0) return 0;
+    if (!s || !out || (backward && !gy)) { set_error("uno_gelu_pad: null pointer"); return -1; }
+    return launch_gelu_pad(s, gy, out, n_img, H, W, Hp, Wp, backward, (hipStream_t)stream);
+}
+
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
                   int mask_overlap, void* stream) {
     if (n_img < 0 || H < 1 || m1 < 1 || m1 > H || m2 < 1 || m3 < 1) {

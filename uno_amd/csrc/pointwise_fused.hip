@@ -1,0 +1,218 @@
+// K11 / K12 - the element-wise ends of the U-NO models fused into single passes (exact-erf GELU, as F.gelu):
+//
+//   K11  gelu_project:  out[b][p] = bias + sum_c w[c] * gelu(pre[b][c][p])        the final projection fc2 (C -> 1) applied to
+//        gelu(fc1(.)) (reference darcy_flow_uno2d.py:128-131, navier_stokes_uno2d.py:222-225, navier_stokes_uno3d.py:
+//        378-381), and its backward  gpre = gelu'(pre) * w[c] * gout,  gw[c] = sum gout * gelu(pre),  gb = sum gout.
+//        Stock ops: GELU (2 passes over the C-channel tensor) + a GEMM with one useful output row; backward 3 + 2 + 2 passes.
+//        Here: forward reads pre once; backward reads pre once and writes gpre once.
+//   K12  gelu_pad:  out[n][h][w] = gelu(s[n][h][w]) for h < H, w < W, else 0       the lift's last GELU followed by the domain
+//        padding F.pad(x, [0, pad, 0, pad]) (darcy_flow_uno2d.py:103-107), and its backward gs = gelu'(s) * gy[n][h][w].
+//
+// Both are pure streaming kernels: 16-byte accesses, rows of consecutive pixels per wave (1 KB per instruction).
+#include "uno_common.h"
+#include <cstdio>
+
+namespace uno {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
+// up to four consecutive floats row[px .. px+3] with zeros from `n` on (n = valid floats in the row, n >= 4)
+__device__ __forceinline__ void load4_guard(const float* row, int px, int n, float v[4]) {
+    if (px + 3 < n) {
+        const f4u t = *reinterpret_cast<const f4u*>(row + px);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = t.v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = px + i < n ? row[px + i] : 0.f;
+    }
+}
+__device__ __forceinline__ void store4_guard(float* row, int px, int n, const float v[4]) {
+    if (px + 3 < n) {
+        f4u t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.v[i] = v[i];
+        *reinterpret_cast<f4u*>(row + px) = t;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (px + i < n) row[px + i] = v[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K11
+constexpr int GP_MAXC = 1024;
+
+__global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int C, int P) {
+    __shared__ float sw[GP_MAXC];
+    for (int c = threadIdx.x; c < C; c += 256) sw[c] = w[c];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (px >= P) return;
+    const float* src = pre + (size_t)b * C * P;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        float v[4];
+        load4_guard(src + (size_t)c * P, px, P, v);
+        const float wc = sw[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(wc, gelu_f(v[i]), acc[i]);
+    }
+    const float bv = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += bv;
+    store4_guard(out + (size_t)b * P, px, P, acc);
+}
+
+// one workgroup = 1024 pixels of one batch entry; partial weight / bias gradients per workgroup: part[blk][C + 1].
+// Per channel every wave reduces its 256 pixels by butterfly and parks the sum in LDS; one barrier at the end, then the
+// four wave sums are added in wave order (fixed order -> bit-reproducible).
+__global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
+                                                               const float* __restrict__ gout, float* __restrict__ gpre,
+                                                               float* __restrict__ part, int C, int P) {
+    __shared__ float sw[GP_MAXC];
+    extern __shared__ float swave[];                    // [4][C + 1]
+    for (int c = threadIdx.x; c < C; c += 256) sw[c] = w[c];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = px < P;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) load4_guard(gout + (size_t)b * P, px, P, g);
+    const float* src = pre + (size_t)b * C * P;
+    float* dst = gpre + (size_t)b * C * P;
+    float* mine = swave + wave * (C + 1);
+    auto wave_sum = [&](float s, int slot) {
+#pragma unroll
+        for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) mine[slot] = s;
+    };
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        if (live) {
+            float v[4], o[4];
+            load4_guard(src + (size_t)c * P, px, P, v);
+            const float wc = sw[c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float cdf = 0.5f * (1.f + erff(v[i] * 0.70710678118654752440f));
+                const float pdf = 0.39894228040143267794f * expf(-0.5f * v[i] * v[i]);
+                o[i] = fmaf(v[i], pdf, cdf) * (wc * g[i]);
+                s = fmaf(g[i], v[i] * cdf, s);              // g is zero past the row end
+            }
+            store4_guard(dst + (size_t)c * P, px, P, o);
+        }
+        wave_sum(s, c);
+    }
+    wave_sum((g[0] + g[1]) + (g[2] + g[3]), C);
+    __syncthreads();
+    float* prow = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (C + 1);
+    for (int e = threadIdx.x; e <= C; e += 256)
+        prow[e] = (swave[e] + swave[(C + 1) + e]) + (swave[2 * (C + 1) + e] + swave[3 * (C + 1) + e]);
+}
+
+__global__ __launch_bounds__(256) void gelu_project_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
+                                                                  float* __restrict__ gb, int C, int nblk) {
+    // one wave per output entry, lanes stride over the workgroup partials, fixed order
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e > C) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * (C + 1) + e];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        if (e < C) gw[e] = s;
+        else if (gb) gb[0] = s;
+    }
+}
+
+int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s) {
+    if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
+    const unsigned nb = (unsigned)((P + 1023) / 1024);
+    {
+        ProfScope prof("uno::gelu_project_fwd_kernel", 4.0 * B * (double)P * (C + 1), s);
+        hipLaunchKernelGGL(gelu_project_fwd_kernel, dim3(nb, B), dim3(256), 0, s, pre, w, bias, out, C, (int)P);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("gelu_project launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+long long gelu_project_ws_floats(int B, int C, long long P) { return (long long)B * ((P + 1023) / 1024) * (C + 1); }
+
+int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
+                            int C, long long P, hipStream_t s) {
+    if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
+    const unsigned nb = (unsigned)((P + 1023) / 1024);
+    {
+        ProfScope prof("uno::gelu_project_bwd_kernel", 4.0 * B * (double)P * (2 * C + 1), s);
+        hipLaunchKernelGGL(gelu_project_bwd_kernel, dim3(nb, B), dim3(256), 4 * (C + 1) * sizeof(float), s, pre, w, gout, gpre, ws, C, (int)P);
+    }
+    hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("gelu_project backward launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K12
+// thread = 4 consecutive columns of one row; rows are flattened so that short rows do not leave lanes idle
+__global__ __launch_bounds__(256) void gelu_pad_fwd_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    const int n = blockIdx.y;
+    const int nq = (Wp + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int h = q / nq;
+    if (h >= Hp) return;
+    const int w0 = (q - h * nq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (h < H && w0 < W) {
+        load4_guard(s + ((size_t)n * H + h) * W, w0, W, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = w0 + i < W ? gelu_f(v[i]) : 0.f;
+    }
+    store4_guard(out + ((size_t)n * Hp + h) * Wp, w0, Wp, v);
+}
+
+__global__ __launch_bounds__(256) void gelu_pad_bwd_kernel(const float* __restrict__ s, const float* __restrict__ gy, float* __restrict__ gs,
+                                                           int H, int W, int Hp, int Wp) {
+    const int n = blockIdx.y;
+    const int nq = (W + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int h = q / nq;
+    if (h >= H) return;
+    const int w0 = (q - h * nq) * 4;
+    float v[4], g[4], o[4];
+    load4_guard(s + ((size_t)n * H + h) * W, w0, W, v);
+    load4_guard(gy + ((size_t)n * Hp + h) * Wp, w0, W, g);          // only the first W columns of the padded row matter
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = dgelu_f(v[i]) * g[i];
+    store4_guard(gs + ((size_t)n * H + h) * W, w0, W, o);
+}
+
+int launch_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, hipStream_t st) {
+    if (n_img > 65535 || (long long)Hp * ((Wp + 3) / 4) > 0x7fffffffLL) { set_error("gelu_pad: at most 65535 images"); return -2; }
+    if (!backward) {
+        ProfScope prof("uno::gelu_pad_fwd_kernel", 4.0 * n_img * ((double)H * W + (double)Hp * Wp), st);
+        const long long quads = (long long)Hp * ((Wp + 3) / 4);
+        hipLaunchKernelGGL(gelu_pad_fwd_kernel, dim3((unsigned)((quads + 255) / 256), n_img), dim3(256), 0, st, s, out, H, W, Hp, Wp);
+    } else {
+        ProfScope prof("uno::gelu_pad_bwd_kernel", 4.0 * n_img * 3.0 * H * W, st);
+        const long long quads = (long long)H * ((W + 3) / 4);
+        hipLaunchKernelGGL(gelu_pad_bwd_kernel, dim3((unsigned)((quads + 255) / 256), n_img), dim3(256), 0, st, s, gy, out, H, W, Hp, Wp);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("gelu_pad launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+}  // namespace uno

@@ -115,6 +115,11 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
                        int transpose_w, int accumulate, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s);
+int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s);
+long long gelu_project_ws_floats(int B, int C, long long P);
+int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
+                            int C, long long P, hipStream_t s);
+int launch_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, hipStream_t st);
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          hipStream_t s);

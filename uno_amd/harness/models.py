@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat
+from ..integral_operators import OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, gelu_pad2d, gelu_project
 
 
 class UNO_9(nn.Module):
@@ -54,10 +54,10 @@ class UNO_9(nn.Module):
     def forward(self, x):
         S1, S2 = x.shape[1], x.shape[2]
         x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()   # (B, 3, S, S): tiny
-        lifted = F.gelu(channel_mix(F.gelu(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias)), self.fc0.weight, self.fc0.bias))
+        lifted = channel_mix(F.gelu(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias)), self.fc0.weight, self.fc0.bias)
         scale = math.ceil(S2 / 85)
         margin = scale * self.padding
-        lifted = F.pad(lifted, [0, margin, 0, margin])
+        lifted = gelu_pad2d(lifted, margin, margin)            # gelu, then pad the end of both axes
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
 
         c0 = self.conv0(lifted, d1 // 2, d2 // 2)
@@ -66,7 +66,7 @@ class UNO_9(nn.Module):
         c4 = torch.cat([self.conv4(c2, d1 // 2, d2 // 2), c0], dim=1)
         # fc1 on cat([conv5 output, lifted]) without building the concatenation
         c5 = channel_mix_cat([self.conv5(c4, d1, d2), lifted], self.fc1.weight, self.fc1.bias)
-        out = channel_mix(F.gelu(c5), self.fc2.weight, self.fc2.bias)
+        out = gelu_project(c5, self.fc2.weight, self.fc2.bias)
         return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)
 
 
@@ -126,7 +126,7 @@ class UNO(nn.Module):
         c6 = torch.cat([self.L6(c5, d1, d2), lifted], dim=1)
         if p != 0:      # the reference pads both sides but crops one (navier_stokes_uno2d.py:201,217-218); kept
             c6 = c6[..., :-p, :-p]
-        out = channel_mix(F.gelu(channel_mix(c6.contiguous(), self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
+        out = gelu_project(channel_mix(c6.contiguous(), self.fc1.weight, self.fc1.bias), self.fc2.weight, self.fc2.bias)
         return out.permute(0, 2, 3, 1).contiguous()
 
 
@@ -185,5 +185,5 @@ class Uno3D_T20(nn.Module):
         c8 = torch.cat([c8, self._resize(lifted, c8)], dim=1)
         if self.padding != 0:
             c8 = c8[..., 2 * self.padding:-2 * self.padding] if self.pad_both else c8[..., :-2 * self.padding]
-        out = channel_mix(F.gelu(channel_mix(c8.contiguous(), self.fc1.weight, self.fc1.bias)), self.fc2.weight, self.fc2.bias)
+        out = gelu_project(channel_mix(c8.contiguous(), self.fc1.weight, self.fc1.bias), self.fc2.weight, self.fc2.bias)
         return out.permute(0, 2, 3, 4, 1).contiguous()

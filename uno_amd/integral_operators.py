@@ -159,6 +159,60 @@ def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None) -> torc
     return channel_mix(torch.cat(list(xs), dim=1), weight, bias)
 
 
+class _GeluProjectFn(torch.autograd.Function):
+    """out[b, p] = bias + sum_c w[c] gelu(pre[b, c, p]) (K11, csrc/pointwise_fused.hip)."""
+
+    @staticmethod
+    def forward(ctx, pre, w, bias):
+        pre, w = _plain(pre), _plain(w)
+        out = _native.gelu_project_forward(pre, w, None if bias is None else _plain(bias))
+        ctx.save_for_backward(pre, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        pre, w = ctx.saved_tensors
+        gpre, gw, gb = _native.gelu_project_backward(pre, w, _plain(gout), need_bias=ctx.has_bias)
+        return gpre, gw, gb
+
+
+def gelu_project(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """channel_mix(F.gelu(pre), weight, bias) for the models' final projection (reference darcy_flow_uno2d.py:128-131:
+    `F.gelu(self.fc1(x))` then `self.fc2`, fc2 = Linear(C, 1)): with ONE output channel on a HIP device the GELU and
+    the projection are a single streaming pass (no GELU output tensor, no one-row GEMM)."""
+    if weight.shape[0] == 1 and pre.is_cuda and pre.dtype == torch.float32 and weight.dtype == torch.float32 and pre.shape[1] <= 1024:
+        B, C = pre.shape[0], pre.shape[1]
+        out = _GeluProjectFn.apply(pre.reshape(B, C, -1), weight.reshape(C), bias)
+        return out.view(B, 1, *pre.shape[2:])
+    return channel_mix(F.gelu(pre), weight, bias)
+
+
+class _GeluPadFn(torch.autograd.Function):
+    """zero-pad(gelu(s)) at the end of the last two axes (K12)."""
+
+    @staticmethod
+    def forward(ctx, s, Hp, Wp):
+        s = _plain(s)
+        ctx.save_for_backward(s)
+        return _native.gelu_pad(s, Hp, Wp)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (s,) = ctx.saved_tensors
+        return _native.gelu_pad_backward(s, _plain(gy)), None, None
+
+
+def gelu_pad2d(s: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
+    """F.pad(F.gelu(s), [0, pad_w, 0, pad_h]) - the lift's last activation and the domain padding (reference
+    darcy_flow_uno2d.py:103-107) in one pass over the tensor on a HIP device."""
+    if s.is_cuda and s.dtype == torch.float32 and s.dim() >= 2 and pad_h >= 0 and pad_w >= 0:
+        return _GeluPadFn.apply(s, s.shape[-2] + int(pad_h), s.shape[-1] + int(pad_w))
+    return F.pad(F.gelu(s), [0, pad_w, 0, pad_h])
+
+
 class _OperatorBlock2dFn(torch.autograd.Function):
     """s = SpectralConv2d_Uno(x) + pointwise_op_2D(x) in ONE buffer (reference integral_operators.py:270-273:
     `x1_out = self.conv(x, ...); x2_out = self.w(x, ...); x_out = x1_out + x2_out`).
