@@ -147,6 +147,17 @@ int uno_gelu_project_backward(const float* pre, const float* w, const float* gou
 int uno_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward,
                  void* stream);
 
+/* InstanceNorm (affine, biased variance, eps, no running statistics) optionally fused with the exact-erf GELU that follows
+ * it in an operator block (reference integral_operators.py:269-270, 277-283; 3-D :497-498, 506-512).  x, y: (rows, N) with
+ * rows = batch * C (channel of row r = r % C) and N = grid points; gamma, beta: (C) or NULL; mean, rstd: (rows) outputs kept
+ * for the backward.  Backward: gx, and the per-row sums s1 = sum g_z, s2 = sum g_z * xhat (g_z = gradient at the affine
+ * output) whose sums over the batch are the gradients of beta and gamma. */
+int uno_instnorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows,
+                         int C, long long N, float eps, int gelu, void* stream);
+int uno_instnorm_backward(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu,
+                          void* stream);
+
 /* One Adam update of one parameter tensor with the reference optimiser's semantics (Adam.py:27-52): coupled L2
  * weight decay (g += wd p) and, for complex tensors, the second moment from g conj(g) (one real entry per complex
  * entry).  p, g, m: float views (interleaved re/im when is_complex), v: n floats; n = entries (complex entries when

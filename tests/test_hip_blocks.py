@@ -127,15 +127,16 @@ def test_fused_block_equals_branch_sum(hw, out_hw, normalize):
     got = torch.autograd.grad(y, [x] + params, gy)
 
     s = blk.conv(x) + blk.w(x)                 # unfused composition of the same kernels
-    if normalize:
-        s = blk.normalize_layer(s)
-    y2 = torch.nn.functional.gelu(s)
+    if normalize:                              # in float64: torch's own InstanceNorm on ROCm (MIOpen) is 3e-4 / 1e-3 off on odd grids
+        nl = blk.normalize_layer
+        s = torch.nn.functional.instance_norm(s.double(), weight=nl.weight.double(), bias=nl.bias.double(), eps=nl.eps)
+    y2 = torch.nn.functional.gelu(s).float()
     ref = torch.autograd.grad(y2, [x] + params, gy)
 
-    def rel(a, b):
-        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
-
-    assert rel(y, y2) < 2e-6
+    assert ((y - y2).abs().max() / y2.abs().max()).item() < 2e-6
+    # gradients: relative to the tensor's own scale, with a floor for tensors whose true gradient is zero (the 1x1
+    # convolution's bias in front of an InstanceNorm: both sides are rounding noise there)
+    gmax = max(float(r.abs().max()) for r in ref)
     for a, b in zip(got, ref):
         assert a.shape == b.shape
-        assert rel(a, b) < 2e-5
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-6 * gmax

@@ -45,6 +45,8 @@ _SIGNATURES = {
     "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
     "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
     "uno_gelu_pad": (C.c_int, [_fp, _fp, _fp] + [_i] * 6 + [_fp]),
+    "uno_instnorm_forward": (C.c_int, [_fp] * 6 + [C.c_longlong, _i, C.c_longlong, C.c_float, _i, _fp]),
+    "uno_instnorm_backward": (C.c_int, [_fp] * 9 + [C.c_longlong, _i, C.c_longlong, _i, _fp]),
     "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
     "uno_adam_step_multi": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
                                       C.POINTER(_i)] + [C.c_double] * 5 + [_i, _fp]),
@@ -411,6 +413,45 @@ def gelu_pad_backward(s, gy):
         rc = lib().uno_gelu_pad(_ptr(s), _ptr(gy), _ptr(out), n, H, W, Hp, Wp, 1, _stream(s))
     _check(rc, "uno_gelu_pad")
     return out
+
+
+def instnorm_forward(x, gamma, beta, eps: float, gelu: bool):
+    """x (B, C, *grid) f32 -> y, mean (B*C), rstd (B*C)."""
+    _require(x, torch.float32, "x")
+    for t, name in ((gamma, "weight"), (beta, "bias")):
+        if t is not None:
+            _require(t, torch.float32, name)
+    B, Cc = x.shape[0], x.shape[1]
+    rows = B * Cc
+    N = x.numel() // max(rows, 1)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    null = C.c_void_p(0)
+    with torch.cuda.device(x.device):
+        rc = lib().uno_instnorm_forward(_ptr(x), _ptr(gamma) if gamma is not None else null, _ptr(beta) if beta is not None else null,
+                                        _ptr(y), _ptr(mean), _ptr(rstd), rows, Cc, N, float(eps), 1 if gelu else 0, _stream(x))
+    _check(rc, "uno_instnorm_forward")
+    return y, mean, rstd
+
+
+def instnorm_backward(x, gy, gamma, beta, mean, rstd, gelu: bool):
+    """-> gx, s1 (B, C), s2 (B, C): sums over the batch of s1 / s2 are the bias / weight gradients."""
+    _require(x, torch.float32, "x")
+    _require(gy, torch.float32, "grad_output")
+    B, Cc = x.shape[0], x.shape[1]
+    rows = B * Cc
+    N = x.numel() // max(rows, 1)
+    gx = torch.empty_like(x)
+    s1 = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    s2 = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    null = C.c_void_p(0)
+    with torch.cuda.device(x.device):
+        rc = lib().uno_instnorm_backward(_ptr(x), _ptr(gy), _ptr(gamma) if gamma is not None else null,
+                                         _ptr(beta) if beta is not None else null, _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(s1), _ptr(s2),
+                                         rows, Cc, N, 1 if gelu else 0, _stream(x))
+    _check(rc, "uno_instnorm_backward")
+    return gx, s1, s2
 
 
 class AdamPlan:

@@ -332,6 +332,22 @@ int uno_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, 
     return launch_gelu_pad(s, gy, out, n_img, H, W, Hp, Wp, backward, (hipStream_t)stream);
 }
 
+int uno_instnorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
+                         long long N, float eps, int gelu, void* stream) {
+    if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_forward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }
+    if (rows == 0) return 0;
+    if (!x || !y || !mean || !rstd) { set_error("uno_instnorm_forward: null pointer"); return -1; }
+    return launch_instnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, N, eps, gelu, (hipStream_t)stream);
+}
+
+int uno_instnorm_backward(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                          float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, void* stream) {
+    if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_backward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }
+    if (rows == 0) return 0;
+    if (!x || !gy || !mean || !rstd || !gx || !s1 || !s2) { set_error("uno_instnorm_backward: null pointer"); return -1; }
+    return launch_instnorm_bwd(x, gy, gamma, beta, mean, rstd, gx, s1, s2, rows, C, N, gelu, (hipStream_t)stream);
+}
+
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
                   int mask_overlap, void* stream) {
     if (n_img < 0 || H < 1 || m1 < 1 || m1 > H || m2 < 1 || m3 < 1) {

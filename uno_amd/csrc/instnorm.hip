@@ -1,0 +1,158 @@
+// K13 - InstanceNorm (affine, biased variance, no running statistics) fused with the GELU that follows it in an
+// operator block (reference integral_operators.py:269-270, 277-283: `normalize_layer = nn.InstanceNorm2d(out, affine=True)`,
+// `x_out = self.normalize_layer(x_out)`, `x_out = F.gelu(x_out)`; 3-D: :497-498, 506-512).
+//
+// One workgroup per (sample, channel) row of N = prod(grid) contiguous floats.  Statistics are two-pass (mean, then
+// sum of squared deviations) like the CPU reference, so results match it to f32 rounding - MIOpen's batch-norm path,
+// which torch uses for InstanceNorm on ROCm, is 3e-4 off at odd sizes.  The row is read from HBM once: the later
+// sweeps of the same workgroup hit L2 (a row is 49-800 KB).
+//   forward : y = [gelu](gamma * (x - mean) * rstd + beta);  saves mean, rstd per row.          HBM: read x, write y
+//   backward: g_z = [gelu'(z)] * gy;  S1 = sum g_z, S2 = sum g_z * xhat  (per row; also the bias / weight gradients)
+//             gx = gamma * rstd * (g_z - S1 / N - xhat * S2 / N).                               HBM: read x, gy, write gx
+#include "uno_common.h"
+#include <cstdio>
+
+namespace uno {
+
+__device__ __forceinline__ float in_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float in_dgelu(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
+constexpr int IN_T = 512;           // threads per row
+
+// fixed-order block sum: butterfly inside a wave, then the 8 wave sums in order
+__device__ __forceinline__ float in_block_sum(float s, float* red) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    __syncthreads();                                    // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < IN_T / 64; ++w) t += red[w];
+    return t;
+}
+
+// visit the row in 16-byte pieces (rows are only 4-byte aligned): f(k, v[4], n_valid)
+template <class F>
+__device__ __forceinline__ void in_sweep(const float* row, int N, F f) {
+    const int nq = N >> 2;
+    for (int q = threadIdx.x; q < nq; q += IN_T) {
+        const f4u t = *reinterpret_cast<const f4u*>(row + 4 * q);
+        f(4 * q, t.v, 4);
+    }
+    const int tail = N & 3;
+    if (tail && threadIdx.x == 0) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < tail; ++i) v[i] = row[4 * nq + i];
+        f(4 * nq, v, tail);
+    }
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(IN_T) void instnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps) {
+    __shared__ float red[IN_T / 64];
+    const int r = blockIdx.x, c = r % C;
+    const float* row = x + (size_t)r * N;
+    float* dst = y + (size_t)r * N;
+    float s = 0.f;
+    in_sweep(row, N, [&](int, const float* v, int n) { for (int i = 0; i < n; ++i) s += v[i]; });
+    const float mean = in_block_sum(s, red) / (float)N;
+    float q = 0.f;
+    in_sweep(row, N, [&](int, const float* v, int n) { for (int i = 0; i < n; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); } });
+    const float var = in_block_sum(q, red) / (float)N;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (threadIdx.x == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float a = g * rstd, sh = b - mean * a;                    // z = a * x + sh
+    in_sweep(row, N, [&](int k, const float* v, int n) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float z = fmaf(a, v[i], sh); o[i] = GELU ? in_gelu(z) : z; }
+        if (n == 4) {
+            f4u t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.v[i] = o[i];
+            *reinterpret_cast<f4u*>(dst + k) = t;
+        } else {
+            for (int i = 0; i < n; ++i) dst[k + i] = o[i];
+        }
+    });
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            float* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N) {
+    __shared__ float red[IN_T / 64];
+    const int r = blockIdx.x, c = r % C;
+    const float* row = x + (size_t)r * N;
+    const float* grow = gy + (size_t)r * N;
+    float* dst = gx + (size_t)r * N;
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    auto gz_of = [&](float xv, float gv, float& xhat) {
+        xhat = (xv - mean) * rstd;
+        return GELU ? in_dgelu(fmaf(g, xhat, b)) * gv : gv;
+    };
+    {
+        const int nq = N >> 2;
+        for (int q = threadIdx.x; q < nq; q += IN_T) {
+            const f4u a = *reinterpret_cast<const f4u*>(row + 4 * q), d = *reinterpret_cast<const f4u*>(grow + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float xh; const float gz = gz_of(a.v[i], d.v[i], xh); s1 += gz; s2 = fmaf(gz, xh, s2); }
+        }
+        if ((N & 3) && threadIdx.x == 0)
+            for (int k = 4 * nq; k < N; ++k) { float xh; const float gz = gz_of(row[k], grow[k], xh); s1 += gz; s2 = fmaf(gz, xh, s2); }
+    }
+    const float S1 = in_block_sum(s1, red), S2 = in_block_sum(s2, red);
+    if (threadIdx.x == 0) { s1_out[r] = S1; s2_out[r] = S2; }
+    const float m1 = S1 / (float)N, m2 = S2 / (float)N, gr = g * rstd;
+    {
+        const int nq = N >> 2;
+        for (int q = threadIdx.x; q < nq; q += IN_T) {
+            const f4u a = *reinterpret_cast<const f4u*>(row + 4 * q), d = *reinterpret_cast<const f4u*>(grow + 4 * q);
+            f4u o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float xh; const float gz = gz_of(a.v[i], d.v[i], xh); o.v[i] = gr * (gz - m1 - xh * m2); }
+            *reinterpret_cast<f4u*>(dst + 4 * q) = o;
+        }
+        if ((N & 3) && threadIdx.x == 0)
+            for (int k = 4 * nq; k < N; ++k) { float xh; const float gz = gz_of(row[k], grow[k], xh); dst[k] = gr * (gz - m1 - xh * m2); }
+    }
+}
+
+int launch_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
+                        long long N, float eps, int gelu, hipStream_t s) {
+    if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
+    {
+        ProfScope prof("uno::instnorm_fwd_kernel", 8.0 * rows * (double)N, s);
+        if (gelu) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gamma, beta, y, mean, rstd, C, (int)N, eps);
+        else hipLaunchKernelGGL(instnorm_fwd_kernel<false>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gamma, beta, y, mean, rstd, C, (int)N, eps);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("instnorm launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+int launch_instnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, hipStream_t s) {
+    if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
+    {
+        ProfScope prof("uno::instnorm_bwd_kernel", 12.0 * rows * (double)N, s);
+        if (gelu) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gy, gamma, beta, mean, rstd, gx, s1, s2, C, (int)N);
+        else hipLaunchKernelGGL(instnorm_bwd_kernel<false>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gy, gamma, beta, mean, rstd, gx, s1, s2, C, (int)N);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("instnorm backward launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+}  // namespace uno

@@ -120,6 +120,10 @@ long long gelu_project_ws_floats(int B, int C, long long P);
 int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
                             int C, long long P, hipStream_t s);
 int launch_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, hipStream_t st);
+int launch_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
+                        long long N, float eps, int gelu, hipStream_t s);
+int launch_instnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, hipStream_t s);
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          hipStream_t s);

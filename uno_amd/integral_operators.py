@@ -213,6 +213,41 @@ def gelu_pad2d(s: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     return F.pad(F.gelu(s), [0, pad_w, 0, pad_h])
 
 
+class _InstanceNormGeluFn(torch.autograd.Function):
+    """[gelu](InstanceNorm(x) * weight + bias) with K13 (csrc/instnorm.hip); saves x and the per-row mean / rstd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, gelu):
+        x = _plain(x)
+        w = None if weight is None else _plain(weight)
+        b = None if bias is None else _plain(bias)
+        y, mean, rstd = _native.instnorm_forward(x, w, b, eps, gelu)
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        ctx.gelu = gelu
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, b, mean, rstd = ctx.saved_tensors
+        gx, s1, s2 = _native.instnorm_backward(x, _plain(gy), w, b, mean, rstd, ctx.gelu)
+        gw = s2.sum(0) if w is not None and ctx.needs_input_grad[1] else None
+        gb = s1.sum(0) if b is not None and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None
+
+
+def instance_norm_gelu(x: torch.Tensor, norm: nn.Module, gelu: bool) -> torch.Tensor:
+    """`norm(x)` followed, if `gelu`, by F.gelu - for an nn.InstanceNorm{2,3}d without running statistics on a float32
+    HIP tensor both run as one kernel; anything else takes the stock modules."""
+    if (x.is_cuda and x.dtype == torch.float32 and isinstance(norm, (nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d))
+            and not norm.track_running_stats and x.dim() >= 3 and x.shape[1] == norm.num_features):
+        if x.numel() // max(x.shape[0] * x.shape[1], 1) <= 1:           # torch.nn.functional.instance_norm refuses this too
+            raise ValueError(f"Expected more than 1 spatial element when training, got input size {x.size()}")
+        return _InstanceNormGeluFn.apply(x, norm.weight, norm.bias, norm.eps, bool(gelu))
+    out = norm(x)
+    return F.gelu(out) if gelu else out
+
+
 class _OperatorBlock2dFn(torch.autograd.Function):
     """s = SpectralConv2d_Uno(x) + pointwise_op_2D(x) in ONE buffer (reference integral_operators.py:270-273:
     `x1_out = self.conv(x, ...); x2_out = self.w(x, ...); x_out = x1_out + x2_out`).
@@ -358,7 +393,7 @@ class OperatorBlock_2D(nn.Module):
     def forward(self, x, dim1=None, dim2=None):
         out = self._branches(x, dim1, dim2)
         if self.normalize:
-            out = self.normalize_layer(out)
+            return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
         if self.non_lin:
             out = F.gelu(out)
         return out
@@ -449,7 +484,7 @@ class OperatorBlock_3D(nn.Module):
     def forward(self, x, dim1=None, dim2=None, dim3=None):
         out = self.conv(x, dim1, dim2, dim3) + self.w(x, dim1, dim2, dim3)
         if self.normalize:
-            out = self.normalize_layer(out)
+            return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
         if self.non_lin:
             out = F.gelu(out)
         return out
