@@ -97,10 +97,9 @@ def test_model_product_vs_oracle_blocks_same_weights():
     lp = lp_loss_rel_sum(prod(a.to(dev())).reshape(2, -1), u.to(dev()).reshape(2, -1))
     lp.backward()
     assert abs(float(lp) - float(lr)) < 1e-4 * abs(float(lr))
-    # Gradient tolerance 2e-2: NOT set by the HIP spectral path (2e-7, test_hip_spectral2d) but by the stock
-    # MIOpen InstanceNorm of the ROCm build, which differs from the CPU op by 3e-4 (fwd) / 1e-3 (bwd) at odd
-    # grid sizes such as 55x55 / 27x27 (measured on MI355X, tools/_diag history in DESIGN.md); two
-    # InstanceNorm layers sit on every gradient path of this model.
+    # Gradient tolerance: 2e-2 while the InstanceNorm layers ran on MIOpen (3e-4 fwd / 1e-3 bwd off the CPU op on odd
+    # grids such as 55x55 / 27x27); with the K13 kernel every operator of the model is within f32 rounding of the
+    # reference and the whole-model gradients agree to <= 3e-6 (measured); asserted at 2e-5.
     pr = dict(ref.named_parameters())
     gmax = max(float(torch.linalg.vector_norm(q.grad)) for q in pr.values())
     for k, p in prod.named_parameters():
@@ -108,7 +107,9 @@ def test_model_product_vs_oracle_blocks_same_weights():
             continue    # in front of an InstanceNorm: true gradient is exactly zero, both sides hold only rounding residue
         g, gr = p.grad.cpu(), pr[k].grad
         n = float(torch.linalg.vector_norm(gr))
-        assert float(torch.linalg.vector_norm(g - gr)) <= 2e-2 * n + 1e-5 * gmax, k
+        err = float(torch.linalg.vector_norm(g - gr))
+        print(f"{k:32s} rel grad err {err / max(n, 1e-30):.2e}")
+        assert err <= 2e-5 * n + 1e-6 * gmax, k
 
 
 @pytest.mark.parametrize("hw,out_hw", [((40, 36), (20, 18)), ((24, 28), (24, 28)), ((20, 18), (41, 37))])
