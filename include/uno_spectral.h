@@ -88,6 +88,14 @@ int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W,
 int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2,
                       float scale, int hermitian_cols, int mask_overlap, void* stream);
 
+/* The same transforms with the spectra of a (B, group) batch of images placed at channels [offset, offset + group) of a
+ * (B, stride, 2*m1, m2) spectrum tensor (image i <-> spectrum (i / group) * stride + offset + i % group): lets an
+ * operator block consume torch.cat([x1, x2], dim=1) (reference darcy_flow_uno2d.py:117-125) from its two sources. */
+int uno_dft2d_forward_grouped(const float* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
+                              int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream);
+int uno_dft2d_inverse_grouped(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale,
+                              int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream);
+
 /* Per-mode channel mixing on the truncated spectrum, `ncorner` weight tensors of
  * `modes_per_corner` modes each (2-D: ncorner = 2, modes_per_corner = m1*m2).
  *   op 0: out[b,o] = sum_i in[b,i] * w[i,o]        (einsum "bixy,ioxy->boxy", :178-179)

@@ -141,3 +141,29 @@ def test_fused_block_equals_branch_sum(hw, out_hw, normalize):
     for a, b in zip(got, ref):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-6 * gmax
+
+
+@pytest.mark.parametrize("hw,out_hw", [((40, 36), (20, 18)), ((24, 28), (24, 28)), ((20, 18), (41, 37))])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_forward_cat_equals_block_of_concatenation(hw, out_hw, normalize):
+    """Two-source block (skip connection consumed without torch.cat) against the same block on the concatenated
+    tensor: output and every gradient, for down-sampling, same-size and up-sampling blocks."""
+    from uno_amd.integral_operators import OperatorBlock_2D
+    torch.manual_seed(5)
+    blk = OperatorBlock_2D(4 + 7, 9, out_hw[0], out_hw[1], 5, 4, Normalize=normalize).cuda()
+    a = torch.randn(3, 4, *hw, device="cuda", requires_grad=True)
+    b = torch.randn(3, 7, *hw, device="cuda", requires_grad=True)
+    params = list(blk.parameters())
+    y = blk.forward_cat([a, b])
+    gy = torch.randn_like(y)
+    got = torch.autograd.grad(y, [a, b] + params, gy)
+    y2 = blk(torch.cat([a, b], dim=1))
+    ref = torch.autograd.grad(y2, [a, b] + params, gy)
+    assert ((y - y2).abs().max() / y2.abs().max()).item() < 2e-6
+    gmax = max(float(r.abs().max()) for r in ref)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape
+        assert float((g - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 2e-6 * gmax
+    # call-time grid override goes through the same path and persists on the spectral layer, as in forward()
+    y3 = blk.forward_cat([a, b], out_hw[0] + 2, out_hw[1] + 1)
+    assert y3.shape[-2:] == (out_hw[0] + 2, out_hw[1] + 1) and (blk.conv.dim1, blk.conv.dim2) == (out_hw[0] + 2, out_hw[1] + 1)

@@ -30,6 +30,8 @@ _SIGNATURES = {
     "uno_spectral_conv2d_backward": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
     "uno_dft2d_forward": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_dft2d_forward_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
+    "uno_dft2d_inverse_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
     "uno_mode_mix": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
     "uno_mode_wgrad": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 5 + [_fp]),
     "uno_spectral_conv3d_fwd_ws_bytes": (C.c_longlong, [_i] * 8),
@@ -147,32 +149,56 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
     return gx, gw1, gw2
 
 
-def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=False):
+def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=False, out=None, channel_offset=0):
+    """images (..., H, W) f32 -> spectra (..., 2*m1, m2) c64.  With `out` (B, Ctot, 2*m1, m2) and images (B, C1, H, W) the
+    spectra go to channels [channel_offset, channel_offset + C1) of `out`."""
     _require(images, torch.float32, "images")
     *lead, H, W = images.shape
     n = 1
     for d in lead:
         n *= d
-    spec = torch.empty((*lead, 2 * m1, m2), dtype=torch.complex64, device=images.device)
+    if out is None:
+        spec = torch.empty((*lead, 2 * m1, m2), dtype=torch.complex64, device=images.device)
+        with torch.cuda.device(images.device):
+            rc = lib().uno_dft2d_forward(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                                         int(mask_overlap), _stream(images))
+        _check(rc, "uno_dft2d_forward")
+        return spec
+    _require(out, torch.complex64, "out")
+    if images.dim() != 4 or out.dim() != 4 or out.shape[0] != images.shape[0] or tuple(out.shape[2:]) != (2 * m1, m2) \
+            or channel_offset < 0 or channel_offset + images.shape[1] > out.shape[1]:
+        raise RuntimeError("uno_amd: out must be (B, Ctot, 2*m1, m2) with room for the image channels at channel_offset")
     with torch.cuda.device(images.device):
-        rc = lib().uno_dft2d_forward(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols),
-                                     int(mask_overlap), _stream(images))
-    _check(rc, "uno_dft2d_forward")
-    return spec
+        rc = lib().uno_dft2d_forward_grouped(_ptr(images), _ptr(out), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                                             int(mask_overlap), images.shape[1], out.shape[1], int(channel_offset), _stream(images))
+    _check(rc, "uno_dft2d_forward_grouped")
+    return out
 
 
-def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True):
+def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True, channels=None, channel_offset=0):
+    """spectra (..., 2*m1, m2) c64 -> images (..., H, W) f32.  With `channels` = C1 and spec (B, Ctot, 2*m1, m2) only the
+    channels [channel_offset, channel_offset + C1) are transformed -> (B, C1, H, W)."""
     _require(spec, torch.complex64, "spec")
     *lead, r2, m2 = spec.shape
     m1 = r2 // 2
-    n = 1
-    for d in lead:
-        n *= d
-    img = torch.empty((*lead, H, W), dtype=torch.float32, device=spec.device)
+    if channels is None:
+        n = 1
+        for d in lead:
+            n *= d
+        img = torch.empty((*lead, H, W), dtype=torch.float32, device=spec.device)
+        with torch.cuda.device(spec.device):
+            rc = lib().uno_dft2d_inverse(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                                         int(mask_overlap), _stream(spec))
+        _check(rc, "uno_dft2d_inverse")
+        return img
+    if spec.dim() != 4 or channel_offset < 0 or channels < 1 or channel_offset + channels > spec.shape[1]:
+        raise RuntimeError("uno_amd: spec must be (B, Ctot, 2*m1, m2) holding the requested channel range")
+    B = spec.shape[0]
+    img = torch.empty((B, channels, H, W), dtype=torch.float32, device=spec.device)
     with torch.cuda.device(spec.device):
-        rc = lib().uno_dft2d_inverse(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols),
-                                     int(mask_overlap), _stream(spec))
-    _check(rc, "uno_dft2d_inverse")
+        rc = lib().uno_dft2d_inverse_grouped(_ptr(spec), _ptr(img), B * channels, H, W, m1, m2, float(scale), int(hermitian_cols),
+                                             int(mask_overlap), int(channels), spec.shape[1], int(channel_offset), _stream(spec))
+    _check(rc, "uno_dft2d_inverse_grouped")
     return img
 
 

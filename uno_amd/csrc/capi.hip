@@ -105,7 +105,7 @@ static int check_modes2d(const char* who, int H, int W, int Ho, int Wo, int m1, 
 }
 
 static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, int W, int m1, int m2, float scale,
-                 int herm, int mask, hipStream_t s) {
+                 int herm, int mask, hipStream_t s, int sp_group = 0, int sp_stride = 0, int sp_offset = 0) {
     const char* who = inverse ? "uno_dft2d_inverse" : "uno_dft2d_forward";
     if (n_img < 0) { set_error("%s: negative image count", who); return -1; }
     if (n_img > 0 && (!in || !out)) { set_error("%s: null pointer", who); return -1; }
@@ -114,6 +114,14 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     Dft2dParams p;
     p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
     p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0;
+    if (sp_group <= 0) { sp_group = n_img; sp_stride = 0; sp_offset = 0; }          // plain layout: spectrum i of image i
+    if (sp_offset < 0 || sp_stride < sp_offset + sp_group || n_img % sp_group) {
+        if (!(sp_stride == 0 && sp_offset == 0 && sp_group == n_img)) {
+            set_error("%s: bad spectrum grouping (group %d, stride %d, offset %d, images %d)", who, sp_group, sp_stride, sp_offset, n_img);
+            return -1;
+        }
+    }
+    p.sp_group = sp_group; p.sp_stride = sp_stride; p.sp_offset = sp_offset;
     p.twH = twiddle_table(H);
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
@@ -217,6 +225,18 @@ int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W,
 int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale,
                       int hermitian_cols, int mask_overlap, void* stream) {
     return dft2d(true, spec, images, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream);
+}
+
+int uno_dft2d_forward_grouped(const float* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
+                              int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream) {
+    if (group < 1) { set_error("uno_dft2d_forward_grouped: group must be positive"); return -1; }
+    return dft2d(false, images, spec, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream, group, stride, offset);
+}
+
+int uno_dft2d_inverse_grouped(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale,
+                              int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream) {
+    if (group < 1) { set_error("uno_dft2d_inverse_grouped: group must be positive"); return -1; }
+    return dft2d(true, spec, images, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream, group, stride, offset);
 }
 
 int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,

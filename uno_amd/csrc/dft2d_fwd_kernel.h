@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
     }
 
     if (wave == 0) {
-        float2* out = reinterpret_cast<float2*>(p.out) + (size_t)blockIdx.x * 2 * m1 * m2;
+        float2* out = reinterpret_cast<float2*>(p.out) + spectrum_index(p, blockIdx.x) * 2 * m1 * m2;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int l = 16 * t + r16;

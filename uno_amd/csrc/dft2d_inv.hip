@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv
     // Operand lane (rho = r16 -> mode 16 t + 4 (rho & 3) + (rho >> 2), k-slot kk -> k = 4 ks + kk).
     constexpr int KSK = 2 * JT + 1;                       // >= ceil((m1 + 1) / 4)
     const int ksk = (m1 + 4) >> 2;                        // k-steps actually needed
-    const float2* O = reinterpret_cast<const float2*>(p.in) + (size_t)blockIdx.x * 2 * m1 * m2;
+    const float2* O = reinterpret_cast<const float2*>(p.in) + spectrum_index(p, blockIdx.x) * 2 * m1 * m2;
     float Pr[NT][KSK], Pi[NT][KSK], Mr[NT][KSK], Mi[NT][KSK];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

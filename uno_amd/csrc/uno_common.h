@@ -66,7 +66,14 @@ struct Dft2dParams {
     float scale;            // applied to every spectrum entry
     int herm;               // 1: multiply column l by the Hermitian weight c_l of W
     int mask;               // 1: zero lo-corner rows overwritten by the hi corner (later-wins)
+    // spectrum of image i lives at index (i / sp_group) * sp_stride + sp_offset + i % sp_group: a (B, C1) batch of
+    // images can face channels [sp_offset, sp_offset + C1) of a (B, sp_stride) spectrum tensor (two-source blocks)
+    int sp_group, sp_stride, sp_offset;
 };
+
+__device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {
+    return (size_t)(img / p.sp_group) * p.sp_stride + p.sp_offset + img % p.sp_group;
+}
 
 // Batched per-mode complex GEMM: out(m, n, p) = sum_k A'(m, k, p) * B'(k, n, p), ' = optional conj.
 // All offsets are in complex (float2) elements.  Modes are split in `ncorner` contiguous runs

@@ -63,11 +63,19 @@ class UNO_9(nn.Module):
         c0 = self.conv0(lifted, d1 // 2, d2 // 2)
         c1 = self.conv1(c0, d1 // 4, d2 // 4)
         c2 = self.conv2(c1, d1 // 4, d2 // 4)
-        c4 = torch.cat([self.conv4(c2, d1 // 2, d2 // 2), c0], dim=1)
-        # fc1 on cat([conv5 output, lifted]) without building the concatenation
-        c5 = channel_mix_cat([self.conv5(c4, d1, d2), lifted], self.fc1.weight, self.fc1.bias)
+        # skip connections: conv5 consumes cat([conv4 output, c0]) and fc1 cat([conv5 output, lifted]) from their two
+        # sources; the concatenations are never built
+        c5 = channel_mix_cat([_block_cat(self.conv5, [self.conv4(c2, d1 // 2, d2 // 2), c0], d1, d2), lifted],
+                             self.fc1.weight, self.fc1.bias)
         out = gelu_project(c5, self.fc2.weight, self.fc2.bias)
         return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)
+
+
+def _block_cat(block, xs, *dims):
+    """block(torch.cat(xs, dim=1), *dims); product blocks take the sources as they are."""
+    if hasattr(block, "forward_cat"):
+        return block.forward_cat(xs, *dims)
+    return block(torch.cat(list(xs), dim=1), *dims)
 
 
 def _cached(cache: dict, key, build):

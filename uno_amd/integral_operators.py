@@ -315,6 +315,95 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         return gx, gw1, gw2, gcw, gcb, None, None
 
 
+class _OperatorBlock2dCatFn(torch.autograd.Function):
+    """_OperatorBlock2dFn for an input that the reference builds with torch.cat([x1, x2], dim=1) (skip connections,
+    reference darcy_flow_uno2d.py:117-125), without building it: K1 transforms the two sources into the channel ranges
+    of one truncated spectrum, the point-wise branch mixes the two sources with the two column blocks of the 1x1
+    weight, and the backward pass returns the two input gradients as separate contiguous tensors (no strided slices
+    of a joint gradient to copy or accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo):
+        from .resample import resample_forward
+        x1, x2, w1, w2 = _plain(x1), _plain(x2), _plain(w1), _plain(w2)
+        B, C1, H, W = x1.shape
+        C2 = x2.shape[1]
+        Ci, Co, m1, m2 = w1.shape
+        cwm = _plain(cw).reshape(Co, Ci)
+        cwa, cwb = cwm[:, :C1].contiguous(), cwm[:, C1:].contiguous()
+        cb = None if cb is None else _plain(cb)
+        # spectral branch, stage by stage (the composite entry point takes a single source)
+        xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x1.device)
+        _native.dft2d_forward(x1, m1, m2, 1.0 / (H * W), out=xt, channel_offset=0)
+        _native.dft2d_forward(x2, m1, m2, 1.0 / (H * W), out=xt, channel_offset=C1)
+        O = _native.mode_mix(xt.view(B, Ci, 2, m1 * m2), [w1, w2], 0)
+        s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True)
+        # point-wise branch accumulates into s
+        same = (H, W) == (Ho, Wo)
+        mix_last = same or Ho * Wo < H * W
+        if mix_last:
+            a1 = x1 if same else resample_forward(x1, Ho, Wo)
+            a2 = x2 if same else resample_forward(x2, Ho, Wo)
+            sv = s.view(B, Co, -1)
+            _native.channel_mix(a1.view(B, C1, -1), cwa, cb, out=sv)
+            _native.channel_mix(a2.view(B, C2, -1), cwb, None, out=sv)
+        else:
+            a1, a2 = x1, x2
+            t = _native.channel_mix(x1.view(B, C1, -1), cwa, cb)
+            _native.channel_mix(x2.view(B, C2, -1), cwb, None, out=t)
+            resample_forward(t.view(B, Co, H, W), Ho, Wo, out=s)
+        ctx.save_for_backward(xt, w1, w2, cwa, cwb, a1, a2)
+        ctx.geom = (H, W, same, mix_last, cb is not None, tuple(cw.shape))
+        return s
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gs):
+        from .resample import resample_adjoint
+        xt, w1, w2, cwa, cwb, a1, a2 = ctx.saved_tensors
+        H, W, same, mix_last, has_bias, cw_shape = ctx.geom
+        gs = _plain(gs)
+        B, Co, Ho, Wo = gs.shape
+        Ci, _, m1, m2 = w1.shape
+        C1, C2 = a1.shape[1], a2.shape[1]
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_gw = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        need_gc = ctx.needs_input_grad[4] or (has_bias and ctx.needs_input_grad[5])
+        gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)                       # c (.) keep (.) DFT_trunc(gs)
+        gw1 = gw2 = None
+        if need_gw:
+            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape), 2)
+        gx1 = gx2 = None
+        if need1 or need2:
+            gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
+            if need1:
+                gx1 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C1, channel_offset=0)
+            if need2:
+                gx2 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C2, channel_offset=C1)
+        gcw = gcb = None
+        if mix_last:
+            g_src = gs.view(B, Co, -1)
+            for gx, cwx, Cx in ((gx1, cwa, C1), (gx2, cwb, C2)):
+                if gx is None:
+                    continue
+                if same:
+                    _native.channel_mix(g_src, cwx, None, transpose_w=True, out=gx.view(B, Cx, -1))
+                else:
+                    g_act = _native.channel_mix(g_src, cwx, None, transpose_w=True)
+                    resample_adjoint(g_act.view(B, Cx, Ho, Wo), H, W, out=gx)
+        else:
+            g_src = resample_adjoint(gs, H, W).view(B, Co, -1)
+            if gx1 is not None:
+                _native.channel_mix(g_src, cwa, None, transpose_w=True, out=gx1.view(B, C1, -1))
+            if gx2 is not None:
+                _native.channel_mix(g_src, cwb, None, transpose_w=True, out=gx2.view(B, C2, -1))
+        if need_gc:
+            gwa, gcb = _native.channel_wgrad(g_src, a1.view(B, C1, -1), need_bias=has_bias)
+            gwb, _ = _native.channel_wgrad(g_src, a2.view(B, C2, -1), need_bias=False)
+            gcw = torch.cat([gwa, gwb], dim=1).view(cw_shape)
+        return gx1, gx2, gw1, gw2, gcw, gcb, None, None
+
+
 def spectral_conv2d(x, weights1, weights2, dim1, dim2):
     """Functional form of SpectralConv2d_Uno.forward (reference integral_operators.py:181-207)."""
     return _SpectralConv2dFn.apply(x, weights1, weights2, dim1, dim2)
@@ -397,6 +486,26 @@ class OperatorBlock_2D(nn.Module):
         if self.non_lin:
             out = F.gelu(out)
         return out
+
+    def forward_cat(self, xs, dim1=None, dim2=None):
+        """self(torch.cat(xs, dim=1), dim1, dim2) for a skip connection (reference darcy_flow_uno2d.py:117-125) - two
+        float32 device tensors are consumed in place, the concatenation is never built."""
+        xs = list(xs)
+        conv, w = self.conv, self.w
+        d1, d2 = (dim1, dim2) if dim1 is not None else (w.dim1, w.dim2)
+        cdims = (dim1, dim2) if dim1 is not None else (conv.dim1, conv.dim2)
+        fused = (len(xs) == 2 and all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 for x in xs)
+                 and xs[0].shape[0] == xs[1].shape[0] and xs[0].shape[2:] == xs[1].shape[2:]
+                 and xs[0].shape[1] + xs[1].shape[1] == conv.in_channels and cdims == (d1, d2)
+                 and w.conv.weight.dtype == torch.float32)
+        if not fused:
+            return self.forward(torch.cat(xs, dim=1), dim1, dim2)
+        if dim1 is not None:
+            conv.dim1, conv.dim2 = dim1, dim2
+        out = _OperatorBlock2dCatFn.apply(xs[0], xs[1], conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2))
+        if self.normalize:
+            return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
+        return F.gelu(out) if self.non_lin else out
 
     def _branches(self, x, dim1, dim2):
         conv, w = self.conv, self.w
