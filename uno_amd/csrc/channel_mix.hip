@@ -225,8 +225,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 // straight from global memory in MFMA operand layout with only W in LDS (10-20 % slower).  What did pay: fewer and
 // wider vector-memory instructions covering fewer cache lines each (W as one 16-byte load per thread, whole-row
 // stores) - the address unit (TA) was the busiest block of the CU at 63 %.
-template <int PT>
-__global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
+// TINY: rows shorter than 4 pixels (scalar guarded path) - a kernel of its own so that its register needs do not set
+// the occupancy of the real one.  Also measured and dropped: two chunks in flight per workgroup (same time).
+template <int PT, bool TINY>
+__global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(ChannelMixParams p) {
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * (PT + 16)];
     __shared__ float sW[2][CM_KC * CM_WS];
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
@@ -235,9 +237,12 @@ __global__ __launch_bounds__(256) void channel_mix_kernel(ChannelMixParams p) {
     const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntile) return;
     const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
-    if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT>(p, sX, sW, p0, o0, b);
-    else if (p.P >= 4) channel_mix_tile<1, PT>(p, sX, sW, p0, o0, b);
-    else channel_mix_tile<0, PT>(p, sX, sW, p0, o0, b);
+    if constexpr (TINY) {
+        channel_mix_tile<0, PT>(p, sX, sW, p0, o0, b);
+    } else {
+        if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT>(p, sX, sW, p0, o0, b);
+        else channel_mix_tile<1, PT>(p, sX, sW, p0, o0, b);
+    }
 }
 
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
@@ -257,7 +262,8 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
         ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0)) + 4.0 * Ci * Co, s);
-        hipLaunchKernelGGL(channel_mix_kernel<CM_PT>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        if (P >= 4) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_mix launch: %s", hipGetErrorString(e)); return -5; }
