@@ -121,6 +121,39 @@ def spectral_block_roofline(dev, iters=10):
             "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS}
 
 
+def spectral_block3d_roofline(dev, iters=10):
+    """Config C4 of SURVEY.md section 8(d): SpectralConv3d(32, 32, 64, 64, 20, modes 16, 16, 8), batch 8, forward and
+    backward against the algorithmic bytes (fwd = in + out + 4 corner weights; bwd = in + out + 2 x weights)."""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(0)
+    B, C, H, W, T, m1, m2, m3 = 8, 32, 64, 64, 20, 16, 16, 8
+    x = torch.randn(B, C, H, W, T, generator=g).to(dev)
+    sc = (1 / (2 * C)) ** 0.5
+    ws = [(sc * torch.randn(C, C, m1, m2, m3, dtype=torch.cfloat, generator=g)).to(dev) for _ in range(4)]
+    gy = torch.randn(B, C, H, W, T, generator=g).to(dev)
+    y, xt = _native.spectral_conv3d_forward(x, ws, H, W, T)
+    _native.spectral_conv3d_backward(gy, xt, ws, H, W, T)
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    tf = timed(lambda: _native.spectral_conv3d_forward(x, ws, H, W, T))
+    tb = timed(lambda: _native.spectral_conv3d_backward(gy, xt, ws, H, W, T))
+    vol = B * C * H * W * T * 4
+    wb = 4 * C * C * m1 * m2 * m3 * 8
+    fwd_b, bwd_b = 2 * vol + wb, 2 * vol + 2 * wb
+    return {"config": f"SpectralConv3d({C},{C},{H},{W},{T},{m1},{m2},{m3}) batch {B} f32",
+            "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_bytes": fwd_b, "bwd_bytes": bwd_b,
+            "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -210,6 +243,7 @@ def main():
                         "kernels": {k: {"launches": v[0], "total_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9}
                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
         block = spectral_block_roofline(dev) if world == 1 else None
+        block3d = spectral_block3d_roofline(dev) if world == 1 else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_bounded(args.cpu_batch)
@@ -221,7 +255,7 @@ def main():
             "config": {"workload": f"Darcy 2D {S}x{S}, UNO_9(3,{WIDTH},pad={PAD}) 64ch, batch {BATCH}/GPU, train step "
                                    "(fwd+loss+bwd+allreduce+Adam)", "global_batch": world * BATCH,
                        "parallelism": f"dp{world}", "final_loss": loss_val},
-            "roofline": roofline, "spectral_block": block, "cpu_baseline": cpu,
+            "roofline": roofline, "spectral_block": block, "spectral_block_3d": block3d, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

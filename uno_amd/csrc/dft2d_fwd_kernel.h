@@ -371,7 +371,7 @@ template <int NT, int MT, bool VEC, int R4>
 static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
     constexpr int NS = (R4 > 0 ? NT - 1 : NT) + R4;
     const int nrt = (p.H + 15) / 16;
-    const int NW = pick_waves_per_image(nrt);
+    const int NW = (long long)p.H * p.W < 4096 ? 1 : pick_waves_per_image(nrt);     // small images (3-D planes): one wave each, more images in flight per CU
     const size_t red = (size_t)(NW / 2) * MT * NT * 8 * 64 * sizeof(float);
     const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)TAILMAX * (2 + NS) * 64 * 4 + red;
     if (lds > 160 * 1024) { set_error("dft2d_fwd: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }

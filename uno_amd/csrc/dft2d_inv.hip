@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv
 template <int KS, int JT>
 static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
     const int nrt = (p.H + 15) / 16;
-    const int NW = pick_waves_per_image(nrt);
+    const int NW = (long long)p.H * p.W < 4096 ? 1 : pick_waves_per_image(nrt);     // small images (3-D planes): one wave each, more images in flight per CU
     const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)NW * 2 * 16 * STG_RS * sizeof(float) + (size_t)KS * 64 * 4;
     if (lds > 160 * 1024) { set_error("dft2d_inv: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
     auto k = dft2d_inv_kernel<KS, JT>;
