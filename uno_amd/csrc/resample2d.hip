@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restr
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
 
-template <bool ACCUM>
+template <bool ACCUM, int KT>      // KT: compiled tap count of the column operator (>= KW; weights past KW are zero)
 __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
@@ -91,16 +91,36 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
         float acc[RS_TR];
 #pragma unroll
         for (int r = 0; r < RS_TR; ++r) acc[r] = 0.f;
-#pragma unroll 4
-        for (int u = 0; u < NP; ++u) {
-            const float x = src[(size_t)min(p0 + u, H - 1) * W + q];
-            const f32x4* w4 = reinterpret_cast<const f32x4*>(sWd + u * RS_TR);      // wave-uniform address: LDS broadcast
+        // input rows in groups of 4, the next group's loads issued before the current group is consumed (the compiler's
+        // own unrolling drained every group - s_waitcnt vmcnt(0) - before issuing the next: one memory latency per 4 rows)
+        const float* col = src + q;
+        auto load4 = [&](int u0, float x[4]) {
 #pragma unroll
-            for (int r4 = 0; r4 < RS_TR / 4; ++r4) {
-                const f32x4 w = w4[r4];
+            for (int i = 0; i < 4; ++i) x[i] = col[(size_t)min(p0 + u0 + i, H - 1) * W];      // clamped: rows past the tile meet no weights
+        };
+        auto fma4 = [&](int u0, const float x[4]) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * r4 + e] = fmaf(w[e], x, acc[4 * r4 + e]);
+            for (int i = 0; i < 4; ++i) {
+                if (u0 + i < NP) {                                                             // uniform
+                    const f32x4* w4 = reinterpret_cast<const f32x4*>(sWd + (u0 + i) * RS_TR);  // wave-uniform address: LDS broadcast
+#pragma unroll
+                    for (int r4 = 0; r4 < RS_TR / 4; ++r4) {
+                        const f32x4 w = w4[r4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * r4 + e] = fmaf(w[e], x[i], acc[4 * r4 + e]);
+                    }
+                }
             }
+        };
+        float xa[4], xb[4];
+        load4(0, xa);
+        for (int u = 0; u < NP; u += 8) {
+            load4(u + 4, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            fma4(u, xa);
+            load4(u + 8, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            fma4(u + 4, xb);
         }
 #pragma unroll
         for (int r = 0; r < RS_TR; ++r) V[r * W + q] = acc[r];
@@ -116,15 +136,20 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
     if (g < G) {
         for (int j = tid - g * WoP; j < Wo; j += jstride) {
             const int s = startW[j];
-            float w[16];
+            // straight-line taps: KW is a run-time value, and `if (t < KW)` per tap compiled to a chain of branches with a
+            // load (then an LDS read) under each
+            float w[KT];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) w[t] = t < KW ? wtW[(size_t)j * KW + t] : 0.f;
+            for (int t = 0; t < KT; ++t) {
+                float wv = wtW[(size_t)j * KW + min(t, KW - 1)];
+                asm volatile("" : "+v"(wv));
+                w[t] = t < KW ? wv : 0.f;
+            }
             for (int r = g; r < nr; r += G) {
                 const float* v = V + r * W;
                 float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    if (t < KW) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
+                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
                 // ACCUM is a template parameter: a run-time flag here put a conditional load into the store loop and
                 // cost the plain path 60 % (227 -> 362 us at 1024 x 446^2 -> 223^2)
                 dst[(size_t)r * Wo + j] = ACCUM ? dst[(size_t)r * Wo + j] + acc : acc;
@@ -144,12 +169,19 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
         // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
         const int sweeps = (W + 511) / 512;
         const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
-        if (accumulate)
-            hipLaunchKernelGGL(resample_fused_kernel<true>, dim3((Ho + RS_TR - 1) / RS_TR, n_img), dim3(nthreads), lds, s, in, out, tile_p0,
-                               tile_w, NP, startW, wtW, KW, H, W, Ho, Wo);
-        else
-            hipLaunchKernelGGL(resample_fused_kernel<false>, dim3((Ho + RS_TR - 1) / RS_TR, n_img), dim3(nthreads), lds, s, in, out, tile_p0,
-                               tile_w, NP, startW, wtW, KW, H, W, Ho, Wo);
+        const dim3 grid((Ho + RS_TR - 1) / RS_TR, n_img);
+#define UNO_RS_LAUNCH(A, K) hipLaunchKernelGGL((resample_fused_kernel<A, K>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
+                                               startW, wtW, KW, H, W, Ho, Wo)
+        // tap counts seen in the U-NO models: 4-5 (up-sampling by ~2 and its adjoint's rows), 9-10 (down-sampling by ~2)
+#define UNO_RS_PICK(A)                                                                                                         \
+        do {                                                                                                                   \
+            if (KW <= 4) UNO_RS_LAUNCH(A, 4); else if (KW <= 5) UNO_RS_LAUNCH(A, 5); else if (KW <= 8) UNO_RS_LAUNCH(A, 8);    \
+            else if (KW <= 9) UNO_RS_LAUNCH(A, 9); else if (KW <= 10) UNO_RS_LAUNCH(A, 10);                                    \
+            else if (KW <= 12) UNO_RS_LAUNCH(A, 12); else UNO_RS_LAUNCH(A, 16);                                                \
+        } while (0)
+        if (accumulate) UNO_RS_PICK(true); else UNO_RS_PICK(false);
+#undef UNO_RS_PICK
+#undef UNO_RS_LAUNCH
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
