@@ -36,20 +36,45 @@ __device__ __forceinline__ float in_block_sum(float s, float* red) {
     return t;
 }
 
-// visit the row in 16-byte pieces (rows are only 4-byte aligned): f(k, v[4], n_valid)
-template <class F>
-__device__ __forceinline__ void in_sweep(const float* row, int N, F f) {
+// Visit the row(s) in 16-byte pieces (rows are only 4-byte aligned): f(k, v0[4], v1[4], n_valid).  Pieces are taken in
+// groups of 4 per thread with the NEXT group's loads issued before the current group is consumed; left to the compiler's
+// unrolling every group was drained (s_waitcnt vmcnt(0)) before the next was issued - one memory latency per group.
+template <bool TWO, class F>
+__device__ __forceinline__ void in_sweep(const float* row0, const float* row1, int N, F f) {
     const int nq = N >> 2;
-#pragma unroll 4
-    for (int q = threadIdx.x; q < nq; q += IN_T) {      // unrolled: 4 independent 16-byte loads in flight per thread
-        const f4u t = *reinterpret_cast<const f4u*>(row + 4 * q);
-        f(4 * q, t.v, 4);
+    if (nq > 0) {
+        f4u a0[4], a1[4], b0[4], b1[4];
+        auto load = [&](int k, f4u* d0, f4u* d1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = min((int)threadIdx.x + (k + i) * IN_T, nq - 1);       // clamped: pieces past the end are not consumed
+                d0[i] = *reinterpret_cast<const f4u*>(row0 + 4 * q);
+                if (TWO) d1[i] = *reinterpret_cast<const f4u*>(row1 + 4 * q);
+            }
+        };
+        auto use = [&](int k, const f4u* d0, const f4u* d1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = threadIdx.x + (k + i) * IN_T;
+                if (q < nq) f(4 * q, d0[i].v, TWO ? d1[i].v : d0[i].v, 4);
+            }
+        };
+        const int cnt = (nq - (int)threadIdx.x + IN_T - 1) / IN_T;                   // pieces of this thread (<= 0: none)
+        load(0, a0, a1);
+        for (int k = 0; k < cnt; k += 8) {
+            load(k + 4, b0, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            use(k, a0, a1);
+            load(k + 8, a0, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            use(k + 4, b0, b1);
+        }
     }
     const int tail = N & 3;
     if (tail && threadIdx.x == 0) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < tail; ++i) v[i] = row[4 * nq + i];
-        f(4 * nq, v, tail);
+        float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < tail; ++i) { v0[i] = row0[4 * nq + i]; if (TWO) v1[i] = row1[4 * nq + i]; }
+        f(4 * nq, v0, v1, tail);
     }
 }
 
@@ -62,16 +87,16 @@ __global__ __launch_bounds__(IN_T) void instnorm_fwd_kernel(const float* __restr
     const float* row = x + (size_t)r * N;
     float* dst = y + (size_t)r * N;
     float s = 0.f;
-    in_sweep(row, N, [&](int, const float* v, int n) { for (int i = 0; i < n; ++i) s += v[i]; });
+    in_sweep<false>(row, row, N, [&](int, const float* v, const float*, int n) { for (int i = 0; i < n; ++i) s += v[i]; });
     const float mean = in_block_sum(s, red) / (float)N;
     float q = 0.f;
-    in_sweep(row, N, [&](int, const float* v, int n) { for (int i = 0; i < n; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); } });
+    in_sweep<false>(row, row, N, [&](int, const float* v, const float*, int n) { for (int i = 0; i < n; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); } });
     const float var = in_block_sum(q, red) / (float)N;
     const float rstd = 1.f / sqrtf(var + eps);
     if (threadIdx.x == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float a = g * rstd, sh = b - mean * a;                    // z = a * x + sh
-    in_sweep(row, N, [&](int k, const float* v, int n) {
+    in_sweep<false>(row, row, N, [&](int k, const float* v, const float*, int n) {
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float z = fmaf(a, v[i], sh); o[i] = GELU ? in_gelu(z) : z; }
@@ -103,33 +128,25 @@ __global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const float* __restr
         xhat = (xv - mean) * rstd;
         return GELU ? in_dgelu(fmaf(g, xhat, b)) * gv : gv;
     };
-    {
-        const int nq = N >> 2;
-#pragma unroll 4
-        for (int q = threadIdx.x; q < nq; q += IN_T) {
-            const f4u a = *reinterpret_cast<const f4u*>(row + 4 * q), d = *reinterpret_cast<const f4u*>(grow + 4 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { float xh; const float gz = gz_of(a.v[i], d.v[i], xh); s1 += gz; s2 = fmaf(gz, xh, s2); }
-        }
-        if ((N & 3) && threadIdx.x == 0)
-            for (int k = 4 * nq; k < N; ++k) { float xh; const float gz = gz_of(row[k], grow[k], xh); s1 += gz; s2 = fmaf(gz, xh, s2); }
-    }
+    in_sweep<true>(row, grow, N, [&](int, const float* xv, const float* gv, int n) {
+        for (int i = 0; i < n; ++i) { float xh; const float gz = gz_of(xv[i], gv[i], xh); s1 += gz; s2 = fmaf(gz, xh, s2); }
+    });
     const float S1 = in_block_sum(s1, red), S2 = in_block_sum(s2, red);
     if (threadIdx.x == 0) { s1_out[r] = S1; s2_out[r] = S2; }
     const float m1 = S1 / (float)N, m2 = S2 / (float)N, gr = g * rstd;
-    {
-        const int nq = N >> 2;
-#pragma unroll 4
-        for (int q = threadIdx.x; q < nq; q += IN_T) {
-            const f4u a = *reinterpret_cast<const f4u*>(row + 4 * q), d = *reinterpret_cast<const f4u*>(grow + 4 * q);
-            f4u o;
+    in_sweep<true>(row, grow, N, [&](int k, const float* xv, const float* gv, int n) {
+        float o[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { float xh; const float gz = gz_of(a.v[i], d.v[i], xh); o.v[i] = gr * (gz - m1 - xh * m2); }
-            *reinterpret_cast<f4u*>(dst + 4 * q) = o;
+        for (int i = 0; i < 4; ++i) { float xh; const float gz = gz_of(xv[i], gv[i], xh); o[i] = gr * (gz - m1 - xh * m2); }
+        if (n == 4) {
+            f4u t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.v[i] = o[i];
+            *reinterpret_cast<f4u*>(dst + k) = t;
+        } else {
+            for (int i = 0; i < n; ++i) dst[k + i] = o[i];
         }
-        if ((N & 3) && threadIdx.x == 0)
-            for (int k = 4 * nq; k < N; ++k) { float xh; const float gz = gz_of(row[k], grow[k], xh); dst[k] = gr * (gz - m1 - xh * m2); }
-    }
+    });
 }
 
 int launch_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
