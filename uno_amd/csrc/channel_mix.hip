@@ -171,6 +171,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         constexpr int OS = PT + 16;         // 64-bank LDS: the 8 rows x 4 lane groups of a 16-byte write spread over all banks
         float* sO = &sX[0][0] + wave * (8 * OS);
         const int c4 = (lane & 31) * 4;
+        // bias of the wave's 16 channels: one load per lane up front, handed out by shuffle (a load per stored row inside
+        // the loop below put an L2 round trip in front of every store); likewise all reads of an accumulating call are
+        // issued before the first store (the compiler must keep a later load of y behind an earlier store to y)
+        const float bias_l = p.bias ? p.bias[o0 + 16 * wave + r16] : 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if ((r16 >> 3) == h) {
@@ -179,18 +183,24 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     *reinterpret_cast<float4*>(sO + (r16 & 7) * OS + 16 * mt + 4 * kk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
             }
             __syncthreads();
+            f4u old[4];
+            float* dst[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
+                dst[it] = p.y + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                if (p.accumulate) old[it] = *reinterpret_cast<const f4u*>(dst[it]);
+                else old[it].v[0] = old[it].v[1] = old[it].v[2] = old[it].v[3] = 0.f;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = 2 * it + (lane >> 5);
-                const int o = o0 + 16 * wave + 8 * h + row;
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
-                const float bv = p.bias ? p.bias[o] : 0.f;
-                float* dst = p.y + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                const float bv = __shfl(bias_l, 8 * h + row);
                 f4u w4;
-                if (p.accumulate) w4 = *reinterpret_cast<const f4u*>(dst);
-                else w4.v[0] = w4.v[1] = w4.v[2] = w4.v[3] = 0.f;
-                w4.v[0] += v.x + bv; w4.v[1] += v.y + bv; w4.v[2] += v.z + bv; w4.v[3] += v.w + bv;
-                *reinterpret_cast<f4u*>(dst) = w4;
+                w4.v[0] = old[it].v[0] + (v.x + bv); w4.v[1] = old[it].v[1] + (v.y + bv);
+                w4.v[2] = old[it].v[2] + (v.z + bv); w4.v[3] = old[it].v[3] + (v.w + bv);
+                *reinterpret_cast<f4u*>(dst[it]) = w4;
             }
             __syncthreads();
         }
