@@ -391,30 +391,47 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     const int o0 = (tile / ntile_i) * CW_T, i0 = (tile % ntile_i) * CW_T;
     const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, p.B * npc);
 
+    // The loads deliver raw 16-byte pieces from clamped addresses; the zero-fill past the row end (shift network) and past
+    // the channel count is applied when the chunk goes to LDS, AFTER the MFMA block - applied at load time it consumed the
+    // loaded registers at once and the wave waited for its loads (s_waitcnt vmcnt(0)) before every MFMA block.
     float4 rg[4], rxv[4];
+    int sh_cur = 0;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     const int c4 = (tid & 15) * 4, row0 = tid >> 4;
+    // buffer loads (uniform base in SGPRs + 32-bit lane offset): the intrinsic is a fixed 128-bit access - as plain loads
+    // of a 4-byte-aligned struct the compiler split these into pairs of 8-byte loads once the registers had to stay
+    // live across the MFMA block, doubling the vector-memory instructions
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_chunk = [&](int idx) {
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK;
-        const float* gb = p.gy + (size_t)b * p.Co * p.P;
-        const float* xb = p.x + (size_t)b * p.Ci * p.P;
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gy + (size_t)b * p.Co * p.P), 0, p.Co * p.P * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.Ci * p.P), 0, p.Ci * p.P * 4, 0x00020000);
+        const int px = pp + c4, pc = min(px, p.P - 4);
+        sh_cur = px - pc;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
-            float4 g = load4_tail(gb + (size_t)min(o0 + row, p.Co - 1) * p.P, pp + c4, p.P);
-            float4 v = load4_tail(xb + (size_t)min(i0 + row, p.Ci - 1) * p.P, pp + c4, p.P);
-            if (o0 + row >= p.Co) g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 + row >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            rg[u] = g; rxv[u] = v;
+            const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 4, 0, 0);
+            const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(i0 + row, p.Ci - 1) * p.P + pc) * 4, 0, 0);
+            rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
+            rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
         }
+    };
+    auto shifted = [&](const float4& v, bool valid) {
+        float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
+        if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
+        if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
+        if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
+        return make_float4(t0, t1, t2, t3);
     };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
-            *reinterpret_cast<float4*>(sG + row * CWV_S + c4) = rg[u];
-            *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = rxv[u];
-            bs[u] += (rg[u].x + rg[u].y) + (rg[u].z + rg[u].w);
+            const float4 g = shifted(rg[u], o0 + row < p.Co), v = shifted(rxv[u], i0 + row < p.Ci);
+            *reinterpret_cast<float4*>(sG + row * CWV_S + c4) = g;
+            *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = v;
+            bs[u] += (g.x + g.y) + (g.z + g.w);
         }
     };
 
@@ -505,7 +522,10 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
 
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          hipStream_t s) {
-    if (P > 0x7fffffffLL || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) { set_error("channel_wgrad: pixel count too large"); return -2; }
+    if ((long long)(Ci > Co ? Ci : Co) * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
+        set_error("channel_wgrad: tensor too large (channels * pixels must stay below 2^29)");
+        return -2;
+    }
     ChannelWgradParams p;
     p.gy = gy; p.x = x; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
     int npc, cps, pk;
