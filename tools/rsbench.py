@@ -23,3 +23,12 @@ for (nimg, a, b) in [(1024, 446, 223), (2048, 223, 111), (2048, 111, 223), (1024
     tb = timeit(lambda: _native.resample2d(y, a, a, bh, bw, tbh))
     t2 = timeit(lambda: _native.resample2d(x, b, b, fh, fw, None))
     print(f"{nimg} x {a}->{b}: fwd {t*1e3:7.1f} us {by/t/1e9:5.2f} TB/s (NP={th[1].shape[1]}) | adjoint {tb*1e3:7.1f} us {by/tb/1e9:5.2f} TB/s (NP={tbh[1].shape[1]}) | two-pass fwd {t2*1e3:7.1f} us")
+print("accumulating calls (out += ...):")
+for (nimg, a, b) in [(1024, 223, 446), (2048, 111, 223), (1024, 446, 223)]:
+    x = torch.randn(nimg, a, a, device=dev)
+    (fh, th), _ = _tables(a, b, str(dev))
+    (fw, _), _ = _tables(a, b, str(dev))
+    out = torch.zeros(nimg, b, b, device=dev)
+    t = timeit(lambda: _native.resample2d(x, b, b, fh, fw, th, out=out))
+    by = 4 * nimg * (a * a + 2 * b * b)
+    print(f"{nimg} x {a}->{b} accumulate: {t*1e3:7.1f} us {by/t/1e9:5.2f} TB/s")
