@@ -69,10 +69,11 @@ def test_ns3d_cpu_oracle_blocks():
 
 @pytest.mark.gpu
 def test_ns2d_gpu_product():
-    _ns2d(None, torch.device("cuda:0"), 1e-4, 5e-3)
+    _ns2d(None, torch.device("cuda:0"), 1e-5, 5e-4)
 
 
 @pytest.mark.gpu
 def test_ns3d_gpu_product():
-    # gradient tolerance: three InstanceNorm3d layers through MIOpen
-    _ns3d(None, torch.device("cuda:0"), 1e-3, 2e-2)
+    # InstanceNorm3d runs on the K13 kernel (it was MIOpen's batch norm, 1e-3 / 2e-2 then); what remains is rocFFT vs
+    # pocketfft inside pointwise_op_3D
+    _ns3d(None, torch.device("cuda:0"), 1e-4, 2e-3)
