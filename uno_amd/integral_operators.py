@@ -557,7 +557,10 @@ class pointwise_op_3D(nn.Module):
     """1x1x1 convolution + the reference's FFT crop/resample (quirks kept bug-for-bug: unnormalised
     forward transform, corners copied into an INPUT-sized zero spectrum, irfftn(s=output dims) that
     trims/zero-pads at the END of each axis, identity trilinear resize) - reference
-    integral_operators.py:430-468.  Stock torch ops; not on the HIP path yet."""
+    integral_operators.py:430-468.  The convolution runs on the channel-mix kernels (K8 / K9) for float32 device
+    tensors - MIOpen executes a 1x1x1 Conv3d with its naive direct kernels, 0.9 s of a 2.2 s first NS-3D step - the
+    FFT resampling is stock torch (rocFFT); the trilinear resize to the size the tensor already has is an exact
+    identity under align_corners=True and is skipped on the device."""
 
     def __init__(self, in_codim, out_codim, dim1, dim2, dim3):
         super().__init__()
@@ -567,7 +570,8 @@ class pointwise_op_3D(nn.Module):
     def forward(self, x, dim1=None, dim2=None, dim3=None):
         if dim1 is None:
             dim1, dim2, dim3 = self.dim1, self.dim2, self.dim3
-        out = self.conv(x)
+        on_device = x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
+        out = channel_mix(x.contiguous(), self.conv.weight, self.conv.bias) if on_device else self.conv(x)
         spec = torch.fft.rfftn(out, dim=[-3, -2, -1])
         kept = torch.zeros_like(spec)
         h1, h2, h3 = dim1 // 2, dim2 // 2, dim3 // 2
@@ -575,6 +579,8 @@ class pointwise_op_3D(nn.Module):
             for cols in (slice(None, h2), slice(-h2, None)):
                 kept[:, :, rows, cols, :h3] = spec[:, :, rows, cols, :h3]
         out = torch.fft.irfftn(kept, s=(dim1, dim2, dim3))
+        if on_device:
+            return out
         return F.interpolate(out, size=(dim1, dim2, dim3), mode="trilinear", align_corners=True)
 
 
