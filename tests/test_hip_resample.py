@@ -78,3 +78,24 @@ def test_resample_accumulates_into_out(sizes):
     gout = gbase.clone()
     resample_adjoint(base, H, W, out=gout)
     assert rel_err(gout.cpu().numpy(), (gbase + resample_adjoint(base, H, W)).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [((8, 10, 6), (8, 10, 11)), ((12, 12, 10), (9, 7, 18)), ((6, 5, 4), (6, 5, 4)), ((5, 40, 30), (9, 33, 30)),
+                                   ((4, 36, 40), (4, 30, 36))])
+def test_trilinear_resample_vs_torch_cpu(sizes):
+    """3-D skip-connection resize (reference navier_stokes_uno3d.py:352-372) on the banded kernels vs torch's CPU op."""
+    from uno_amd.resample import resample3d_trilinear
+    src, dst = sizes
+    g = torch.Generator().manual_seed(sum(src) + sum(dst))
+    x = torch.randn(2, 3, *src, generator=g)
+    gy = torch.randn(2, 3, *dst, generator=g)
+    xc = x.clone().requires_grad_(True)
+    yc = F.interpolate(xc, size=dst, mode="trilinear", align_corners=True)
+    yc.backward(gy)
+    xd = x.cuda().requires_grad_(True)
+    yd = resample3d_trilinear(xd, dst)
+    yd.backward(gy.cuda())
+    assert yd.shape == yc.shape
+    assert rel_err(yd.detach().cpu().numpy(), yc.detach().numpy()) < 2e-6
+    assert rel_err(xd.grad.cpu().numpy(), xc.grad.numpy()) < 2e-6

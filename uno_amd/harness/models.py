@@ -173,7 +173,10 @@ class Uno3D_T20(nn.Module):
 
     @staticmethod
     def _resize(t, like):
-        return F.interpolate(t, size=tuple(like.shape[2:]), mode="trilinear", align_corners=True)
+        # the reference resizes every skip tensor with trilinear / align_corners (navier_stokes_uno3d.py:352-372); on the
+        # device this is the separable banded kernel (the stock backward kernel alone took 20 ms of a 60 ms step)
+        from ..resample import resample3d_trilinear
+        return resample3d_trilinear(t, tuple(like.shape[2:]))
 
     def forward(self, x):
         x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 4, 1, 2, 3).contiguous()

@@ -19,11 +19,19 @@ from . import _native
 
 
 @functools.lru_cache(maxsize=None)
-def _matrix(n_in: int, n_out: int) -> torch.Tensor:
+def _matrix(n_in: int, n_out: int, mode: str = "bicubic_aa") -> torch.Tensor:
+    """1-D operator (n_out, n_in) of torch's own float32 CPU op: "bicubic_aa" = bicubic / antialias / align_corners (the 2-D
+    point-wise branch), "linear" = the per-axis factor of trilinear / align_corners (skip connections of the 3-D model,
+    reference navier_stokes_uno3d.py:352-372)."""
     # a second axis of size 2 -> 2 is an exact identity under align_corners, and avoids torch's
     # degenerate handling of a length-1 axis
     eye = torch.eye(n_in, dtype=torch.float32).view(1, n_in, n_in, 1).expand(1, n_in, n_in, 2).contiguous()
-    r = F.interpolate(eye, size=(n_out, 2), mode="bicubic", align_corners=True, antialias=True)
+    if mode == "bicubic_aa":
+        r = F.interpolate(eye, size=(n_out, 2), mode="bicubic", align_corners=True, antialias=True)
+    elif mode == "linear":
+        r = F.interpolate(eye, size=(n_out, 2), mode="bilinear", align_corners=True)
+    else:
+        raise ValueError(mode)
     return r[0, :, :, 0].t().contiguous()          # (n_out, n_in)
 
 
@@ -69,9 +77,9 @@ def _row_tiles(mat: torch.Tensor):
 
 
 @functools.lru_cache(maxsize=None)
-def _tables(n_in: int, n_out: int, device_str: str):
+def _tables(n_in: int, n_out: int, device_str: str, mode: str = "bicubic_aa"):
     """per direction (forward R, adjoint R^T): ((start, weights) band table, (p0, dense tile weights)) on the device."""
-    R = _matrix(n_in, n_out)
+    R = _matrix(n_in, n_out, mode)
     dev = torch.device(device_str)
     out = []
     for M in (R, R.t().contiguous()):
@@ -115,3 +123,60 @@ def resample2d_bicubic_aa(x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
     if x.shape[-2] == Ho and x.shape[-1] == Wo:
         return x            # the operator is the identity for equal sizes (weights 0, 1, 0, 0)
     return _Resample2dFn.apply(x, int(Ho), int(Wo))
+
+
+# ------------------------------------------------------------------------------------------------ trilinear (3-D skips)
+def _apply3d(x: torch.Tensor, sizes, adjoint: bool) -> torch.Tensor:
+    """Separable trilinear / align_corners operator on (B, C, D1, D2, D3) with the banded kernels: the last two axes in one
+    fused pass over (B*C*D1) images, the first axis as the row operator of (B*C) images of D2*D3 columns (identity on the
+    columns).  adjoint: x is the gradient on the `sizes`-shaped... see callers for the argument order."""
+    dev = str(x.device)
+    B, C = x.shape[:2]
+    (i1, i2, i3), (o1, o2, o3) = sizes              # operator maps (i1, i2, i3) -> (o1, o2, o3); the adjoint maps back
+    k = 1 if adjoint else 0
+    src, dst = ((o1, o2, o3), (i1, i2, i3)) if adjoint else ((i1, i2, i3), (o1, o2, o3))
+
+    def tabs(n_in, n_out):
+        return _tables(n_in, n_out, dev, "linear")[k]       # (band table, row tiles) of R or R^T
+
+    def last_two(t, d1):
+        if (src[1], src[2]) == (dst[1], dst[2]):
+            return t
+        (bh, th), (bw, _) = tabs(i2, o2), tabs(i3, o3)
+        return _native.resample2d(t.reshape(B * C * d1, src[1], src[2]), dst[1], dst[2], bh, bw, th).view(B, C, d1, dst[1], dst[2])
+
+    def first(t, d2, d3):
+        if src[0] == dst[0]:
+            return t
+        (bh, th) = tabs(i1, o1)
+        (bw, _) = _tables(d2 * d3, d2 * d3, dev, "linear")[0]          # identity on the flattened (D2, D3) columns
+        return _native.resample2d(t.reshape(B * C, src[0], d2 * d3), dst[0], d2 * d3, bh, bw, th).view(B, C, dst[0], d2, d3)
+
+    # run the shrinking step first: less data through the second one
+    if src[0] * dst[1] * dst[2] <= dst[0] * src[1] * src[2]:
+        return first(last_two(x, src[0]), dst[1], dst[2])
+    return last_two(first(x, src[1], src[2]), dst[0])
+
+
+class _Trilinear3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        x = x.contiguous()
+        ctx.sizes = (tuple(x.shape[2:]), tuple(size))
+        return _apply3d(x, ctx.sizes, adjoint=False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        return _apply3d(gy.contiguous(), ctx.sizes, adjoint=True), None
+
+
+def resample3d_trilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """== F.interpolate(x, size=size, mode="trilinear", align_corners=True) for 5-D x; float32 device tensors run the banded
+    kernels with torch's own float32 weights (the stock backward is an atomics kernel: 20 ms of a 60 ms NS-3D step)."""
+    size = tuple(int(v) for v in size)
+    if tuple(x.shape[2:]) == size:
+        return x                                    # exact identity under align_corners
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and min(x.shape[2:]) > 1 and min(size) > 1:
+        return _Trilinear3dFn.apply(x, size)
+    return F.interpolate(x, size=size, mode="trilinear", align_corners=True)
