@@ -51,10 +51,10 @@ constexpr int GP_MAXC = 1024;
 __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ out, int C, int P) {
     __shared__ float sw[GP_MAXC];
-    for (int c = threadIdx.x; c < C; c += 256) sw[c] = w[c];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sw[c] = w[c];
     __syncthreads();
     const int b = blockIdx.y;
-    const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int px = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (px >= P) return;
     const float* src = pre + (size_t)b * C * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -91,18 +91,20 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __re
     store4_guard(out + (size_t)b * P, px, P, acc);
 }
 
-// one workgroup = 1024 pixels of one batch entry; partial weight / bias gradients per workgroup: part[blk][C + 1].
+// one workgroup = 4 pixels per thread of one batch entry (256 threads, or 64 when the tensor is small: a 64 x 64 grid at
+// batch 32 gave 128 workgroups of 256 threads for 256 CUs); partial weight / bias gradients per workgroup: part[blk][C + 1].
 // Per channel every wave reduces its 256 pixels by butterfly and parks the sum in LDS; one barrier at the end, then the
 // four wave sums are added in wave order (fixed order -> bit-reproducible).
 __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
                                                                const float* __restrict__ gout, float* __restrict__ gpre,
                                                                float* __restrict__ part, int C, int P) {
     __shared__ float sw[GP_MAXC];
-    extern __shared__ float swave[];                    // [4][C + 1]
-    for (int c = threadIdx.x; c < C; c += 256) sw[c] = w[c];
+    extern __shared__ float swave[];                    // [waves][C + 1]
+    const int nw = blockDim.x >> 6;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) sw[c] = w[c];
     __syncthreads();
     const int b = blockIdx.y;
-    const int px = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int px = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = px < P;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -136,8 +138,11 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __re
     wave_sum((g[0] + g[1]) + (g[2] + g[3]), C);
     __syncthreads();
     float* prow = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (C + 1);
-    for (int e = threadIdx.x; e <= C; e += 256)
-        prow[e] = (swave[e] + swave[(C + 1) + e]) + (swave[2 * (C + 1) + e] + swave[3 * (C + 1) + e]);
+    for (int e = threadIdx.x; e <= C; e += blockDim.x) {
+        float t = swave[e];
+        for (int k = 1; k < nw; ++k) t += swave[k * (C + 1) + e];          // wave order: fixed
+        prow[e] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void gelu_project_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
@@ -156,27 +161,35 @@ __global__ __launch_bounds__(256) void gelu_project_reduce_kernel(const float* _
     }
 }
 
+// 256-thread workgroups unless that leaves the GPU under-filled (< 4 workgroups per CU)
+static int gelu_project_threads(int B, long long P) { return (long long)B * ((P + 1023) / 1024) >= 1024 ? 256 : 64; }
+
 int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s) {
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
-    const unsigned nb = (unsigned)((P + 1023) / 1024);
+    const int threads = gelu_project_threads(B, P);
+    const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     {
         ProfScope prof("uno::gelu_project_fwd_kernel", 4.0 * B * (double)P * (C + 1), s);
-        hipLaunchKernelGGL(gelu_project_fwd_kernel, dim3(nb, B), dim3(256), 0, s, pre, w, bias, out, C, (int)P);
+        hipLaunchKernelGGL(gelu_project_fwd_kernel, dim3(nb, B), dim3(threads), 0, s, pre, w, bias, out, C, (int)P);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gelu_project launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
 }
 
-long long gelu_project_ws_floats(int B, int C, long long P) { return (long long)B * ((P + 1023) / 1024) * (C + 1); }
+long long gelu_project_ws_floats(int B, int C, long long P) {
+    const int t = gelu_project_threads(B, P);
+    return (long long)B * ((P + 4 * t - 1) / (4 * t)) * (C + 1);
+}
 
 int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
                             int C, long long P, hipStream_t s) {
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
-    const unsigned nb = (unsigned)((P + 1023) / 1024);
+    const int threads = gelu_project_threads(B, P);
+    const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     {
         ProfScope prof("uno::gelu_project_bwd_kernel", 4.0 * B * (double)P * (2 * C + 1), s);
-        hipLaunchKernelGGL(gelu_project_bwd_kernel, dim3(nb, B), dim3(256), 4 * (C + 1) * sizeof(float), s, pre, w, gout, gpre, ws, C, (int)P);
+        hipLaunchKernelGGL(gelu_project_bwd_kernel, dim3(nb, B), dim3(threads), (threads / 64) * (C + 1) * sizeof(float), s, pre, w, gout, gpre, ws, C, (int)P);
     }
     hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B));
     const hipError_t e = hipGetLastError();
