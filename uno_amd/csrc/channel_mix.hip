@@ -255,6 +255,125 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
     }
 }
 
+
+// Wide variant for Co % 128 == 0: one workgroup computes 128 output channels of its 128 pixels (each wave two groups of
+// 16 channels), so X is staged once instead of twice and every X fragment read from LDS feeds two MFMAs.  Interior
+// pixel tiles only; the last (partial) pixel tile of a row runs the guarded 64-channel path twice.
+constexpr int CMW_WS = 128 + 16;
+
+__global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixParams p) {
+    constexpr int PT = CM_PT, XS = PT + 16, NM = PT / 16;
+    __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * XS];
+    __shared__ __attribute__((aligned(16))) float sW[2][CM_KC * CMW_WS];
+    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntile) return;
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = blockIdx.y;
+    if (p0 + PT > p.P || (p.Ci & (CM_KC - 1)) != 0) {
+        auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(&sW[0][0]);
+        channel_mix_tile<1, PT>(p, sX, sWn, p0, o0, b);
+        __syncthreads();
+        channel_mix_tile<1, PT>(p, sX, sWn, p0, o0 + 64, b);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* xb = p.x + (size_t)b * p.Ci * p.P;
+    const bool tr = p.w_so == 1 && p.w_si != 1;
+
+    float4 rx[2], rw[2];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            const f4u v = *reinterpret_cast<const f4u*>(xb + (unsigned)((k0 + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+            rx[u] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + 64 * u + (tid & 15) * 4)
+                                     : (unsigned)((o0 + 64 * u + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
+            const f4u wv = *reinterpret_cast<const f4u*>(p.w + woff);
+            rw[u] = make_float4(wv.v[0], wv.v[1], wv.v[2], wv.v[3]);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<float4*>(&sX[buf][(e >> 5) * XS + (e & 31) * 4]) = rx[u];
+            float* d = sW[buf] + (tr ? (tid >> 4) * CMW_WS + 64 * u + (tid & 15) * 4 : (tid & 3) * 4 * CMW_WS + 64 * u + (tid >> 2));
+            const int dstep = tr ? 1 : CMW_WS;
+            d[0] = rw[u].x; d[dstep] = rw[u].y; d[2 * dstep] = rw[u].z; d[3 * dstep] = rw[u].w;
+        }
+    };
+
+    f32x4 acc[2][NM];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) acc[g][mt] = f32x4{0, 0, 0, 0};
+
+    const int nchunk = p.Ci / CM_KC;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) load_chunk((c + 1) * CM_KC);
+#pragma unroll
+        for (int ks = 0; ks < CM_KC / 4; ++ks) {
+            const float* wrow = sW[buf] + (4 * ks + kk) * CMW_WS + 16 * wave + r16;
+            const float w0 = wrow[0], w1 = wrow[64];
+            const float* xrow = sX[buf] + (4 * ks + kk) * XS + r16;
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt) {
+                const float xv = xrow[16 * mt];
+                acc[0][mt] = mfma16(xv, w0, acc[0][mt]);
+                acc[1][mt] = mfma16(xv, w1, acc[1][mt]);
+            }
+        }
+        if (c + 1 < nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue as in the 64-channel kernel, once per channel group
+    constexpr int OS = PT + 16;
+    float* sO = &sX[0][0] + wave * (8 * OS);
+    const int c4 = (lane & 31) * 4;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int ob = o0 + 64 * g + 16 * wave;
+        const float bias_l = p.bias ? p.bias[ob + r16] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((r16 >> 3) == h) {
+#pragma unroll
+                for (int mt = 0; mt < NM; ++mt)
+                    *reinterpret_cast<float4*>(sO + (r16 & 7) * OS + 16 * mt + 4 * kk) =
+                        make_float4(acc[g][mt][0], acc[g][mt][1], acc[g][mt][2], acc[g][mt][3]);
+            }
+            __syncthreads();
+            f4u old[4];
+            float* dst[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int o = ob + 8 * h + 2 * it + (lane >> 5);
+                dst[it] = p.y + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                if (p.accumulate) old[it] = *reinterpret_cast<const f4u*>(dst[it]);
+                else old[it].v[0] = old[it].v[1] = old[it].v[2] = old[it].v[3] = 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = 2 * it + (lane >> 5);
+                const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
+                const float bv = __shfl(bias_l, 8 * h + row);
+                f4u w4;
+                w4.v[0] = old[it].v[0] + (v.x + bv); w4.v[1] = old[it].v[1] + (v.y + bv);
+                w4.v[2] = old[it].v[2] + (v.z + bv); w4.v[3] = old[it].v[3] + (v.w + bv);
+                *reinterpret_cast<f4u*>(dst[it]) = w4;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, hipStream_t s) {
     ChannelMixParams p;
@@ -264,7 +383,8 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     p.w_so = transpose_w ? 1 : Ci;
     p.w_si = transpose_w ? Co : 1;
     constexpr int PT = CM_PT;
-    const long long npt = (P + PT - 1) / PT, ncot = (Co + CM_MT - 1) / CM_MT;
+    const bool wide = Co % 128 == 0 && P >= PT;
+    const long long npt = (P + PT - 1) / PT, ncot = wide ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
@@ -272,7 +392,8 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
         ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0)) + 4.0 * Ci * Co, s);
-        if (P >= 4) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else if (P >= 4) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
     }
     const hipError_t e = hipGetLastError();
