@@ -186,3 +186,18 @@ def test_bucketed_allreduce_with_unused_parameters(tmp_path):
              for p in list(used.parameters()) + list(unused.parameters()) + list(tail.parameters())]
         exp = exp + torch.cat([t.reshape(-1) for t in g])
     assert torch.allclose(flat, exp, rtol=1e-6, atol=1e-7)
+
+
+def test_flat_gradients_rebind_after_zero_grad_set_to_none():
+    from uno_amd.harness.train import FlatGradients
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 3)
+    fg = FlatGradients(lin.parameters())
+    lin(torch.ones(2, 4)).sum().backward()
+    assert fg.flat.abs().sum() > 0
+    for p in lin.parameters():
+        p.grad = None                      # what optimizer.zero_grad() does by default
+    fg.zero_()
+    lin(torch.ones(2, 4)).sum().backward()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(lin.parameters(), fg.views))
+    assert torch.allclose(fg.flat[:12].view(3, 4), torch.full((3, 4), 2.0)) and torch.allclose(fg.flat[12:], torch.full((3,), 2.0))

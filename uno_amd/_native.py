@@ -504,7 +504,7 @@ class AdamPlan:
         self.v = arr(*[r[3].data_ptr() for r in reals])
         self.sizes = (C.c_longlong * self.n)(*[r[4] for r in reals])
         self.cplx = (_i * self.n)(*[r[5] for r in reals])
-        self.key = tuple((r[0].data_ptr(), r[1].data_ptr()) for r in reals)
+        self.key = tuple((r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), r[3].data_ptr()) for r in reals)
 
     def step(self, step: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
         with torch.cuda.device(self.device):

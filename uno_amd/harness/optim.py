@@ -25,7 +25,8 @@ class ComplexAdam(Optimizer):
         from .. import _native
         gid = next(i for i, g in enumerate(self.param_groups) if g is group)
         plan = self._plans.get(gid)
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                    for p in params)       # rebuilt if any buffer moved (e.g. load_state_dict replaces the moments)
         if plan is None or plan.key != key:
             plan = _native.AdamPlan([p.data for p in params], [p.grad for p in params],
                                     [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params])

@@ -43,14 +43,17 @@ class FlatGradients:
         dev = self.params[0].device
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         offsets = []
+        self.views = []
         off = 0
         for p, n in zip(self.params, sizes):
             seg = self.flat[off:off + n]
             if p.is_complex():
-                p.grad = torch.view_as_complex(seg.view(*p.shape, 2))
+                view = torch.view_as_complex(seg.view(*p.shape, 2))
             else:
                 assert p.dtype == torch.float32
-                p.grad = seg.view(p.shape)
+                view = seg.view(p.shape)
+            p.grad = view
+            self.views.append(view)
             offsets.append(off)
             off += n
         # buckets: walk the parameters backwards, close a bucket once it holds bucket_mb
@@ -79,7 +82,12 @@ class FlatGradients:
         self._hooks = []
 
     def zero_(self):
+        """Zero the buffer and make sure every .grad still is its view (optimizer.zero_grad(set_to_none=True) or a user
+        assignment would otherwise leave gradients outside the buffer that gets all-reduced)."""
         self.flat.zero_()
+        for p, view in zip(self.params, self.views):
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
 
     # ------------------------------------------------------------------ overlapped all-reduce
     def arm(self, group=None, force=False):
