@@ -146,6 +146,8 @@ SEEDED = [
     (2, 16, 8, 45, 45, 90, 90, 18, 18),         # UNO_9.conv5 geometry
     (2, 4, 4, 64, 64, 64, 64, 32, 33),          # Nyquist column + full rows
     (3, 5, 3, 37, 50, 29, 31, 9, 13),
+    (1, 2, 3, 96, 100, 88, 96, 40, 48),         # the largest compiled mode counts (modes1 = 40, modes2 = 48)
+    (1, 2, 2, 128, 136, 128, 136, 32, 32),      # BASELINE config 5 modes (32, 32) on a small grid
 ]
 
 
@@ -240,3 +242,13 @@ def test_empty_batch():
     w = torch.randn(3, 4, 2, 3, dtype=torch.cfloat, device=dev())
     x = torch.zeros(0, 3, 8, 8, device=dev())
     assert tuple(spectral_conv2d(x, w, w, 8, 8).shape) == (0, 4, 8, 8)
+
+
+def test_mode_counts_beyond_the_compiled_range_raise():
+    """modes1 <= 40 and modes2 <= 48 are compiled; larger requests fail loudly (no silent fallback)."""
+    from uno_amd.integral_operators import spectral_conv2d
+    x = torch.randn(1, 1, 128, 128, device=dev())
+    for m1, m2 in ((41, 8), (8, 49)):
+        w = torch.randn(1, 1, m1, m2, dtype=torch.cfloat, device=dev())
+        with pytest.raises(RuntimeError, match="compiled range"):
+            spectral_conv2d(x, w, w, 128, 128)
