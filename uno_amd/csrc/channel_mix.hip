@@ -391,7 +391,7 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
-        ProfScope prof("uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0)) + 4.0 * Ci * Co, s);
+        ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0)) + 4.0 * Ci * Co, s);
         if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (P >= 4) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
