@@ -170,11 +170,17 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the product path")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dev = torch.device("cuda", local_rank)
+    # developer check of the N > 1 code path on a one-GPU box: UNO_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses
+    # gloo (RCCL refuses two ranks on one device); the driver never sets it
+    share = os.environ.get("UNO_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
 
     from uno_amd import _native
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch

@@ -39,3 +39,51 @@ def test_one_rank_rccl_group_matches_plain_step():
     assert losses == ref_losses
     for p, q in zip(params, ref_params):
         assert torch.equal(p, q)
+
+
+def _two_rank_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")                     # both ranks share the one GPU of the test box (gloo: RCCL refuses that)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                # different init per rank: the broadcast must fix it
+        model = UNO_9(3, 8, pad=5).to(dev)
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3, bucket_mb=0.05)
+        assert len(tr.grads.buckets) > 3
+        a, u = synthetic_darcy_batch(4, 72, 7, dev)
+        sl = slice(2 * rank, 2 * rank + 2)
+        for _ in range(2):
+            tr.step(a[sl], u[sl])
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_device_tensors_equal_single_process(tmp_path):
+    """World size 2 with the product kernels: the bucketed all-reduce is issued from the autograd thread on DEVICE gradient
+    buffers while the backward pass is still running (the CPU gloo test cannot exercise that).  Two ranks on half batches ==
+    one process on the whole batch."""
+    import torch.multiprocessing as mp
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_path = str(tmp_path / "dp2.pt")
+    mp.spawn(_two_rank_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(100)
+    model = UNO_9(3, 8, pad=5).to(dev)
+    tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    a, u = synthetic_darcy_batch(4, 72, 7, dev)
+    for _ in range(2):
+        tr.step(a, u)
+    for k, v in model.state_dict().items():
+        r, g = v.detach().cpu(), got[k]
+        if r.is_complex():
+            r, g = torch.view_as_real(r), torch.view_as_real(g)
+        assert float((r - g).norm()) <= 2e-4 * float(r.norm()) + 1e-12, k
