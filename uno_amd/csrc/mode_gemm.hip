@@ -48,31 +48,33 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     const float sgnA = p.A.conj ? -1.f : 1.f;
     const float sgnB = p.B.conj ? -1.f : 1.f;
 
-    // staging map: element e = tid + 256 * u  ->  (row = e / QC, q = e % QC); A rows = (k, m), B rows = (k, n)
+    // staging map: element e = tid + 256 * u  ->  (row = e / QC, q = e % QC); A rows = (k, m), B rows = (k, n).  With 256 threads
+    // and QC = 16 this is k-local = u, x = tid / 16, q = tid % 16: a thread walks K with a fixed (x, q), so its addresses are
+    // one base per operand plus u * stride (computing the general form per load cost 20-40 integer instructions each)
     float2 ra[EPT], rb[EPT];
+    const int q_t = tid & (QC - 1), x_t = tid >> 4;
+    const bool okA = q_t < nmodes && m0 + x_t < p.M, okB = q_t < nmodes && n0 + x_t < p.N;
+    const float2* pA = Ab + (okA ? (long long)(m0 + x_t) * p.A.s0 + q_t : 0);
+    const float2* pB = Bb + (okB ? (long long)(n0 + x_t) * p.B.s1 + q_t : 0);
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
-            const int e = tid + 256 * u;
-            const int q = e & (QC - 1), row = e >> 4;
-            const int kl = row >> 4, x = row & 15;          // kl in [0, KC), x = m or n within the tile
-            const int k = k0 + kl;
-            float2 va = make_float2(0.f, 0.f), vb = make_float2(0.f, 0.f);
-            if (q < nmodes && k < p.K) {
-                if (m0 + x < p.M) va = Ab[(long long)(m0 + x) * p.A.s0 + (long long)k * p.A.s1 + q];
-                if (n0 + x < p.N) vb = Bb[(long long)k * p.B.s0 + (long long)(n0 + x) * p.B.s1 + q];
-            }
-            ra[u] = va; rb[u] = vb;
+            const int k = min(k0 + u, p.K - 1);                 // clamped address: unconditional loads; the zero-fill of invalid
+            ra[u] = pA[(long long)k * p.A.s1];                  // entries happens on the way to LDS, after the MFMA block
+            rb[u] = pB[(long long)k * p.B.s0];                  // (masking here would consume the registers at once)
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             const int e = tid + 256 * u;
             const int q = e & (QC - 1), row = e >> 4;
             const int o = q * PLANE + row;                  // row = kl * 16 + x
-            sA[o] = ra[u].x; sA[QC * PLANE + o] = sgnA * ra[u].y;
-            sB[o] = rb[u].x; sB[QC * PLANE + o] = sgnB * rb[u].y;
+            const bool kv = k0 + u < p.K;
+            const float2 va = (kv && okA) ? ra[u] : make_float2(0.f, 0.f);
+            const float2 vb = (kv && okB) ? rb[u] : make_float2(0.f, 0.f);
+            sA[o] = va.x; sA[QC * PLANE + o] = sgnA * va.y;
+            sB[o] = vb.x; sB[QC * PLANE + o] = sgnB * vb.y;
         }
     };
 
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     load_chunk(0);
     for (int k0 = 0; k0 < p.K; k0 += KC) {
         __syncthreads();                    // previous chunk fully consumed
-        store_chunk();
+        store_chunk(k0);
         __syncthreads();
         if (k0 + KC < p.K) load_chunk(k0 + KC);
 #pragma unroll
