@@ -14,8 +14,11 @@ forward DFT, per-mode complex MFMA GEMM, pruned inverse DFT; custom autograd wit
 family).  The full spectrum is never materialised.  There is no CPU fallback for these layers: a
 tensor that is not on a HIP device raises ``RuntimeError``.
 
-The point-wise branch of the blocks (1x1 conv + resampling), InstanceNorm and GELU are stock
-PyTorch-ROCm ops here ("next" row 1).
+The rest of an operator block runs on the same library for float32 device tensors: the point-wise branch (1x1
+convolution = channel-mix kernels, bicubic anti-aliased resampling = banded separable kernels) accumulates into the
+spectral branch's output buffer, InstanceNorm (+ GELU) is one kernel; only the GELU of non-normalised blocks and the
+FFT-based resampling of pointwise_op_3D are stock PyTorch-ROCm ops.  CPU tensors take stock torch ops in these helper
+layers (they are not part of the spectral path and the CPU-side harness tests use them with the oracle blocks).
 """
 from __future__ import annotations
 
