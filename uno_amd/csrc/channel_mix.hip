@@ -607,8 +607,19 @@ __global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* 
     const int e = blockIdx.x * 32 + el;
     const int n = Co * (Ci + 1);
     float acc = 0.f;
-    if (e < n)
-        for (int s = grp; s < nsplit; s += 8) acc += part[(size_t)s * n + e];
+    if (e < n) {
+        // 8 independent loads per round (the plain loop issued one load per iteration: a chain of nsplit / 8 memory latencies);
+        // the order of the additions stays fixed
+        int s = grp;
+        for (; s + 56 < nsplit; s += 64) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = part[(size_t)(s + 8 * i) * n + e];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i];
+        }
+        for (; s < nsplit; s += 8) acc += part[(size_t)s * n + e];
+    }
     sh[grp][el] = acc;
     __syncthreads();
     if (grp == 0 && e < n) {
