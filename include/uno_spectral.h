@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 1
+#define UNO_SPECTRAL_ABI_VERSION 2
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNO_AMD_LIB") or os.path.join(_HERE, "lib", "libuno_spectral.so")   # env override: developer A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _lock = threading.Lock()
