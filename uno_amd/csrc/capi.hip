@@ -171,6 +171,35 @@ static int mode_gemm(int op, const float2* act, const float2* const* w, const fl
 
 using namespace uno;
 
+
+// A side stream per device for work that is independent of the caller's critical path (the weight-gradient GEMM of a
+// backward call next to input-gradient GEMM + inverse DFT).  fork(): side waits for everything enqueued on `s` so far;
+// join(): `s` waits for the side stream.  The mutex is held from fork to join, so concurrent callers on one device take
+// turns (enqueueing is short).  Works under stream capture (event fork / join is the capture-safe pattern).
+namespace {
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    std::mutex mu;
+    bool ok = false;
+};
+SideStream* side_stream_of_current_device() {
+    static std::mutex mu;
+    static std::map<int, SideStream*> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = table.find(dev);
+    if (it != table.end()) return it->second->ok ? it->second : nullptr;
+    SideStream* ss = new SideStream();
+    ss->ok = hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ss->fork_ev, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ss->join_ev, hipEventDisableTiming) == hipSuccess;
+    table[dev] = ss;
+    return ss->ok ? ss : nullptr;
+}
+}  // namespace
+
 extern "C" {
 
 int uno_abi_version(void) { return UNO_SPECTRAL_ABI_VERSION; }
@@ -498,17 +527,34 @@ int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const flo
     }
     // gO = c (.) keep (.) DFT_trunc(gy)                                   (adjoint of irfft2 + CopySlices)
     if (int rc = dft2d(false, gy, gO, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s)) return rc;
+    // The weight gradient only shares gO with the input-gradient chain: it runs on the side stream next to the
+    // (under-filled) input-gradient GEMM and the store-bound inverse DFT.
+    SideStream* side = (gw1 && gx) ? side_stream_of_current_device() : nullptr;
+    int rc_w = 0;
     if (gw1) {
         float* gwv[2] = {gw1, gw2};
-        if (int rc = uno_mode_wgrad(xtrunc, gO, gwv, B, Ci, Co, 2, m1 * m2, stream)) return rc;
+        if (side) {
+            side->mu.lock();
+            if (hipEventRecord(side->fork_ev, s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork_ev, 0) != hipSuccess) {
+                side->mu.unlock();
+                side = nullptr;
+            }
+        }
+        rc_w = uno_mode_wgrad(xtrunc, gO, gwv, B, Ci, Co, 2, m1 * m2, side ? (void*)side->s : stream);
     }
-    if (gx) {
+    int rc_x = 0;
+    if (gx && rc_w == 0) {
         const float* wv[2] = {w1, w2};
-        if (int rc = uno_mode_mix(gO, wv, gX, 1, B, Ci, Co, 2, m1 * m2, stream)) return rc;
+        rc_x = uno_mode_mix(gO, wv, gX, 1, B, Ci, Co, 2, m1 * m2, stream);
         // gx = 1/(H W) Re iDFT_trunc(gX)                                   (adjoint of rfft2(norm="forward"))
-        if (int rc = dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s)) return rc;
+        if (rc_x == 0) rc_x = dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s);
     }
-    return 0;
+    if (side) {
+        const bool joined = hipEventRecord(side->join_ev, side->s) == hipSuccess && hipStreamWaitEvent(s, side->join_ev, 0) == hipSuccess;
+        side->mu.unlock();
+        if (!joined) { set_error("uno_spectral_conv2d_backward: side-stream join failed"); return -5; }
+    }
+    return rc_w ? rc_w : rc_x;
 }
 
 }  // extern "C"
