@@ -127,16 +127,20 @@ int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, in
  * applied without the channels-last permute.  x (B, Ci, P), y (B, Co, P), P = pixels per sample (contiguous).
  * transpose_w = 0: w is (Co, Ci) row-major; transpose_w = 1: w is (Ci, Co) row-major and Wm = w^T (this is
  * the input-gradient call: x := grad_y, Ci := forward Co).  bias may be NULL.  accumulate != 0: y += (as in
- * uno_resample2d). */
+ * uno_resample2d).
+ * Fused activation forms for a layer whose input tensor is kept PRE-activation (the model's `fc(F.gelu(t))` patterns,
+ * reference darcy_flow_uno2d.py:98-101, 128-131): act_in != 0 applies the exact-erf GELU to x as it is read (y = Wm gelu(x)
+ * + bias); dgelu_of != NULL (B, Co, P) multiplies the product by gelu'(dgelu_of) - the input-gradient call then returns the
+ * gradient of the pre-activation tensor.  The two are mutually exclusive. */
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co,
-                    long long P, int transpose_w, int accumulate, void* stream);
+                    long long P, int transpose_w, int accumulate, int act_in, const float* dgelu_of, void* stream);
 
 /* Weight / bias gradient of uno_channel_mix: gw[o][i] = sum_{b,p} gy[b][o][p] x[b][i][p], gb[o] = sum gy[b][o][p]
  * (gb may be NULL).  ws: scratch of uno_channel_wgrad_ws_bytes() bytes; partial sums are combined in a fixed
- * order (bit-reproducible run to run). */
+ * order (bit-reproducible run to run).  act_x != 0: x := gelu(x) as it is read (see uno_channel_mix). */
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P);
 int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co,
-                      long long P, void* stream);
+                      long long P, int act_x, void* stream);
 
 /* Final projection of the U-NO models fused with the GELU in front of it (reference darcy_flow_uno2d.py:128-131:
  * `x_fc1 = F.gelu(self.fc1(x)); x_out = self.fc2(x_fc1)` with fc2 = Linear(C, 1)), channels-first:

@@ -64,10 +64,10 @@ def test_argument_errors_of_the_block_level_entry_points(libpath):
     p = ctypes.cast(buf, ctypes.c_void_p)
     nul = ctypes.c_void_p(0)
     cases = [
-        (lib.uno_channel_mix(p, p, nul, p, 2, 0, 4, 10, 0, 0, None), b"bad sizes"),
-        (lib.uno_channel_mix(nul, p, nul, p, 2, 3, 4, 10, 0, 0, None), b"null"),
-        (lib.uno_channel_wgrad(p, p, nul, nul, p, 2, 3, 4, 10, None), b"null"),
-        (lib.uno_channel_wgrad(p, p, p, nul, p, 2, 3, -1, 10, None), b"bad sizes"),
+        (lib.uno_channel_mix(p, p, nul, p, 2, 0, 4, 10, 0, 0, 0, nul, None), b"bad sizes"),
+        (lib.uno_channel_mix(nul, p, nul, p, 2, 3, 4, 10, 0, 0, 0, nul, None), b"null"),
+        (lib.uno_channel_wgrad(p, p, nul, nul, p, 2, 3, 4, 10, 0, None), b"null"),
+        (lib.uno_channel_wgrad(p, p, p, nul, p, 2, 3, -1, 10, 0, None), b"bad sizes"),
         (lib.uno_resample2d(p, p, p, 1, 0, 4, 4, 4, p, p, 1, p, p, 1, nul, nul, 0, 0, None), b"bad sizes"),
         (lib.uno_gelu_project_forward(p, p, nul, p, 1, 0, 5, None), b"bad sizes"),
         (lib.uno_gelu_project_backward(p, p, p, p, nul, nul, p, 1, 3, 5, None), b"null"),
@@ -82,9 +82,9 @@ def test_argument_errors_of_the_block_level_entry_points(libpath):
         assert rc < 0
     # messages are per call: check the last few individually
     assert lib.uno_gelu_pad(p, nul, p, 1, 4, 4, 3, 4, 0, None) < 0 and b"bad sizes" in lib.uno_last_error()
-    assert lib.uno_channel_mix(nul, p, nul, p, 2, 3, 4, 10, 0, 0, None) < 0 and b"null" in lib.uno_last_error()
+    assert lib.uno_channel_mix(nul, p, nul, p, 2, 3, 4, 10, 0, 0, 0, nul, None) < 0 and b"null" in lib.uno_last_error()
     # zero-sized problems are no-ops that succeed without touching the device
-    assert lib.uno_channel_mix(nul, nul, nul, nul, 0, 3, 4, 10, 0, 0, None) == 0
+    assert lib.uno_channel_mix(nul, nul, nul, nul, 0, 3, 4, 10, 0, 0, 0, nul, None) == 0
     assert lib.uno_gelu_pad(nul, nul, nul, 0, 4, 4, 5, 5, 0, None) == 0
     assert lib.uno_instnorm_forward(nul, nul, nul, nul, nul, nul, 0, 2, 7, 1e-5, 1, None) == 0
     assert lib.uno_channel_wgrad_ws_bytes(2, 64, 64, 1000) > 0 and lib.uno_gelu_project_bwd_ws_bytes(2, 64, 5000) % (4 * 65) == 0 and lib.uno_gelu_project_bwd_ws_bytes(2, 64, 5000) > 0

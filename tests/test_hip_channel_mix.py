@@ -137,3 +137,43 @@ def test_channel_mix_cat_equals_mix_of_cat():
     assert rel(y, y2.double()) < 2e-6
     for g, r in zip(got, ref):
         assert g.shape == r.shape and rel(g, r.double()) < 2e-5
+
+
+@pytest.mark.parametrize("B,Ci,Co,shape", [(2, 32, 64, (45, 41)), (3, 7, 5, (19,)), (1, 16, 130, (300,)), (2, 64, 64, (3,))])
+def test_gelu_channel_mix_matches_stock_sequence(B, Ci, Co, shape):
+    """y = W gelu(pre) + b with the GELU applied on read (K8 act_in, K9 act_x) and gelu'(pre) in the input-gradient epilogue,
+    against F.gelu -> channel mix in float64."""
+    from uno_amd.integral_operators import gelu_channel_mix
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Ci + Co)
+    pre = (1.5 * torch.randn(B, Ci, *shape, generator=g)).cuda().requires_grad_(True)
+    w = torch.randn(Co, Ci, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(Co, generator=g).cuda().requires_grad_(True)
+    y = gelu_channel_mix(pre, w, b)
+    gy = torch.randn_like(y)
+    got = torch.autograd.grad(y, (pre, w, b), gy)
+    pre2, w2, b2 = (t.detach().double().requires_grad_(True) for t in (pre, w, b))
+    y2 = torch.einsum("oc,bc...->bo...", w2, F.gelu(pre2)) + b2.view(1, -1, *([1] * len(shape)))
+    ref = torch.autograd.grad(y2, (pre2, w2, b2), gy.double())
+    assert rel(y, y2.detach()) < 2e-6
+    assert rel(got[0], ref[0]) < 2e-6
+    assert rel(got[1], ref[1]) < 2e-5 and rel(got[2], ref[2]) < 2e-5
+
+
+def test_channel_mix_cat_with_deferred_gelu():
+    from uno_amd.integral_operators import channel_mix_cat
+    import torch.nn.functional as F
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(24 + 40, 36).cuda()
+    a = (1.5 * torch.randn(3, 24, 19, 23, device="cuda")).requires_grad_(True)
+    b = torch.randn(3, 40, 19, 23, device="cuda", requires_grad=True)
+    y = channel_mix_cat([a, b], lin.weight, lin.bias, gelu_first=True)
+    gy = torch.randn_like(y)
+    got = torch.autograd.grad(y, (a, b, lin.weight, lin.bias), gy)
+    a2, b2 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    w2, c2 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    y2 = torch.einsum("oc,bchw->bohw", w2, torch.cat([F.gelu(a2), b2], dim=1)) + c2.view(1, -1, 1, 1)
+    ref = torch.autograd.grad(y2, (a2, b2, w2, c2), gy.double())
+    assert rel(y, y2.detach()) < 2e-6
+    for g_, r_ in zip(got, ref):
+        assert g_.shape == r_.shape and rel(g_, r_) < 2e-5

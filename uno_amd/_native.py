@@ -40,9 +40,9 @@ _SIGNATURES = {
     "uno_spectral_conv3d_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp), _fp] + [_i] * 12 + [_fp]),
     "uno_cdft_axis": (C.c_int, [_fp, _fp] + [_i] * 6 + [C.c_float, _i, _fp]),
     "uno_resample2d": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _fp]),
-    "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
+    "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
-    "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _fp]),
+    "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_gelu_project_forward": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
     "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
@@ -314,9 +314,10 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
     return out
 
 
-def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None):
+def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bool = False, dgelu_of=None):
     """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias;
-    out: accumulate into this (B, Co, P) tensor instead."""
+    out: accumulate into this (B, Co, P) tensor instead; act_in: x := gelu(x) as it is read; dgelu_of (B, Co, P): the
+    product is multiplied by gelu'(dgelu_of)."""
     _require(x, torch.float32, "x")
     _require(w, torch.float32, "weight")
     if bias is not None:
@@ -334,14 +335,19 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None):
     else:
         y = torch.empty((B, Co, P), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
+        if dgelu_of is not None:
+            _require(dgelu_of, torch.float32, "dgelu_of")
+            if tuple(dgelu_of.shape) != (B, Co, P):
+                raise RuntimeError(f"uno_amd: dgelu_of has shape {tuple(dgelu_of.shape)}, expected {(B, Co, P)}")
         rc = lib().uno_channel_mix(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y),
-                                   B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, _stream(x))
+                                   B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, 1 if act_in else 0,
+                                   _ptr(dgelu_of) if dgelu_of is not None else C.c_void_p(0), _stream(x))
     _check(rc, "uno_channel_mix")
     return y
 
 
-def channel_wgrad(gy, x, need_bias: bool = True):
-    """gy (B, Co, P), x (B, Ci, P) -> gw (Co, Ci), gb (Co) or None."""
+def channel_wgrad(gy, x, need_bias: bool = True, act_x: bool = False):
+    """gy (B, Co, P), x (B, Ci, P) -> gw (Co, Ci), gb (Co) or None; act_x: x := gelu(x) as it is read."""
     _require(gy, torch.float32, "grad_output")
     _require(x, torch.float32, "x")
     B, Co, P = gy.shape
@@ -354,7 +360,7 @@ def channel_wgrad(gy, x, need_bias: bool = True):
     with torch.cuda.device(x.device):
         ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, P)), dtype=torch.uint8, device=x.device)
         rc = L.uno_channel_wgrad(_ptr(gy), _ptr(x), _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws),
-                                 B, Ci, Co, P, _stream(x))
+                                 B, Ci, Co, P, 1 if act_x else 0, _stream(x))
     _check(rc, "uno_channel_wgrad")
     return gw, gb
 

@@ -299,11 +299,11 @@ int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, in
 }
 
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                    int transpose_w, int accumulate, void* stream) {
+                    int transpose_w, int accumulate, int act_in, const float* dgelu_of, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (B == 0 || P == 0) return 0;
     if (!x || !w || !y) { set_error("uno_channel_mix: null pointer"); return -1; }
-    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, (hipStream_t)stream);
+    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, (hipStream_t)stream);
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
@@ -312,7 +312,7 @@ long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
 }
 
 int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
-                      void* stream) {
+                      int act_x, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (!gw) { set_error("uno_channel_wgrad: null pointer"); return -1; }
     if (B == 0 || P == 0) {
@@ -321,7 +321,7 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
         return 0;
     }
     if (!gy || !x || !ws) { set_error("uno_channel_wgrad: null pointer"); return -1; }
-    return launch_channel_wgrad(gy, x, gw, gb, (float*)ws, B, Ci, Co, P, (hipStream_t)stream);
+    return launch_channel_wgrad(gy, x, gw, gb, (float*)ws, B, Ci, Co, P, act_x, (hipStream_t)stream);
 }
 
 int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,

@@ -34,6 +34,16 @@ __device__ __forceinline__ float4 load4_tail(const float* row, int px, int P) {
     return make_float4(t0, t1, t2, t3);
 }
 
+// exact-erf GELU (F.gelu default) and its derivative, for the fused forms: x := gelu(x) while a chunk goes to LDS
+// (`act_in`: the layer consumes the activation of a tensor that is kept pre-activation) and y := (W x) * gelu'(pre) in the
+// epilogue (`dgelu_of`: the input gradient of such a layer, handed back as the gradient of the pre-activation tensor)
+__device__ __forceinline__ float cm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float cm_dgelu(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    return fmaf(x, 0.39894228040143267794f * expf(-0.5f * x * x), cdf);
+}
+__device__ __forceinline__ float4 cm_gelu4(float4 v) { return make_float4(cm_gelu(v.x), cm_gelu(v.y), cm_gelu(v.z), cm_gelu(v.w)); }
+
 struct ChannelMixParams {
     const float* x;         // (B, Ci, P)
     const float* w;         // Wm(o, i) = w[o * w_so + i * w_si]
@@ -44,12 +54,13 @@ struct ChannelMixParams {
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
     int accumulate;         // y += instead of y =
+    const float* dgelu_of;  // nullptr, or (B, Co, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
 };
 
 // MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
 //         32-bit offsets from a uniform base - the per-element clamps and selects of the guarded path cost more
 //         VALU issue slots than the tile has MFMAs;  MODE 1: guarded 16-byte loads (P >= 4);  MODE 0: guarded scalars.
-template <int MODE, int PT>
+template <int MODE, int PT, bool ACT = false, bool DG = false>
 __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, float (*sX)[CM_KC * (PT + 16)], float (*sW)[CM_KC * CM_WS],
                                                  int p0, int o0, int b) {
     constexpr int XS = PT + 16;         // LDS row stride of the X chunk [KC][PT]: 4 consecutive rows hit disjoint bank groups
@@ -115,14 +126,14 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                *reinterpret_cast<float4*>(&sX[buf][(e / F4R) * XS + (e % F4R) * 4]) = rx[u];
+                *reinterpret_cast<float4*>(&sX[buf][(e / F4R) * XS + (e % F4R) * 4]) = ACT ? cm_gelu4(rx[u]) : rx[u];
             }
         } else {
             const float* r = reinterpret_cast<const float*>(rx);
 #pragma unroll
             for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
-                sX[buf][(e / PT) * XS + e % PT] = r[u];
+                sX[buf][(e / PT) * XS + e % PT] = ACT ? cm_gelu(r[u]) : r[u];
             }
         }
         if constexpr (MODE == 2) {
@@ -183,23 +194,29 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     *reinterpret_cast<float4*>(sO + (r16 & 7) * OS + 16 * mt + 4 * kk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
             }
             __syncthreads();
-            f4u old[4];
+            f4u old[4], pre[DG ? 4 : 1];
             float* dst[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
-                dst[it] = p.y + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                const size_t off = ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                dst[it] = p.y + off;
                 if (p.accumulate) old[it] = *reinterpret_cast<const f4u*>(dst[it]);
                 else old[it].v[0] = old[it].v[1] = old[it].v[2] = old[it].v[3] = 0.f;
+                if constexpr (DG) pre[it] = *reinterpret_cast<const f4u*>(p.dgelu_of + off);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = 2 * it + (lane >> 5);
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
                 const float bv = __shfl(bias_l, 8 * h + row);
+                float r4[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
                 f4u w4;
-                w4.v[0] = old[it].v[0] + (v.x + bv); w4.v[1] = old[it].v[1] + (v.y + bv);
-                w4.v[2] = old[it].v[2] + (v.z + bv); w4.v[3] = old[it].v[3] + (v.w + bv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (DG) r4[i] *= cm_dgelu(pre[it].v[i]);
+                    w4.v[i] = old[it].v[i] + r4[i];
+                }
                 *reinterpret_cast<f4u*>(dst[it]) = w4;
             }
             __syncthreads();
@@ -213,17 +230,20 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk;
+            const float* drow = DG ? p.dgelu_of + ((size_t)b * p.Co + o) * p.P : nullptr;
             if (MODE == 2 || px + 3 < p.P) {
-                f4u w4;
+                f4u w4, pre;
                 if (p.accumulate) w4 = *reinterpret_cast<const f4u*>(yrow + px);
                 else w4.v[0] = w4.v[1] = w4.v[2] = w4.v[3] = 0.f;
+                if constexpr (DG) pre = *reinterpret_cast<const f4u*>(drow + px);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w4.v[r] += acc[mt][r] + bv;
+                for (int r = 0; r < 4; ++r) w4.v[r] += (acc[mt][r] + bv) * (DG ? cm_dgelu(pre.v[r]) : 1.f);
                 *reinterpret_cast<f4u*>(yrow + px) = w4;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (px + r < p.P) yrow[px + r] = (p.accumulate ? yrow[px + r] : 0.f) + (acc[mt][r] + bv);
+                    if (px + r < p.P)
+                        yrow[px + r] = (p.accumulate ? yrow[px + r] : 0.f) + (acc[mt][r] + bv) * (DG ? cm_dgelu(drow[px + r]) : 1.f);
             }
         }
     }
@@ -237,7 +257,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 // stores) - the address unit (TA) was the busiest block of the CU at 63 %.
 // TINY: rows shorter than 4 pixels (scalar guarded path) - a kernel of its own so that its register needs do not set
 // the occupancy of the real one.  Also measured and dropped: two chunks in flight per workgroup (same time).
-template <int PT, bool TINY>
+template <int PT, bool TINY, bool ACT = false, bool DG = false>
 __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(ChannelMixParams p) {
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * (PT + 16)];
     __shared__ float sW[2][CM_KC * CM_WS];
@@ -248,10 +268,10 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
     if (tile >= p.ntile) return;
     const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
     if constexpr (TINY) {
-        channel_mix_tile<0, PT>(p, sX, sW, p0, o0, b);
+        channel_mix_tile<0, PT, ACT, DG>(p, sX, sW, p0, o0, b);
     } else {
-        if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT>(p, sX, sW, p0, o0, b);
-        else channel_mix_tile<1, PT>(p, sX, sW, p0, o0, b);
+        if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT, ACT, DG>(p, sX, sW, p0, o0, b);
+        else channel_mix_tile<1, PT, ACT, DG>(p, sX, sW, p0, o0, b);
     }
 }
 
@@ -375,15 +395,17 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
 }
 
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, hipStream_t s) {
+                       int transpose_w, int accumulate, int act_in, const float* dgelu_of, hipStream_t s) {
     ChannelMixParams p;
     p.accumulate = accumulate ? 1 : 0;
+    p.dgelu_of = dgelu_of;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
     // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
     p.w_so = transpose_w ? 1 : Ci;
     p.w_si = transpose_w ? Co : 1;
     constexpr int PT = CM_PT;
-    const bool wide = Co % 128 == 0 && P >= PT;
+    if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
+    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of;
     const long long npt = (P + PT - 1) / PT, ncot = wide ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
@@ -391,10 +413,20 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
-        ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel", 4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0)) + 4.0 * Ci * Co, s);
+        ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
+                       4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + (dgelu_of ? Co : 0)) + 4.0 * Ci * Co, s);
         if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
-        else if (P >= 4) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else {
+            const dim3 grid((unsigned)(8 * p.per_xcd), B);
+#define UNO_CM_LAUNCH(T) \
+            do { \
+                if (act_in) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, true, false>), grid, dim3(256), 0, s, p); \
+                else if (dgelu_of) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, true>), grid, dim3(256), 0, s, p); \
+                else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, false>), grid, dim3(256), 0, s, p); \
+            } while (0)
+            if (P >= 4) UNO_CM_LAUNCH(false); else UNO_CM_LAUNCH(true);
+#undef UNO_CM_LAUNCH
+        }
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_mix launch: %s", hipGetErrorString(e)); return -5; }
@@ -411,6 +443,7 @@ struct ChannelWgradParams {
     const float* x;         // (B, Ci, P)
     float* part;            // (nsplit, Co, Ci + 1) partial sums; column Ci holds the bias gradient
     int B, Ci, Co, P, nsplit;
+    int act_x;              // scalar kernel: x := gelu(x)
     long long span;         // pixels per split (informational)
 };
 
@@ -436,6 +469,7 @@ __global__ __launch_bounds__(256) void channel_wgrad_kernel(ChannelWgradParams p
             const int row = e >> 5, px = pp0 + (e & 31);
             rg[u] = (px < p.P && o0 + row < p.Co) ? gb[(size_t)(o0 + row) * p.P + px] : 0.f;
             rxv[u] = (px < p.P && i0 + row < p.Ci) ? xb[(size_t)(i0 + row) * p.P + px] : 0.f;
+            if (p.act_x) rxv[u] = cm_gelu(rxv[u]);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -496,6 +530,7 @@ constexpr int CWV_PK = 64;
 constexpr int CWV_S = CWV_PK + 4;       // 272-byte rows: 16-byte aligned for ds_write_b128; fragment reads hit banks 4 r16 + kk,
                                         // distinct over all 64 lanes (gfx950 LDS: 64 banks; a stride of 66 cost one conflict cycle per read)
 
+template <bool ACTX>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
 __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
     __shared__ __attribute__((aligned(16))) float sG[CW_T * CWV_S];
     __shared__ __attribute__((aligned(16))) float sXc[CW_T * CWV_S];
@@ -549,7 +584,9 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
-            const float4 g = shifted(rg[u], o0 + row < p.Co), v = shifted(rxv[u], i0 + row < p.Ci);
+            const float4 g = shifted(rg[u], o0 + row < p.Co);
+            float4 v = shifted(rxv[u], i0 + row < p.Ci);
+            if constexpr (ACTX) v = cm_gelu4(v);             // gelu(0) = 0: the zero fill survives
             *reinterpret_cast<float4*>(sG + row * CWV_S + c4) = g;
             *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = v;
             bs[u] += (g.x + g.y) + (g.z + g.w);
@@ -653,21 +690,23 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
 }
 
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
-                         hipStream_t s) {
+                         int act_x, hipStream_t s) {
     if ((long long)(Ci > Co ? Ci : Co) * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
         set_error("channel_wgrad: tensor too large (channels * pixels must stay below 2^29)");
         return -2;
     }
     ChannelWgradParams p;
-    p.gy = gy; p.x = x; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
+    p.gy = gy; p.x = x; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = act_x ? 1 : 0;
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     p.span = (long long)cps * pk;
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
     {
         ProfScope prof(pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel", 4.0 * B * (double)P * (Ci + Co), s);
-        if (pk == CWV_PK)
-            hipLaunchKernelGGL(channel_wgrad_vec_kernel, dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
+        if (pk == CWV_PK && act_x)
+            hipLaunchKernelGGL(channel_wgrad_vec_kernel<true>, dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
+        else if (pk == CWV_PK)
+            hipLaunchKernelGGL(channel_wgrad_vec_kernel<false>, dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
         else
             hipLaunchKernelGGL(channel_wgrad_kernel, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
     }

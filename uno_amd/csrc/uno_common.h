@@ -119,7 +119,7 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
                       const float* tile_w, int NP, int accumulate, hipStream_t s);
 int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, hipStream_t s);
+                       int transpose_w, int accumulate, int act_in, const float* dgelu_of, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s);
 int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s);
@@ -133,6 +133,6 @@ int launch_instnorm_bwd(const float* x, const float* gy, const float* gamma, con
                         float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, hipStream_t s);
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
-                         hipStream_t s);
+                         int act_x, hipStream_t s);
 
 }  // namespace uno

@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, gelu_pad2d, gelu_project
+from ..integral_operators import (OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, gelu_channel_mix, gelu_pad2d,
+                                  gelu_project)
 
 
 class UNO_9(nn.Module):
@@ -54,7 +55,8 @@ class UNO_9(nn.Module):
     def forward(self, x):
         S1, S2 = x.shape[1], x.shape[2]
         x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()   # (B, 3, S, S): tiny
-        lifted = channel_mix(F.gelu(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias)), self.fc0.weight, self.fc0.bias)
+        # lift: fc0(gelu(fc_n1(x))) with the intermediate kept pre-activation (GELU applied as fc0's kernels read it)
+        lifted = gelu_channel_mix(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias), self.fc0.weight, self.fc0.bias)
         scale = math.ceil(S2 / 85)
         margin = scale * self.padding
         lifted = gelu_pad2d(lifted, margin, margin)            # gelu, then pad the end of both axes
@@ -65,8 +67,13 @@ class UNO_9(nn.Module):
         c2 = self.conv2(c1, d1 // 4, d2 // 4)
         # skip connections: conv5 consumes cat([conv4 output, c0]) and fc1 cat([conv5 output, lifted]) from their two
         # sources; the concatenations are never built
-        c5 = channel_mix_cat([_block_cat(self.conv5, [self.conv4(c2, d1 // 2, d2 // 2), c0], d1, d2), lifted],
-                             self.fc1.weight, self.fc1.bias)
+        skip5 = [self.conv4(c2, d1 // 2, d2 // 2), c0]
+        if hasattr(self.conv5, "forward_cat") and self.conv5.non_lin and not self.conv5.normalize:
+            # conv5's GELU is deferred to its only consumer: fc1 applies it while reading the pre-activation tensor
+            c5 = channel_mix_cat([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True), lifted], self.fc1.weight, self.fc1.bias,
+                                 gelu_first=True)
+        else:
+            c5 = channel_mix_cat([_block_cat(self.conv5, skip5, d1, d2), lifted], self.fc1.weight, self.fc1.bias)
         out = gelu_project(c5, self.fc2.weight, self.fc2.bias)
         return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)
 
@@ -121,7 +128,7 @@ class UNO(nn.Module):
     def forward(self, x):
         S1, S2 = x.shape[1], x.shape[2]
         x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()
-        lifted = F.gelu(channel_mix(F.gelu(channel_mix(x, self.fc.weight, self.fc.bias)), self.fc0.weight, self.fc0.bias))
+        lifted = F.gelu(gelu_channel_mix(channel_mix(x, self.fc.weight, self.fc.bias), self.fc0.weight, self.fc0.bias))
         p = self.padding
         lifted = F.pad(lifted, [p, p, p, p])
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
@@ -180,7 +187,7 @@ class Uno3D_T20(nn.Module):
 
     def forward(self, x):
         x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 4, 1, 2, 3).contiguous()
-        lifted = F.gelu(channel_mix(F.gelu(channel_mix(x, self.fc.weight, self.fc.bias)), self.fc0.weight, self.fc0.bias))
+        lifted = F.gelu(gelu_channel_mix(channel_mix(x, self.fc.weight, self.fc.bias), self.fc0.weight, self.fc0.bias))
         self.padding = int(self.pad * 0.1 * lifted.shape[-1])
         lifted = F.pad(lifted, [self.padding, self.padding, 0, 0, 0, 0] if self.pad_both else [0, self.padding, 0, 0, 0, 0])
         d1, d2, d3 = lifted.shape[-3:]

@@ -120,18 +120,21 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
 
 
 class _ChannelMixCatFn(torch.autograd.Function):
-    """y[b] = W . cat(x1[b], x2[b]) + bias without the concatenation: W[:, :C1] . x1 writes y, W[:, C1:] . x2
-    accumulates into it; the input gradients come out as two contiguous tensors (no strided slices of a joint one)."""
+    """y[b] = W . cat(a1[b], x2[b]) + bias without the concatenation: W[:, :C1] . a1 writes y, W[:, C1:] . x2
+    accumulates into it; the input gradients come out as two contiguous tensors (no strided slices of a joint one).
+    gelu_first: a1 = gelu(x1) with x1 kept pre-activation - the GELU is applied as K8 / K9 read x1, and the input-gradient
+    call returns the gradient of x1 itself (its epilogue multiplies by gelu'(x1)): the activation tensor never exists."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias):
+    def forward(ctx, x1, x2, w, bias, gelu_first):
         x1, x2 = _plain(x1), _plain(x2)
         C1 = x1.shape[1]
         w1, w2 = w[:, :C1].contiguous(), w[:, C1:].contiguous()
-        y = _native.channel_mix(x1, w1, None if bias is None else _plain(bias))
+        y = _native.channel_mix(x1, w1, None if bias is None else _plain(bias), act_in=gelu_first)
         _native.channel_mix(x2, w2, None, out=y)
         ctx.save_for_backward(x1, x2, w1, w2)
         ctx.has_bias = bias is not None
+        ctx.gelu_first = gelu_first
         return y
 
     @staticmethod
@@ -139,27 +142,68 @@ class _ChannelMixCatFn(torch.autograd.Function):
     def backward(ctx, gy):
         x1, x2, w1, w2 = ctx.saved_tensors
         gy = _plain(gy)
-        g1 = _native.channel_mix(gy, w1, None, transpose_w=True) if ctx.needs_input_grad[0] else None
-        g2 = _native.channel_mix(gy, w2, None, transpose_w=True) if ctx.needs_input_grad[1] else None
+        g1 = g2 = None
+        if ctx.needs_input_grad[0]:
+            g1 = _native.channel_mix(gy, w1, None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
+        if ctx.needs_input_grad[1]:
+            g2 = _native.channel_mix(gy, w2, None, transpose_w=True)
         gw = gb = None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            gw1, gb = _native.channel_wgrad(gy, x1, need_bias=ctx.has_bias)
+            gw1, gb = _native.channel_wgrad(gy, x1, need_bias=ctx.has_bias, act_x=ctx.gelu_first)
             gw2, _ = _native.channel_wgrad(gy, x2, need_bias=False)
             gw = torch.cat([gw1, gw2], dim=1)
-        return g1, g2, gw, gb
+        return g1, g2, gw, gb, None
 
 
-def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_first: bool = False) -> torch.Tensor:
     """channel_mix(torch.cat(xs, dim=1), weight, bias) - the projection after a skip connection (reference
     darcy_flow_uno2d.py:122-127: `torch.cat([x_c5, x_fc0], dim=1)` then `fc1`) - without materialising the
-    concatenation when there are two float32 device tensors."""
+    concatenation when there are two float32 device tensors.  gelu_first: xs[0] is a PRE-activation tensor and stands
+    for gelu(xs[0]) (the block in front deferred its GELU to this consumer)."""
     if len(xs) == 2 and all(x.is_cuda and x.dtype == torch.float32 for x in xs) and weight.dtype == torch.float32:
         x1, x2 = xs
         B = x1.shape[0]
         w = weight.reshape(weight.shape[0], -1)
-        y = _ChannelMixCatFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias)
+        y = _ChannelMixCatFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias, bool(gelu_first))
         return y.view(B, w.shape[0], *x1.shape[2:])
-    return channel_mix(torch.cat(list(xs), dim=1), weight, bias)
+    xs = list(xs)
+    if gelu_first:
+        xs[0] = F.gelu(xs[0])
+    return channel_mix(torch.cat(xs, dim=1), weight, bias)
+
+
+class _GeluChannelMixFn(torch.autograd.Function):
+    """y[b] = W . gelu(pre[b]) + bias with `pre` kept pre-activation (the lift `fc0(F.gelu(fc_n1(x)))`, reference
+    darcy_flow_uno2d.py:98-101): GELU on read in K8 / K9, gelu'(pre) in the input-gradient epilogue."""
+
+    @staticmethod
+    def forward(ctx, pre, w, bias):
+        pre, w = _plain(pre), _plain(w)
+        y = _native.channel_mix(pre, w, None if bias is None else _plain(bias), act_in=True)
+        ctx.save_for_backward(pre, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        pre, w = ctx.saved_tensors
+        gy = _plain(gy)
+        g_pre = _native.channel_mix(gy, w, None, transpose_w=True, dgelu_of=pre) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _native.channel_wgrad(gy, pre, need_bias=ctx.has_bias, act_x=True)
+        return g_pre, gw, gb
+
+
+def gelu_channel_mix(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """channel_mix(F.gelu(pre), weight, bias) without the activation tensor (float32 device tensors)."""
+    B, Ci = pre.shape[0], pre.shape[1]
+    w = weight.reshape(weight.shape[0], Ci)
+    if pre.is_cuda and pre.dtype == torch.float32 and w.dtype == torch.float32:
+        y = _GeluChannelMixFn.apply(pre.reshape(B, Ci, -1), w, bias)
+        return y.view(B, w.shape[0], *pre.shape[2:])
+    return channel_mix(F.gelu(pre), weight, bias)
 
 
 class _GeluProjectFn(torch.autograd.Function):
@@ -490,9 +534,12 @@ class OperatorBlock_2D(nn.Module):
             out = F.gelu(out)
         return out
 
-    def forward_cat(self, xs, dim1=None, dim2=None):
+    def forward_cat(self, xs, dim1=None, dim2=None, defer_gelu=False):
         """self(torch.cat(xs, dim=1), dim1, dim2) for a skip connection (reference darcy_flow_uno2d.py:117-125) - two
-        float32 device tensors are consumed in place, the concatenation is never built."""
+        float32 device tensors are consumed in place, the concatenation is never built.  defer_gelu (blocks without
+        normalisation only): return the PRE-activation sum; the caller's consumer applies the GELU as it reads it."""
+        if defer_gelu and (self.normalize or not self.non_lin):
+            raise ValueError("defer_gelu needs a block with Non_Lin=True and Normalize=False")
         xs = list(xs)
         conv, w = self.conv, self.w
         d1, d2 = (dim1, dim2) if dim1 is not None else (w.dim1, w.dim2)
@@ -502,10 +549,14 @@ class OperatorBlock_2D(nn.Module):
                  and xs[0].shape[1] + xs[1].shape[1] == conv.in_channels and cdims == (d1, d2)
                  and w.conv.weight.dtype == torch.float32)
         if not fused:
+            if defer_gelu:
+                return self._branches(torch.cat(xs, dim=1), dim1, dim2)
             return self.forward(torch.cat(xs, dim=1), dim1, dim2)
         if dim1 is not None:
             conv.dim1, conv.dim2 = dim1, dim2
         out = _OperatorBlock2dCatFn.apply(xs[0], xs[1], conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2))
+        if defer_gelu:
+            return out
         if self.normalize:
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
         return F.gelu(out) if self.non_lin else out
