@@ -35,6 +35,10 @@ DFT_SHAPES = [
     (3, 16, 16, 4, 5), (2, 21, 18, 4, 5), (2, 23, 23, 11, 12), (1, 40, 44, 17, 20), (2, 85, 85, 12, 12),
     (1, 90, 90, 18, 18), (2, 111, 111, 8, 8), (1, 223, 223, 8, 8), (1, 64, 66, 32, 33), (2, 10, 14, 7, 5),
     (1, 7, 130, 3, 40), (1, 130, 6, 40, 4), (1, 1, 2, 1, 2), (1, 421, 421, 20, 20),
+    # many small images: the plane-batched kernels K1p / K3p (n_img >= 128, H*W <= 2048, W <= 64, 2 m1 <= 48, 2 m2 <= 32)
+    (130, 16, 16, 6, 6), (200, 64, 20, 16, 8), (129, 64, 13, 22, 5), (128, 48, 26, 14, 8), (160, 32, 32, 14, 14),
+    (128, 21, 18, 4, 5), (131, 23, 23, 11, 12), (128, 16, 15, 8, 8), (1100, 10, 14, 5, 5), (150, 4, 4, 2, 3),
+    (128, 5, 7, 2, 4), (128, 33, 61, 16, 16), (128, 32, 64, 16, 16), (4200, 64, 26, 22, 8), (128, 50, 40, 24, 3),
 ]
 
 
@@ -75,6 +79,24 @@ def test_dft2d_inverse_stage(shape, flags):
     U = np.einsum("bojl,jh->bohl", O.astype(np.complex128) * keep[None, None, :, None], Gh)
     ref = 0.25 * np.einsum("bohl,lw->bohw", U * c, Gw).real
     assert rel_err(got, ref) < TOL
+
+
+def test_plane_kernels_grouped_spectrum_layout():
+    """Two-source blocks at a coarse level: the plane-batched kernels honour the (group, stride, offset) spectrum layout."""
+    from uno_amd import _native
+    B, C1, C2, H, W, m1, m2 = 8, 24, 16, 16, 20, 6, 7
+    rng = np.random.default_rng(77)
+    x1 = rng.standard_normal((B, C1, H, W)).astype(np.float32)
+    x2 = rng.standard_normal((B, C2, H, W)).astype(np.float32)
+    spec = torch.zeros((B, C1 + C2, 2 * m1, m2), dtype=torch.complex64, device=dev())
+    _native.dft2d_forward(cu(x1), m1, m2, out=spec, channel_offset=0)
+    _native.dft2d_forward(cu(x2), m1, m2, out=spec, channel_offset=C1)
+    ref = so.truncated_rfft2_dense(np.concatenate([x1, x2], axis=1), m1, m2) * (H * W)
+    assert rel_err(spec.cpu().numpy(), ref) < TOL
+    whole = _native.dft2d_inverse(spec, H, W, scale=1.0).cpu().numpy()
+    part1 = _native.dft2d_inverse(spec, H, W, scale=1.0, channels=C1, channel_offset=0).cpu().numpy()
+    part2 = _native.dft2d_inverse(spec, H, W, scale=1.0, channels=C2, channel_offset=C1).cpu().numpy()
+    assert np.array_equal(part1, whole[:, :C1]) and np.array_equal(part2, whole[:, C1:])
 
 
 # ------------------------------------------------------------------ stage level: per-mode GEMMs

@@ -125,6 +125,9 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     p.twH = twiddle_table(H);
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
+    // many small images (3-D planes, coarse 2-D levels): plane-batched kernels (dft2d_plane.hip)
+    if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
+        return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);
     return inverse ? launch_dft2d_inv(p, s) : launch_dft2d_fwd(p, s);
 }
 

@@ -113,6 +113,10 @@ struct ProfScope {
 
 int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
+bool dft2d_fwd_plane_applies(const Dft2dParams& p);      // dft2d_plane.hip: many small images
+bool dft2d_inv_plane_applies(const Dft2dParams& p);
+int launch_dft2d_fwd_plane(const Dft2dParams& p, hipStream_t s);
+int launch_dft2d_inv_plane(const Dft2dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
