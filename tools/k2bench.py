@@ -1,0 +1,35 @@
+"""K2 (per-mode complex GEMM) timing for the layer shapes of the three models: python tools/k2bench.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from uno_amd import _native
+dev = torch.device("cuda:0")
+SHAPES = [  # B, Ci, Co, modes per corner, corners, label
+    (16, 64, 128, 18 * 18, 2, "darcy conv1"), (16, 128, 256, 64, 2, "darcy conv2"), (16, 256, 256, 64, 2, "darcy conv3"),
+    (16, 256, 64, 18 * 18, 2, "darcy conv5"), (16, 64, 64, 400, 2, "C2 block"),
+    (32, 32, 48, 22 * 22, 2, "ns2d L1"), (32, 48, 96, 14 * 14, 2, "ns2d L2"), (32, 96, 192, 36, 2, "ns2d L3"),
+    (32, 192, 192, 36, 2, "ns2d L4"), (32, 192, 48, 14 * 14, 2, "ns2d L6"),
+    (8, 32, 32, 16 * 16 * 8, 4, "C4 block"),
+]
+def timeit(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+for B, Ci, Co, Mc, nc, label in SHAPES:
+    x = torch.randn(B, Ci, nc, Mc, dtype=torch.cfloat, device=dev)
+    go = torch.randn(B, Co, nc, Mc, dtype=torch.cfloat, device=dev)
+    ws = [torch.randn(Ci, Co, Mc, dtype=torch.cfloat, device=dev) for _ in range(nc)]
+    t0 = timeit(lambda: _native.mode_mix(x, ws, 0))
+    t1 = timeit(lambda: _native.mode_mix(go, ws, 1))
+    t2 = timeit(lambda: _native.mode_wgrad(x, go, (Ci, Co, Mc), nc))
+    wb = 8.0 * Ci * Co * Mc * nc
+    ab = 8.0 * B * (Ci + Co) * Mc * nc
+    print(f"{label:12s} B={B:2d} {Ci:3d}->{Co:3d} modes {nc}x{Mc:5d}: fwd {t0:6.1f} dgrad {t1:6.1f} wgrad {t2:6.1f} us   "
+          f"(weights {wb/1e6:5.1f} MB, act {ab/1e6:5.1f} MB -> {(wb+ab)/t0/1e6:5.0f} GB/s fwd)")

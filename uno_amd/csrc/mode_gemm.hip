@@ -21,13 +21,17 @@
 
 namespace uno {
 
-constexpr int QC = 16;          // modes per workgroup
 constexpr int KC = 8;           // reduction chunk staged in LDS
-constexpr int PLANE = KC * 16 + 4;      // floats per (mode) plane; +4 breaks the power-of-two stride on the transposing writes
-constexpr int TILE_ELEMS = 16 * KC * QC;        // complex elements of one operand chunk = 2048
-constexpr int EPT = TILE_ELEMS / 256;           // elements per thread per operand = 8
 
+// QC = modes per workgroup: 16 (128-byte runs along the mode axis) or 8 (64-byte runs, twice the workgroups: layers with few
+// modes and many channels - 2 x 64 modes x 256 x 256 channels - give only 128 workgroups of 16 modes, and a workgroup's phases
+// (stage to LDS, issue loads, multiply) do not overlap with one wave per SIMD: the time was the sum of the three)
+template <int QC>
 __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
+    constexpr int TILE_ELEMS = 16 * KC * QC;        // complex elements of one operand chunk
+    constexpr int EPT = TILE_ELEMS / 256;           // elements per thread per operand: 8 / 4
+    constexpr int KSTEP = 16 / QC;                  // k rows covered by one pass of the 256 threads: 1 / 2
+    constexpr int PLANE = KC * 16 + 64 / QC;        // floats per (mode) plane; the pad makes the transposing writes conflict-free (lane -> bank 4 q + x / 8 q + x)
     // [operand A|B][re|im][QC][PLANE] floats; reused as the [16 m][16 n][QC] c64 output tile
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * QC * PLANE > 16 * 16 * (QC + 1) * 2 ? 2 * 2 * QC * PLANE : 16 * 16 * (QC + 1) * 2];
     float* sA = sm;
@@ -49,17 +53,18 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     const float sgnB = p.B.conj ? -1.f : 1.f;
 
     // staging map: element e = tid + 256 * u  ->  (row = e / QC, q = e % QC); A rows = (k, m), B rows = (k, n).  With 256 threads
-    // and QC = 16 this is k-local = u, x = tid / 16, q = tid % 16: a thread walks K with a fixed (x, q), so its addresses are
-    // one base per operand plus u * stride (computing the general form per load cost 20-40 integer instructions each)
+    // this is q = tid % QC, x = (tid / QC) % 16, k-local = KSTEP * u + tid / (16 QC): a thread walks K with a fixed (x, q), so
+    // its addresses are one base per operand plus k * stride (computing the general form per load cost 20-40 integer
+    // instructions each)
     float2 ra[EPT], rb[EPT];
-    const int q_t = tid & (QC - 1), x_t = tid >> 4;
+    const int q_t = tid & (QC - 1), x_t = (tid / QC) & 15, kb_t = tid / (16 * QC);
     const bool okA = q_t < nmodes && m0 + x_t < p.M, okB = q_t < nmodes && n0 + x_t < p.N;
     const float2* pA = Ab + (okA ? (long long)(m0 + x_t) * p.A.s0 + q_t : 0);
     const float2* pB = Bb + (okB ? (long long)(n0 + x_t) * p.B.s1 + q_t : 0);
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
-            const int k = min(k0 + u, p.K - 1);                 // clamped address: unconditional loads; the zero-fill of invalid
+            const int k = min(k0 + KSTEP * u + kb_t, p.K - 1);  // clamped address: unconditional loads; the zero-fill of invalid
             ra[u] = pA[(long long)k * p.A.s1];                  // entries happens on the way to LDS, after the MFMA block
             rb[u] = pB[(long long)k * p.B.s0];                  // (masking here would consume the registers at once)
         }
@@ -67,10 +72,8 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     auto store_chunk = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
-            const int e = tid + 256 * u;
-            const int q = e & (QC - 1), row = e >> 4;
-            const int o = q * PLANE + row;                  // row = kl * 16 + x
-            const bool kv = k0 + u < p.K;
+            const int o = q_t * PLANE + (KSTEP * u + kb_t) * 16 + x_t;     // row = k-local * 16 + x
+            const bool kv = k0 + KSTEP * u + kb_t < p.K;
             const float2 va = (kv && okA) ? ra[u] : make_float2(0.f, 0.f);
             const float2 vb = (kv && okB) ? rb[u] : make_float2(0.f, 0.f);
             sA[o] = va.x; sA[QC * PLANE + o] = sgnA * va.y;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     __syncthreads();
     float2* Ob = p.out[corner] + q0;
     for (int e = tid; e < 16 * 16 * QC; e += 256) {
-        const int q = e & (QC - 1), mn = e >> 4;
+        const int q = e & (QC - 1), mn = e / QC;
         const int m = mn >> 4, n = mn & 15;
         if (q < nmodes && m0 + m < p.M && n0 + n < p.N)
             Ob[(long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q] = sO[mn * (QC + 1) + q];
@@ -132,13 +135,19 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         set_error("mode_gemm: bad sizes M=%d N=%d K=%d corners=%d modes=%d", p.M, p.N, p.K, p.ncorner, p.Mc);
         return -2;
     }
-    const int nq = (p.Mc + QC - 1) / QC;
+    const int tiles = ((p.N + 15) / 16) * ((p.M + 15) / 16);
+    // under two workgroups per CU and a long K loop: halve the mode chunk (measured, tools/k2bench.py: 256 -> 256 channels x 2 x 64
+    // modes 53 -> 36 us, 192 -> 192 x 2 x 36 modes 42 -> 28 us; with K <= 64 the 64-byte runs cost more than the extra workgroups give)
+    const bool narrow = (long long)p.ncorner * ((p.Mc + 15) / 16) * tiles < 512 && p.K >= 96;
+    const int qc = narrow ? 8 : 16;
+    const int nq = (p.Mc + qc - 1) / qc;
     dim3 grid(p.ncorner * nq, (p.N + 15) / 16, (p.M + 15) / 16);
     {
         // each operand counted once: A (M x K), B (K x N), out (M x N) complex64 per mode
         const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
         ProfScope prof("uno::mode_gemm_kernel", per_mode * p.ncorner * p.Mc, s);
-        hipLaunchKernelGGL(mode_gemm_kernel, grid, dim3(256), 0, s, p);
+        if (narrow) hipLaunchKernelGGL(mode_gemm_kernel<8>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(mode_gemm_kernel<16>, grid, dim3(256), 0, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }
