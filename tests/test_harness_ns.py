@@ -77,3 +77,31 @@ def test_ns3d_gpu_product():
     # InstanceNorm3d runs on the K13 kernel (it was MIOpen's batch norm, 1e-3 / 2e-2 then); what remains is rocFFT vs
     # pocketfft inside pointwise_op_3D
     _ns3d(None, torch.device("cuda:0"), 1e-4, 2e-3)
+
+
+@pytest.mark.gpu
+def test_graphed_step_equals_eager_step():
+    """harness.GraphedStep: forward + loss + backward replayed from a HIP graph give the eager step's loss, gradients and
+    updated parameters bit for bit (every kernel is deterministic), for two different batches through one capture."""
+    from uno_amd.harness import ComplexAdam, GraphedStep
+    dev = torch.device("cuda:0")
+    def make():
+        torch.manual_seed(5)
+        m = UNO(14, 4).to(dev)
+        return m, ComplexAdam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(2, 64, 64, 10, generator=g).to(dev), torch.randn(2, 64, 64, 3, generator=g).to(dev)) for _ in range(2)]
+    me, oe = make()
+    mg, og = make()
+    gs = GraphedStep(mg, og, lambda a, b: ns2d_rollout_loss(mg, a, b, T_f=3, step=1), batches[0])
+    for xx, yy in batches:
+        oe.zero_grad(set_to_none=True)
+        le = ns2d_rollout_loss(me, xx, yy, T_f=3, step=1)
+        le.backward()
+        ge = {k: p.grad.clone() for k, p in me.named_parameters()}
+        oe.step()
+        lg = gs.step(xx, yy)
+        assert float(lg) == float(le)
+        for (k, pe), (_, pg) in zip(me.named_parameters(), mg.named_parameters()):
+            assert torch.equal(ge[k], pg.grad), k
+            assert torch.equal(pe, pg), k

@@ -4,18 +4,27 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from uno_amd.harness import UNO, Uno3D_T20, ComplexAdam, ns2d_rollout_loss, ns3d_loss
+from uno_amd.harness import UNO, Uno3D_T20, ComplexAdam, GraphedStep, ns2d_rollout_loss, ns3d_loss
 dev = torch.device("cuda:0")
 
 
-def run(name, model, closure, samples, steps=5, warmup=2):
+GRAPH = "--graph" in sys.argv       # forward + backward replayed from a HIP graph (harness.GraphedStep)
+
+
+def run(name, model, closure, samples, steps=5, warmup=2, inputs=()):
     opt = ComplexAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = closure()
-        loss.backward()
-        opt.step()
-        return loss
+    if GRAPH:
+        gs = GraphedStep(model, opt, closure, inputs)
+        name += " [HIP graph]"
+        def step():
+            return gs.step(*inputs)
+    else:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = closure(*inputs)
+            loss.backward()
+            opt.step()
+            return loss
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -30,11 +39,11 @@ def run(name, model, closure, samples, steps=5, warmup=2):
 torch.manual_seed(0)
 m = UNO(14, 32).to(dev)
 xx = torch.randn(32, 64, 64, 10, device=dev); yy = torch.randn(32, 64, 64, 40, device=dev)
-run("C3 NS-2D UNO(14,32) 64^2 B=32 T_f=40", m, lambda: ns2d_rollout_loss(m, xx, yy, T_f=40, step=1), 32)
+run("C3 NS-2D UNO(14,32) 64^2 B=32 T_f=40", m, lambda a, b: ns2d_rollout_loss(m, a, b, T_f=40, step=1), 32, inputs=(xx, yy))
 del m
 for w in (8, 32):
     torch.manual_seed(0)
     m3 = Uno3D_T20(6, w, pad=3).to(dev)
     x = torch.randn(8, 64, 64, 10, 1, device=dev); y = torch.randn(8, 64, 64, 20, device=dev)
-    run(f"C4 NS-3D Uno3D_T20(6,{w},pad=3) 64x64x10 B=8", m3, lambda: ns3d_loss(m3, x, y), 8)
+    run(f"C4 NS-3D Uno3D_T20(6,{w},pad=3) 64x64x10 B=8", m3, lambda a, b: ns3d_loss(m3, a, b), 8, inputs=(x, y))
     del m3

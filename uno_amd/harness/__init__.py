@@ -5,4 +5,4 @@ re-implementation of the reference's training scripts."""
 from .models import UNO, UNO_9, Uno3D_T20  # noqa: F401
 from .optim import ComplexAdam  # noqa: F401
 from .losses import lp_loss_rel_sum  # noqa: F401
-from .train import DarcyTrainer, ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch  # noqa: F401
+from .train import DarcyTrainer, GraphedStep, ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch  # noqa: F401

@@ -159,6 +159,47 @@ def ns3d_loss(model, x, y):
     return lp_loss_rel_sum(out.reshape(B, -1), y.reshape(B, -1))
 
 
+class GraphedStep:
+    """Forward + loss + backward of one training step captured ONCE into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm)
+    and replayed per step; the optimiser update stays eager (its bias correction takes the step count as a kernel argument).
+
+    For launch-bound steps: the NS-2D roll-out (reference ns_train_2d.py:46-68) issues ~7400 kernels of 5-40 us per step and
+    the host needs ~95 ms to enqueue them - as long as the device needs to run them.  A replay has no per-launch host work.
+    Every kernel of this package launches on torch's current stream and allocates through torch's caching allocator, so
+    the capture sees all of them (including the event fork / join onto the spectral backward's side stream); one-time set-up
+    (twiddle tables, resampling tables, side streams) happens in the eager warm-up steps that precede the capture.
+
+        gs = GraphedStep(model, opt, lambda xx, yy: ns2d_rollout_loss(model, xx, yy, 40), (xx0, yy0))
+        loss = gs.step(xx, yy)        # device tensor, no host synchronisation
+    """
+
+    def __init__(self, model, opt, loss_fn, example_inputs, warmup: int = 2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs the GPU (HIP graph capture)")
+        self.model, self.opt, self.loss_fn = model, opt, loss_fn
+        self.static_in = tuple(t.clone() for t in example_inputs)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                   # eager warm-up off the default stream, as capture requires
+            for _ in range(warmup):
+                opt.zero_grad(set_to_none=True)
+                loss_fn(*self.static_in).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)                 # .grad tensors are created inside the capture: static across replays
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = loss_fn(*self.static_in)
+            self.static_loss.backward()
+
+    def step(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()                             # gradients are overwritten by the captured backward
+        self.opt.step()
+        return self.static_loss
+
+
 class DarcyTrainer:
     """model + ComplexAdam + flat-gradient data parallelism.  step(a, u) runs forward, relative-L2 loss,
     backward, gradient all-reduce and the optimiser update; it returns the (device) loss tensor and
