@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 2
+#define UNO_SPECTRAL_ABI_VERSION 3
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -54,6 +54,19 @@ int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const flo
                                  const float* w2, float* gx, float* gw1, float* gw2, void* ws,
                                  int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1,
                                  int m2, void* stream);
+
+/* Mixed-precision form of the two entry points above (BASELINE.json config 5: bf16 activations, f32 accumulation; the
+ * reference itself raises on bf16 input, so this is an opt-in extension of integral_operators.py:181-207, not a replacement):
+ * x / y and gy / gx are bfloat16 (same shapes, contiguous), read and written as such by the pruned DFT kernels (8-byte
+ * loads / stores of four values, << 16 on load, round-to-nearest-even on store); weights, the truncated spectrum, every
+ * accumulation and the weight gradients stay f32 / c64.  Half-precision weight STORAGE is the caller's cast. */
+int uno_spectral_conv2d_forward_bf16(const void* x, const float* w1, const float* w2, void* y,
+                                     float* xtrunc, void* ws, int B, int Ci, int Co, int H, int W,
+                                     int Ho, int Wo, int m1, int m2, void* stream);
+int uno_spectral_conv2d_backward_bf16(const void* gy, const float* xtrunc, const float* w1,
+                                      const float* w2, void* gx, float* gw1, float* gw2, void* ws,
+                                      int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1,
+                                      int m2, void* stream);
 
 /* SpectralConv3d_Uno.forward - reference integral_operators.py:385-427
  *   x (B, Ci, H, W, T) f32;  w[0..3] = weights1..4 (Ci, Co, m1, m2, m3) c64 in the reference's corner
@@ -87,6 +100,12 @@ int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W,
 /* Pruned inverse DFT: images[h][w] = Re sum_{j,l} scale * c_l * keep_j * spec[j][l] e^{+2 pi i (...)}. */
 int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2,
                       float scale, int hermitian_cols, int mask_overlap, void* stream);
+
+/* The two transforms with bfloat16 images (the stages of uno_spectral_conv2d_*_bf16); spectra are c64 as above. */
+int uno_dft2d_forward_bf16(const void* images, float* spec, int n_img, int H, int W, int m1, int m2,
+                           float scale, int hermitian_cols, int mask_overlap, void* stream);
+int uno_dft2d_inverse_bf16(const float* spec, void* images, int n_img, int H, int W, int m1, int m2,
+                           float scale, int hermitian_cols, int mask_overlap, void* stream);
 
 /* The same transforms with the spectra of a (B, group) batch of images placed at channels [offset, offset + group) of a
  * (B, stride, 2*m1, m2) spectrum tensor (image i <-> spectrum (i / group) * stride + offset + i % group): lets an

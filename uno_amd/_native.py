@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNO_AMD_LIB") or os.path.join(_HERE, "lib", "libuno_spectral.so")   # env override: developer A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _lock = threading.Lock()
@@ -28,7 +28,11 @@ _SIGNATURES = {
     "uno_spectral_conv2d_bwd_ws_bytes": (C.c_longlong, [_i] * 5),
     "uno_spectral_conv2d_forward": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
     "uno_spectral_conv2d_backward": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
+    "uno_spectral_conv2d_forward_bf16": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
+    "uno_spectral_conv2d_backward_bf16": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
     "uno_dft2d_forward": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_dft2d_forward_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_dft2d_inverse_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_forward_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
     "uno_dft2d_inverse_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
@@ -104,9 +108,16 @@ def _require(t: torch.Tensor, dtype, name: str):
         raise RuntimeError(f"uno_amd: {name} must be contiguous")
 
 
+def _act_dtype(t, name):
+    """f32, or bf16 for the mixed-precision entry points (activations bf16, everything else f32 / c64)."""
+    bf16 = t.dtype == torch.bfloat16
+    _require(t, torch.bfloat16 if bf16 else torch.float32, name)
+    return bf16
+
+
 def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
-    """-> (y (B,Co,Ho,Wo) f32, xtrunc (B,Ci,2*m1,m2) c64)."""
-    _require(x, torch.float32, "x")
+    """-> (y (B,Co,Ho,Wo) in x's dtype (f32 | bf16), xtrunc (B,Ci,2*m1,m2) c64)."""
+    bf16 = _act_dtype(x, "x")
     _require(w1, torch.complex64, "weights1")
     _require(w2, torch.complex64, "weights2")
     B, Ci, H, W = x.shape
@@ -115,18 +126,19 @@ def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
         raise RuntimeError(f"uno_amd: weight shapes {tuple(w1.shape)} / {tuple(w2.shape)} do not match input channels {Ci}")
     L = lib()
     with torch.cuda.device(x.device):
-        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
         xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x.device)
         ws = torch.empty(max(1, L.uno_spectral_conv2d_fwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=x.device)
-        rc = L.uno_spectral_conv2d_forward(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws),
+        fn = L.uno_spectral_conv2d_forward_bf16 if bf16 else L.uno_spectral_conv2d_forward
+        rc = fn(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws),
                                            B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(x))
     _check(rc, "uno_spectral_conv2d_forward")
     return y, xt
 
 
 def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_gw=True):
-    """-> (gx or None, gw1 or None, gw2 or None)."""
-    _require(gy, torch.float32, "grad_output")
+    """-> (gx or None (gy's dtype: f32 | bf16), gw1 or None, gw2 or None (c64))."""
+    bf16 = _act_dtype(gy, "grad_output")
     _require(xt, torch.complex64, "xtrunc")
     _require(w1, torch.complex64, "weights1")
     _require(w2, torch.complex64, "weights2")
@@ -136,12 +148,13 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
         raise RuntimeError("uno_amd: grad_output channels do not match the weights")
     L = lib()
     with torch.cuda.device(gy.device):
-        gx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=gy.device) if need_gx else None
+        gx = torch.empty((B, Ci, H, W), dtype=gy.dtype, device=gy.device) if need_gx else None
         gw1 = torch.empty_like(w1) if need_gw else None
         gw2 = torch.empty_like(w2) if need_gw else None
         ws = torch.empty(max(1, L.uno_spectral_conv2d_bwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=gy.device)
         null = C.c_void_p(0)
-        rc = L.uno_spectral_conv2d_backward(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2),
+        fn = L.uno_spectral_conv2d_backward_bf16 if bf16 else L.uno_spectral_conv2d_backward
+        rc = fn(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2),
                                             _ptr(gx) if need_gx else null,
                                             _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
                                             _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(gy))
@@ -151,8 +164,10 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
 
 def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=False, out=None, channel_offset=0):
     """images (..., H, W) f32 -> spectra (..., 2*m1, m2) c64.  With `out` (B, Ctot, 2*m1, m2) and images (B, C1, H, W) the
-    spectra go to channels [channel_offset, channel_offset + C1) of `out`."""
-    _require(images, torch.float32, "images")
+    spectra go to channels [channel_offset, channel_offset + C1) of `out`.  bf16 images: plain form only."""
+    bf16 = _act_dtype(images, "images")
+    if bf16 and out is not None:
+        raise RuntimeError("uno_amd: the grouped spectrum layout takes float32 images")
     *lead, H, W = images.shape
     n = 1
     for d in lead:
@@ -160,8 +175,8 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
     if out is None:
         spec = torch.empty((*lead, 2 * m1, m2), dtype=torch.complex64, device=images.device)
         with torch.cuda.device(images.device):
-            rc = lib().uno_dft2d_forward(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols),
-                                         int(mask_overlap), _stream(images))
+            fn = lib().uno_dft2d_forward_bf16 if bf16 else lib().uno_dft2d_forward
+            rc = fn(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(images))
         _check(rc, "uno_dft2d_forward")
         return spec
     _require(out, torch.complex64, "out")
@@ -175,8 +190,9 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
     return out
 
 
-def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True, channels=None, channel_offset=0):
-    """spectra (..., 2*m1, m2) c64 -> images (..., H, W) f32.  With `channels` = C1 and spec (B, Ctot, 2*m1, m2) only the
+def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True, channels=None, channel_offset=0,
+                  dtype=torch.float32):
+    """spectra (..., 2*m1, m2) c64 -> images (..., H, W) f32 (or bf16 with dtype=torch.bfloat16, plain form only).  With `channels` = C1 and spec (B, Ctot, 2*m1, m2) only the
     channels [channel_offset, channel_offset + C1) are transformed -> (B, C1, H, W)."""
     _require(spec, torch.complex64, "spec")
     *lead, r2, m2 = spec.shape
@@ -185,12 +201,16 @@ def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True,
         n = 1
         for d in lead:
             n *= d
-        img = torch.empty((*lead, H, W), dtype=torch.float32, device=spec.device)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("uno_amd: images are float32 or bfloat16")
+        img = torch.empty((*lead, H, W), dtype=dtype, device=spec.device)
         with torch.cuda.device(spec.device):
-            rc = lib().uno_dft2d_inverse(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols),
-                                         int(mask_overlap), _stream(spec))
+            fn = lib().uno_dft2d_inverse_bf16 if dtype == torch.bfloat16 else lib().uno_dft2d_inverse
+            rc = fn(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(spec))
         _check(rc, "uno_dft2d_inverse")
         return img
+    if dtype != torch.float32:
+        raise RuntimeError("uno_amd: the grouped spectrum layout produces float32 images")
     if spec.dim() != 4 or channel_offset < 0 or channels < 1 or channel_offset + channels > spec.shape[1]:
         raise RuntimeError("uno_amd: spec must be (B, Ctot, 2*m1, m2) holding the requested channel range")
     B = spec.shape[0]

@@ -105,7 +105,7 @@ static int check_modes2d(const char* who, int H, int W, int Ho, int Wo, int m1, 
 }
 
 static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, int W, int m1, int m2, float scale,
-                 int herm, int mask, hipStream_t s, int sp_group = 0, int sp_stride = 0, int sp_offset = 0) {
+                 int herm, int mask, hipStream_t s, int sp_group = 0, int sp_stride = 0, int sp_offset = 0, int bf16 = 0) {
     const char* who = inverse ? "uno_dft2d_inverse" : "uno_dft2d_forward";
     if (n_img < 0) { set_error("%s: negative image count", who); return -1; }
     if (n_img > 0 && (!in || !out)) { set_error("%s: null pointer", who); return -1; }
@@ -113,7 +113,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     if (n_img == 0) return 0;
     Dft2dParams p;
     p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
-    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0;
+    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0;
     if (sp_group <= 0) { sp_group = n_img; sp_stride = 0; sp_offset = 0; }          // plain layout: spectrum i of image i
     if (sp_offset < 0 || sp_stride < sp_offset + sp_group || n_img % sp_group) {
         if (!(sp_stride == 0 && sp_offset == 0 && sp_group == n_img)) {
@@ -257,6 +257,18 @@ int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W,
 int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale,
                       int hermitian_cols, int mask_overlap, void* stream) {
     return dft2d(true, spec, images, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream);
+}
+
+int uno_dft2d_forward_bf16(const void* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
+                           int hermitian_cols, int mask_overlap, void* stream) {
+    return dft2d(false, static_cast<const float*>(images), spec, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap,
+                 (hipStream_t)stream, 0, 0, 0, 1);
+}
+
+int uno_dft2d_inverse_bf16(const float* spec, void* images, int n_img, int H, int W, int m1, int m2, float scale,
+                           int hermitian_cols, int mask_overlap, void* stream) {
+    return dft2d(true, spec, static_cast<float*>(images), n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap,
+                 (hipStream_t)stream, 0, 0, 0, 1);
 }
 
 int uno_dft2d_forward_grouped(const float* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
@@ -492,8 +504,8 @@ int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const flo
     return 0;
 }
 
-int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
-                                int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
+static int spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
+                                   int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream, int bf16) {
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_forward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
     if (int rc = check_modes2d("uno_spectral_conv2d_forward", H, W, Ho, Wo, m1, m2)) return rc;
     if (B == 0) return 0;           // empty batch: nothing to do (empty tensors carry null pointers)
@@ -501,17 +513,28 @@ int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2
     hipStream_t s = (hipStream_t)stream;
     float* O = static_cast<float*>(ws);
     // rfft2(x, norm="forward") restricted to the two corners            (reference :187)
-    if (int rc = dft2d(false, x, xtrunc, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s)) return rc;
+    if (int rc = dft2d(false, x, xtrunc, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s, 0, 0, 0, bf16)) return rc;
     // einsum("bixy,ioxy->boxy") with weights1 / weights2                  (reference :198-203)
     const float* wv[2] = {w1, w2};
     if (int rc = uno_mode_mix(xtrunc, wv, O, 0, B, Ci, Co, 2, m1 * m2, stream)) return rc;
     // irfft2(out_ft, s=(Ho, Wo), norm="forward"), later-wins on overlapping rows (reference :190-206)
-    return dft2d(true, O, y, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s);
+    return dft2d(true, O, y, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s, 0, 0, 0, bf16);
 }
 
-int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
-                                 float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
-                                 int m1, int m2, void* stream) {
+int uno_spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
+                                int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
+    return spectral_conv2d_forward(x, w1, w2, y, xtrunc, ws, B, Ci, Co, H, W, Ho, Wo, m1, m2, stream, 0);
+}
+
+int uno_spectral_conv2d_forward_bf16(const void* x, const float* w1, const float* w2, void* y, float* xtrunc, void* ws,
+                                     int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
+    return spectral_conv2d_forward(static_cast<const float*>(x), w1, w2, static_cast<float*>(y), xtrunc, ws, B, Ci, Co, H, W, Ho, Wo,
+                                   m1, m2, stream, 1);
+}
+
+static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
+                                    float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                    int m1, int m2, void* stream, int bf16) {
     if (B > 0 && (!gy || !xtrunc || !w1 || !w2 || !ws)) { set_error("uno_spectral_conv2d_backward: null pointer"); return -1; }
     if ((gw1 == nullptr) != (gw2 == nullptr)) { set_error("uno_spectral_conv2d_backward: gw1/gw2 must both be given or both be NULL"); return -1; }
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_backward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
@@ -529,7 +552,7 @@ int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const flo
         return 0;
     }
     // gO = c (.) keep (.) DFT_trunc(gy)                                   (adjoint of irfft2 + CopySlices)
-    if (int rc = dft2d(false, gy, gO, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s)) return rc;
+    if (int rc = dft2d(false, gy, gO, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s, 0, 0, 0, bf16)) return rc;
     // The weight gradient only shares gO with the input-gradient chain: it runs on the side stream next to the
     // (under-filled) input-gradient GEMM and the store-bound inverse DFT.
     SideStream* side = (gw1 && gx) ? side_stream_of_current_device() : nullptr;
@@ -550,7 +573,7 @@ int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const flo
         const float* wv[2] = {w1, w2};
         rc_x = uno_mode_mix(gO, wv, gX, 1, B, Ci, Co, 2, m1 * m2, stream);
         // gx = 1/(H W) Re iDFT_trunc(gX)                                   (adjoint of rfft2(norm="forward"))
-        if (rc_x == 0) rc_x = dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s);
+        if (rc_x == 0) rc_x = dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s, 0, 0, 0, bf16);
     }
     if (side) {
         const bool joined = hipEventRecord(side->join_ev, side->s) == hipSuccess && hipStreamWaitEvent(s, side->join_ev, 0) == hipSuccess;
@@ -558,6 +581,19 @@ int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const flo
         if (!joined) { set_error("uno_spectral_conv2d_backward: side-stream join failed"); return -5; }
     }
     return rc_w ? rc_w : rc_x;
+}
+
+int uno_spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
+                                 float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                 int m1, int m2, void* stream) {
+    return spectral_conv2d_backward(gy, xtrunc, w1, w2, gx, gw1, gw2, ws, B, Ci, Co, H, W, Ho, Wo, m1, m2, stream, 0);
+}
+
+int uno_spectral_conv2d_backward_bf16(const void* gy, const float* xtrunc, const float* w1, const float* w2, void* gx,
+                                      float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                      int m1, int m2, void* stream) {
+    return spectral_conv2d_backward(static_cast<const float*>(gy), xtrunc, w1, w2, static_cast<float*>(gx), gw1, gw2, ws, B, Ci, Co,
+                                    H, W, Ho, Wo, m1, m2, stream, 1);
 }
 
 }  // extern "C"

@@ -45,8 +45,12 @@ constexpr int fwd_waves_per_simd() {
 // R4 > 0: the last mode tile holds at most 4*R4 <= 8 modes and is computed with R4 4x4x1 MFMAs (8 cycles each)
 // instead of one 16x16x4 MFMA (32 cycles) that would be 50-94 % padding; "stream" q < NTF is a full 16-mode
 // tile, stream NTF + g is the 4-mode group g.
-template <int NT, int MT, bool VEC, int R4>
+// BF16: the images are bfloat16 (config C5: bf16 activations, f32 accumulation): 8-byte loads of four values, widened
+// (<< 16) where they enter the E / D sums; the spectrum stays complex64.
+template <int NT, int MT, bool VEC, int R4, bool BF16>
 __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd_kernel(Dft2dParams p) {
+    using in_t = typename IoElem<BF16>::type;           // float | unsigned short
+    using vec_t = typename IoElem<BF16>::vec4;          // f4u | h4u: four consecutive elements, element-aligned
     constexpr int NTF = R4 > 0 ? NT - 1 : NT;
     constexpr int NS = NTF + R4;
     constexpr int NQ = R4 > 0 ? R4 : 1;
@@ -120,47 +124,47 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xr[mt][t] = f32x4{0, 0, 0, 0}; Xi[mt][t] = f32x4{0, 0, 0, 0}; }
 
-    const float* img = p.in + (size_t)blockIdx.x * H * W;
+    const in_t* img = reinterpret_cast<const in_t*>(p.in) + (size_t)blockIdx.x * H * W;
     const int nrt = (H + 15) >> 4;
 
     // Ring of four chunk buffers: chunk c of a row tile lives in buffer c & 3, loads run three chunks ahead.
     // Every load below is UNCONDITIONAL (chunk / row indices are clamped instead of branched around) so the
     // compiler can count outstanding loads and emit s_waitcnt vmcnt(N) with N > 0; a load under a branch
     // makes it fall back to vmcnt(0), which would expose the full HBM latency once per chunk.
-    f4u bl[4], br[4];
+    vec_t bl[4], br[4];
     auto row_ptr = [&](int rt) { return img + (size_t)min(rt * 16 + r16, H - 1) * W; };
     const int clast = max(nfull - 1, 0);
 #define UNO_LOAD_CHUNK(buf, xr, c)                                                        \
     do {                                                                                  \
         const int a_ = 16 * min((c), clast) + 4 * kk;                                     \
         if (UNO_ABLATE & 8) { /* same bytes, fully contiguous per instruction (wrong data) */ \
-        const float* t_ = img + min(__builtin_amdgcn_readfirstlane((int)((xr) - img)), (H - 16) * W) + 128 * min((c), clast) + 4 * lane; \
-        bl[buf] = *reinterpret_cast<const f4u*>(t_);                                      \
-        br[buf] = *reinterpret_cast<const f4u*>(t_ + 256);                                \
+        const in_t* t_ = img + min(__builtin_amdgcn_readfirstlane((int)((xr) - img)), (H - 16) * W) + 128 * min((c), clast) + 4 * lane; \
+        bl[buf] = *reinterpret_cast<const vec_t*>(t_);                                    \
+        br[buf] = *reinterpret_cast<const vec_t*>(t_ + 256);                              \
         } else if (!(UNO_ABLATE & 2)) {                                                   \
-        bl[buf] = *reinterpret_cast<const f4u*>((xr) + 1 + a_);                           \
-        br[buf] = *reinterpret_cast<const f4u*>((xr) + W - 4 - a_);                       \
+        bl[buf] = *reinterpret_cast<const vec_t*>((xr) + 1 + a_);                         \
+        br[buf] = *reinterpret_cast<const vec_t*>((xr) + W - 4 - a_);                     \
         }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);  /* keep the prefetch where it is issued */    \
     } while (0)
 
     int rt = wave;
     if constexpr (VEC) {
-        const float* xr0 = row_ptr(min(rt, nrt - 1));
+        const in_t* xr0 = row_ptr(min(rt, nrt - 1));
         UNO_LOAD_CHUNK(0, xr0, 0);
         UNO_LOAD_CHUNK(1, xr0, 1);
         UNO_LOAD_CHUNK(2, xr0, 2);
     }
 
     for (; rt < nrt; rt += NW) {
-        const float* xr = row_ptr(rt);
+        const in_t* xr = row_ptr(rt);
         asm volatile("" ::: "memory");          // keep the (loop-invariant) LDS table reads inside the loop: registers are scarcer
         float TL[TAILMAX], TR[TAILMAX];
 #pragma unroll
         for (int s = 0; s < TAILMAX; ++s) {
             const int wl = sTailW[(s * 2 + 0) * 64 + lane], wr = sTailW[(s * 2 + 1) * 64 + lane];
-            const float vl = xr[max(wl, 0)];    // unconditional (clamped) loads, masked by select
-            const float vr = xr[max(wr, 0)];
+            const float vl = io_widen(xr[max(wl, 0)]);    // unconditional (clamped) loads, masked by select
+            const float vr = io_widen(xr[max(wr, 0)]);
             TL[s] = wl >= 0 ? vl : 0.f;
             TR[s] = wr >= 0 ? vr : 0.f;
         }
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
 #define UNO_COMPUTE_CHUNK(buf)                                                            \
     do {                                                                                  \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                   \
-            const float E = bl[buf].v[s] + br[buf].v[3 - s];                              \
-            const float D = bl[buf].v[s] - br[buf].v[3 - s];                              \
+            const float E = io_widen(bl[buf].v[s]) + io_widen(br[buf].v[3 - s]);          \
+            const float D = io_widen(bl[buf].v[s]) - io_widen(br[buf].v[3 - s]);          \
             float2 twn[NS];                                                               \
             _Pragma("unroll") for (int t = 0; t < NS; ++t) {                              \
                 if (UNO_ABLATE & 1) { twn[t] = tw[t]; }                                   \
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
         }
         if constexpr (VEC) {
             // all buffers are free: start the next row tile's first chunks, they land during stage B
-            const float* xn = row_ptr(min(rt + NW, nrt - 1));
+            const in_t* xn = row_ptr(min(rt + NW, nrt - 1));
             UNO_LOAD_CHUNK(0, xn, 0);
             UNO_LOAD_CHUNK(1, xn, 1);
             UNO_LOAD_CHUNK(2, xn, 2);
@@ -367,15 +371,15 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
     }
 }
 
-template <int NT, int MT, bool VEC, int R4>
-static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
+template <int NT, int MT, bool VEC, int R4, bool BF16>
+static int launch_fwd_b(const Dft2dParams& p, hipStream_t s) {
     constexpr int NS = (R4 > 0 ? NT - 1 : NT) + R4;
     const int nrt = (p.H + 15) / 16;
     const int NW = (long long)p.H * p.W < 4096 ? 1 : pick_waves_per_image(nrt);     // small images (3-D planes): one wave each, more images in flight per CU
     const size_t red = (size_t)(NW / 2) * MT * NT * 8 * 64 * sizeof(float);
     const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)TAILMAX * (2 + NS) * 64 * 4 + red;
     if (lds > 160 * 1024) { set_error("dft2d_fwd: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
-    auto k = dft2d_fwd_kernel<NT, MT, VEC, R4>;
+    auto k = dft2d_fwd_kernel<NT, MT, VEC, R4, BF16>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", lds);
@@ -383,14 +387,19 @@ static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
         }
     }
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d>", NT, MT, VEC ? "true" : "false", R4);
+    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d%s>", NT, MT, VEC ? "true" : "false", R4, BF16 ? ", bf16" : "");
     {
-        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
+        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * (BF16 ? 2.0 : 4.0) + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dft2d_fwd launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
+}
+
+template <int NT, int MT, bool VEC, int R4>
+static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
+    return p.bf16 ? launch_fwd_b<NT, MT, VEC, R4, true>(p, s) : launch_fwd_b<NT, MT, VEC, R4, false>(p, s);
 }
 
 }  // namespace uno

@@ -40,8 +40,10 @@ constexpr int inv_waves_per_simd() {
     return regs <= 120 ? 4 : (regs <= 160 ? 3 : (regs <= 230 ? 2 : 1));
 }
 
-template <int KS, int JT>
+// BF16: the images are written as bfloat16 (round to nearest even; config C5), everything before the store is f32.
+template <int KS, int JT, bool BF16>
 __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv_kernel(Dft2dParams p) {
+    using out_t = typename IoElem<BF16>::type;
     constexpr int NT = (KS + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, W = p.W, m1 = p.m1, m2 = p.m2;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv
     }
     __syncthreads();
 
-    float* img = p.out + (size_t)blockIdx.x * H * W;
+    out_t* img = reinterpret_cast<out_t*>(p.out) + (size_t)blockIdx.x * H * W;
     const int nrt = (H + 15) >> 4;
     const int Wh = W >> 1;                      // columns 0..Wh are computed, Wh+1..W-1 are their mirror images
     const int nwt = (Wh + 16) >> 4;             // 16-column tiles covering 0..Wh
@@ -185,20 +187,20 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = 4 * q + kk;
-                    float* rowp = img + (size_t)(16 * rt + row) * W;
+                    out_t* rowp = img + (size_t)(16 * rt + row) * W;
                     if (left_full) {
                         const f32x4 vl = *reinterpret_cast<const f32x4*>(stL + row * STG_RS + 4 * r16);
                         if (UNO_ABLATE & 4)      // timing probe: the row segment snapped to a 64-byte boundary (wrong place)
                             *reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(rowp + c0) & ~uintptr_t(63)) + 16 * r16) = vl;
                         else
-                        *reinterpret_cast<f4u*>(rowp + c0 + 4 * r16) = f4u{{vl[0], vl[1], vl[2], vl[3]}};
+                        io_store4(rowp + c0 + 4 * r16, vl[0], vl[1], vl[2], vl[3]);
                     }
                     if (right_full) {
                         const f32x4 vr = *reinterpret_cast<const f32x4*>(stR + row * STG_RS + 4 * r16);
                         if (UNO_ABLATE & 4)
                             *reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(rowp + cr0) & ~uintptr_t(63)) + 16 * r16) = vr;
                         else
-                        *reinterpret_cast<f4u*>(rowp + cr0 + 4 * r16) = f4u{{vr[0], vr[1], vr[2], vr[3]}};
+                        io_store4(rowp + cr0 + 4 * r16, vr[0], vr[1], vr[2], vr[3]);
                     }
                 }
             }
@@ -213,24 +215,24 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv
                     if (UNO_ABLATE & 32) {      // timing probe: LDS read-back kept, global stores dropped
                         asm volatile("" ::"v"(vl[0]), "v"(vl[3]), "v"(vr[0]), "v"(vr[3]));
                     } else if (h < H) {
-                        float* rowp = img + (size_t)h * W;
+                        out_t* rowp = img + (size_t)h * W;
                         const int cl = c0 + 4 * r16;        // first of this lane's four left columns
                         if (!do_left) {
                         } else if (cl + 3 <= Wh) {
-                            *reinterpret_cast<f4u*>(rowp + cl) = f4u{{vl[0], vl[1], vl[2], vl[3]}};
+                            io_store4(rowp + cl, vl[0], vl[1], vl[2], vl[3]);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (cl + e <= Wh) rowp[cl + e] = vl[e];
+                                if (cl + e <= Wh) io_store1(rowp + cl + e, vl[e]);
                         }
                         const int cr = cr0 + 4 * r16;       // mirrored columns must stay in (Wh, W-1]
                         if (!do_right) {
                         } else if (cr > Wh && cr + 3 < W) {
-                            *reinterpret_cast<f4u*>(rowp + cr) = f4u{{vr[0], vr[1], vr[2], vr[3]}};
+                            io_store4(rowp + cr, vr[0], vr[1], vr[2], vr[3]);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (cr + e > Wh && cr + e < W) rowp[cr + e] = vr[e];
+                                if (cr + e > Wh && cr + e < W) io_store1(rowp + cr + e, vr[e]);
                         }
                     }
                 }
@@ -239,13 +241,13 @@ __global__ __launch_bounds__(256, (inv_waves_per_simd<KS, JT>())) void dft2d_inv
     }
 }
 
-template <int KS, int JT>
-static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
+template <int KS, int JT, bool BF16>
+static int launch_inv_b(const Dft2dParams& p, hipStream_t s) {
     const int nrt = (p.H + 15) / 16;
     const int NW = (long long)p.H * p.W < 4096 ? 1 : pick_waves_per_image(nrt);     // small images (3-D planes): one wave each, more images in flight per CU
     const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)NW * 2 * 16 * STG_RS * sizeof(float) + (size_t)KS * 64 * 4;
     if (lds > 160 * 1024) { set_error("dft2d_inv: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
-    auto k = dft2d_inv_kernel<KS, JT>;
+    auto k = dft2d_inv_kernel<KS, JT, BF16>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_error("dft2d_inv: cannot raise dynamic LDS to %zu", lds);
@@ -253,14 +255,19 @@ static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
         }
     }
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d>", KS, JT);
+    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d%s>", KS, JT, BF16 ? ", bf16" : "");
     {
-        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
+        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * (BF16 ? 2.0 : 4.0) + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dft2d_inv launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
+}
+
+template <int KS, int JT>
+static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
+    return p.bf16 ? launch_inv_b<KS, JT, true>(p, s) : launch_inv_b<KS, JT, false>(p, s);
 }
 
 #ifndef UNO_INV_KS_LO

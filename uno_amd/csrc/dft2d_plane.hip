@@ -57,7 +57,7 @@ static size_t inv_plane_lds(const Dft2dParams& p) {
 }
 static bool plane_shape_ok(const Dft2dParams& p) {
     static const bool off = getenv("UNO_NO_PLANE_KERNELS") != nullptr;          // developer A/B switch
-    if (off) return false;
+    if (off || p.bf16) return false;
     const long long hw = (long long)p.H * p.W;
     return p.n_img >= PL_MIN_IMAGES && hw >= 16 && hw <= PL_MAX_ELEMS && p.W <= 64 && 2 * p.m1 <= 48 && 2 * p.m2 <= 32 &&
            p.m1 >= 1 && p.m2 >= 1;

@@ -27,6 +27,26 @@ __device__ __forceinline__ unsigned wrap_sub(unsigned idx, unsigned dec, unsigne
 // 4-byte-aligned 16-byte load: rows of odd length leave row starts only 4-byte aligned.
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 
+// bfloat16 activations (config C5): four consecutive elements, 2-byte aligned; widened by << 16, narrowed round-to-nearest-even
+struct __attribute__((packed, aligned(2))) h4u { unsigned short v[4]; };
+template <bool BF16> struct IoElem { typedef float type; typedef f4u vec4; };
+template <> struct IoElem<true> { typedef unsigned short type; typedef h4u vec4; };
+__device__ __forceinline__ float io_widen(float v) { return v; }
+__device__ __forceinline__ float io_widen(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);       // NaN stays NaN (quiet)
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void io_store4(float* dst, float a, float b, float c, float d) {
+    *reinterpret_cast<f4u*>(dst) = f4u{{a, b, c, d}};
+}
+__device__ __forceinline__ void io_store4(unsigned short* dst, float a, float b, float c, float d) {
+    *reinterpret_cast<h4u*>(dst) = h4u{{bf16_rne(a), bf16_rne(b), bf16_rne(c), bf16_rne(d)}};
+}
+__device__ __forceinline__ void io_store1(float* dst, float a) { *dst = a; }
+__device__ __forceinline__ void io_store1(unsigned short* dst, float a) { *dst = bf16_rne(a); }
+
 __device__ __forceinline__ float2 lds_tw(const float2* tab, unsigned byte_off) {
     return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab) + byte_off);
 }
@@ -69,6 +89,7 @@ struct Dft2dParams {
     // spectrum of image i lives at index (i / sp_group) * sp_stride + sp_offset + i % sp_group: a (B, C1) batch of
     // images can face channels [sp_offset, sp_offset + C1) of a (B, sp_stride) spectrum tensor (two-source blocks)
     int sp_group, sp_stride, sp_offset;
+    int bf16;               // 1: the images (forward input / inverse output) are bfloat16; spectra stay complex64
 };
 
 __device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {

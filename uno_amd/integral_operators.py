@@ -456,6 +456,27 @@ def spectral_conv2d(x, weights1, weights2, dim1, dim2):
     return _SpectralConv2dFn.apply(x, weights1, weights2, dim1, dim2)
 
 
+def spectral_conv2d_mixed(x, weights1, weights2, dim1, dim2):
+    """Mixed-precision form of the 2-D Fourier integral operator (BASELINE.json config 5: bf16 activations, half-precision
+    weight storage, f32 accumulation).  Opt-in: the reference - and SpectralConv2d_Uno.forward here - raise on bf16 input
+    (integral_operators.py:187).
+
+    x (B, Ci, H, W) bfloat16 -> (B, Co, dim1, dim2) bfloat16; gradients: gx bfloat16, weights in their own dtype.
+    weights1/2: complex64 (Ci, Co, m1, m2), or their half-precision storage (Ci, Co, m1, m2, 2) float16 (re, im), which is
+    widened on the fly (33 MB at the C5 size against 1 GB of activations).  The pruned DFT kernels read / write the bf16
+    tensors directly; the truncated spectrum, the per-mode GEMM and every accumulation are f32 / c64, so the result equals the
+    f32 operator applied to the widened inputs, rounded once (to nearest even) on the way out - tests/test_hip_mixed.py."""
+    if x.dtype != torch.bfloat16:
+        raise RuntimeError(f"spectral_conv2d_mixed: input must be bfloat16 (got {x.dtype})")
+    def widen(w):
+        if w.dtype == torch.float16:
+            if w.shape[-1] != 2:
+                raise RuntimeError("spectral_conv2d_mixed: half-precision weights are stored as (..., 2) = (re, im)")
+            return torch.view_as_complex(w.float())
+        return w
+    return _SpectralConv2dFn.apply(x, widen(weights1), widen(weights2), dim1, dim2)
+
+
 # --------------------------------------------------------------------------------------------- 2-D
 class SpectralConv2d_Uno(nn.Module):
     """2-D Fourier integral operator (reference integral_operators.py:127-207).
