@@ -33,16 +33,23 @@ template <bool BF16> struct IoElem { typedef float type; typedef f4u vec4; };
 template <> struct IoElem<true> { typedef unsigned short type; typedef h4u vec4; };
 __device__ __forceinline__ float io_widen(float v) { return v; }
 __device__ __forceinline__ float io_widen(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ unsigned short bf16_rne(float f) {
-    const unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);       // NaN stays NaN (quiet)
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// f32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 (gfx950), two values per instruction
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
+__device__ __forceinline__ unsigned short bf16_rne(float f) { return (unsigned short)(bf16_pack2(f, 0.f) & 0xffffu); }
+struct __attribute__((packed, aligned(2))) h8u { unsigned w[4]; };      // eight bf16, 2-byte aligned
 __device__ __forceinline__ void io_store4(float* dst, float a, float b, float c, float d) {
     *reinterpret_cast<f4u*>(dst) = f4u{{a, b, c, d}};
 }
 __device__ __forceinline__ void io_store4(unsigned short* dst, float a, float b, float c, float d) {
-    *reinterpret_cast<h4u*>(dst) = h4u{{bf16_rne(a), bf16_rne(b), bf16_rne(c), bf16_rne(d)}};
+    struct __attribute__((packed, aligned(2))) h4w { unsigned w[2]; };
+    *reinterpret_cast<h4w*>(dst) = h4w{{bf16_pack2(a, b), bf16_pack2(c, d)}};
+}
+__device__ __forceinline__ void io_store8(unsigned short* dst, const f32x4& a, const f32x4& b) {
+    *reinterpret_cast<h8u*>(dst) = h8u{{bf16_pack2(a[0], a[1]), bf16_pack2(a[2], a[3]), bf16_pack2(b[0], b[1]), bf16_pack2(b[2], b[3])}};
 }
 __device__ __forceinline__ void io_store1(float* dst, float a) { *dst = a; }
 __device__ __forceinline__ void io_store1(unsigned short* dst, float a) { *dst = bf16_rne(a); }
