@@ -104,6 +104,8 @@ MIX_SHAPES = [
     # B, Ci, Co, ncorner, modes-per-corner shape
     (2, 3, 4, 2, (4, 5)), (16, 64, 64, 2, (20, 20)), (8, 32, 32, 2, (12, 12)), (5, 7, 9, 2, (3, 11)),
     (17, 20, 33, 2, (2, 9)), (1, 1, 1, 2, (1, 1)), (4, 6, 5, 4, (3, 3, 2)), (3, 48, 24, 2, (18, 18)),
+    # long channel loop on a small grid: the 8-mode workgroup variant (forward K = Ci, input gradient K = Co)
+    (4, 96, 40, 2, (3, 3)), (3, 20, 128, 2, (5, 4)), (2, 130, 100, 4, (3, 2, 2)), (16, 256, 256, 2, (8, 8)), (5, 192, 48, 2, (3, 7)),
 ]
 
 

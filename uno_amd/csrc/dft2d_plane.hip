@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #ifndef UNO_ABLATE
 #define UNO_ABLATE 0        // developer ablation builds only (tools/ablate.sh); 0 = product
@@ -363,16 +365,29 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2d
 // One wave of workgroups: as many as are resident at once (LDS / register bound), so that every wave walks over the same
 // number of images (+-1) instead of a second, partly filled round of workgroups.
 static int plane_grid(const void* kernel, size_t lds, int n_img) {
-    int dev = 0, cus = 256, per_cu = 0;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        static int cached_dev = -1, cached_cus = 256;
-        if (cached_dev != dev && hipGetDeviceProperties(&prop, dev) == hipSuccess) { cached_cus = prop.multiProcessorCount; cached_dev = dev; }
-        cus = cached_cus;
+    // the occupancy query costs microseconds of host time: remember it per (device, kernel, LDS size)
+    struct Key { int dev; const void* k; size_t lds; };
+    struct Entry { Key key; int resident; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int resident = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry& e : cache)
+            if (e.key.dev == dev && e.key.k == kernel && e.key.lds == lds) { resident = e.resident; break; }
+        if (!resident) {
+            int cus = 256, per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * PL_WAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            resident = cus * per_cu;
+            cache.push_back(Entry{Key{dev, kernel, lds}, resident});
+        }
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * PL_WAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const long long want = ((long long)n_img + PL_WAVES - 1) / PL_WAVES;
-    return (int)std::min<long long>(want, (long long)cus * per_cu);
+    return (int)std::min<long long>(want, (long long)resident);
 }
 
 template <int MT, int NTN>
