@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __re
 // four wave sums are added in wave order (fixed order -> bit-reproducible).
 __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
                                                                const float* __restrict__ gout, float* __restrict__ gpre,
-                                                               float* __restrict__ part, int C, int P) {
+                                                               float* __restrict__ part, int C, int P, int Cs) {
+    // blockIdx.z = channel split: channels [z Cs, min(C, (z + 1) Cs)); small tensors (one-wave workgroups) are split over
+    // channels as well, so that the chip sees 4x the waves (a 64 x 64 grid at batch 32 gave 512 waves walking 128 channels each)
     __shared__ float sw[GP_MAXC];
     extern __shared__ float swave[];                    // [waves][C + 1]
     const int nw = blockDim.x >> 6;
@@ -117,8 +119,9 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __re
         for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0) mine[slot] = s;
     };
+    const int c_lo = blockIdx.z * Cs, c_hi = min(C, c_lo + Cs);
 #pragma unroll 2
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         float s = 0.f;
         if (live) {
             float v[4], o[4];
@@ -137,20 +140,24 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __re
     }
     wave_sum((g[0] + g[1]) + (g[2] + g[3]), C);
     __syncthreads();
-    float* prow = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (C + 1);
-    for (int e = threadIdx.x; e <= C; e += blockDim.x) {
+    // part[z][blk][C + 1]: a split fills its own channels (split 0 also the bias slot C); the reduction reads exactly those
+    float* prow = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (C + 1);
+    auto total = [&](int e) {
         float t = swave[e];
         for (int k = 1; k < nw; ++k) t += swave[k * (C + 1) + e];          // wave order: fixed
-        prow[e] = t;
-    }
+        return t;
+    };
+    for (int e = c_lo + threadIdx.x; e < c_hi; e += blockDim.x) prow[e] = total(e);
+    if (blockIdx.z == 0 && threadIdx.x == 0) prow[C] = total(C);
 }
 
 __global__ __launch_bounds__(256) void gelu_project_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
-                                                                  float* __restrict__ gb, int C, int nblk) {
-    // one wave per output entry, lanes stride over the workgroup partials, fixed order
+                                                                  float* __restrict__ gb, int C, int nblk, int Cs) {
+    // one wave per output entry, lanes stride over the workgroup partials of the entry's channel split, fixed order
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e > C) return;
     const int lane = threadIdx.x & 63;
+    part += (size_t)(e < C ? e / Cs : 0) * nblk * (C + 1);
     float s = 0.f;
     for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * (C + 1) + e];
 #pragma unroll
@@ -177,9 +184,12 @@ int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias,
     return 0;
 }
 
+// channel splits of the backward pass: 4 for the small-tensor (one-wave workgroup) case
+static int gelu_project_splits(int B, int C, long long P) { return (gelu_project_threads(B, P) == 64 && C >= 16) ? 4 : 1; }
+
 long long gelu_project_ws_floats(int B, int C, long long P) {
     const int t = gelu_project_threads(B, P);
-    return (long long)B * ((P + 4 * t - 1) / (4 * t)) * (C + 1);
+    return (long long)gelu_project_splits(B, C, P) * B * ((P + 4 * t - 1) / (4 * t)) * (C + 1);
 }
 
 int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
@@ -187,11 +197,12 @@ int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout,
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
     const int threads = gelu_project_threads(B, P);
     const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
+    const int nsplit = gelu_project_splits(B, C, P), Cs = (C + nsplit - 1) / nsplit;
     {
         ProfScope prof("uno::gelu_project_bwd_kernel", 4.0 * B * (double)P * (2 * C + 1), s);
-        hipLaunchKernelGGL(gelu_project_bwd_kernel, dim3(nb, B), dim3(threads), (threads / 64) * (C + 1) * sizeof(float), s, pre, w, gout, gpre, ws, C, (int)P);
+        hipLaunchKernelGGL(gelu_project_bwd_kernel, dim3(nb, B, nsplit), dim3(threads), (threads / 64) * (C + 1) * sizeof(float), s, pre, w, gout, gpre, ws, C, (int)P, Cs);
     }
-    hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B));
+    hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B), Cs);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gelu_project backward launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
