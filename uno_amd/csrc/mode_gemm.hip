@@ -59,14 +59,24 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     float2 ra[EPT], rb[EPT];
     const int q_t = tid & (QC - 1), x_t = (tid / QC) & 15, kb_t = tid / (16 * QC);
     const bool okA = q_t < nmodes && m0 + x_t < p.M, okB = q_t < nmodes && n0 + x_t < p.N;
-    const float2* pA = Ab + (okA ? (long long)(m0 + x_t) * p.A.s0 + q_t : 0);
-    const float2* pB = Bb + (okB ? (long long)(n0 + x_t) * p.B.s1 + q_t : 0);
+    // raw buffer loads: per-thread byte offset (fixed) + scalar offset k * stride - no per-load vector address arithmetic
+    // (the 64-bit address of each of the 16 loads of a chunk cost 3-4 VALU instructions, issued between the MFMA blocks)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, -1, 0x00020000);
+    const unsigned voA = okA ? (unsigned)(((long long)(m0 + x_t) * p.A.s0 + q_t + (long long)kb_t * p.A.s1) * 8) : 0u;
+    const unsigned voB = okB ? (unsigned)(((long long)(n0 + x_t) * p.B.s1 + q_t + (long long)kb_t * p.B.s0) * 8) : 0u;
+    const unsigned strideA = (unsigned)(p.A.s1 * 8), strideB = (unsigned)(p.B.s0 * 8);
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
-            const int k = min(k0 + KSTEP * u + kb_t, p.K - 1);  // clamped address: unconditional loads; the zero-fill of invalid
-            ra[u] = pA[(long long)k * p.A.s1];                  // entries happens on the way to LDS, after the MFMA block
-            rb[u] = pB[(long long)k * p.B.s0];                  // (masking here would consume the registers at once)
+            // clamped (wave-uniform) row: unconditional loads; the zero-fill of invalid entries happens on the way to LDS,
+            // after the MFMA block (masking here would consume the registers at once)
+            const unsigned kb = (unsigned)max(min(k0 + KSTEP * u, p.K - KSTEP), 0);
+            const u32x2 ta = __builtin_amdgcn_raw_buffer_load_b64(rA, voA, kb * strideA, 0);
+            const u32x2 tb = __builtin_amdgcn_raw_buffer_load_b64(rB, voB, kb * strideB, 0);
+            ra[u] = make_float2(__uint_as_float(ta[0]), __uint_as_float(ta[1]));
+            rb[u] = make_float2(__uint_as_float(tb[0]), __uint_as_float(tb[1]));
         }
     };
     auto store_chunk = [&](int k0) {
@@ -135,6 +145,10 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         set_error("mode_gemm: bad sizes M=%d N=%d K=%d corners=%d modes=%d", p.M, p.N, p.K, p.ncorner, p.Mc);
         return -2;
     }
+    // byte offsets inside an operand are 32-bit (raw buffer loads)
+    const long long spanA = ((long long)(p.M - 1) * p.A.s0 + (long long)(p.K - 1) * p.A.s1 + p.Mc) * 8;
+    const long long spanB = ((long long)(p.N - 1) * p.B.s1 + (long long)(p.K - 1) * p.B.s0 + p.Mc) * 8;
+    if (spanA >= (1LL << 31) || spanB >= (1LL << 31)) { set_error("mode_gemm: an operand spans %lld bytes per corner (limit 2 GiB)", spanA > spanB ? spanA : spanB); return -2; }
     const int tiles = ((p.N + 15) / 16) * ((p.M + 15) / 16);
     // under two workgroups per CU and a long K loop: halve the mode chunk (measured, tools/k2bench.py: 256 -> 256 channels x 2 x 64
     // modes 53 -> 36 us, 192 -> 192 x 2 x 36 modes 42 -> 28 us; with K <= 64 the 64-byte runs cost more than the extra workgroups give)
