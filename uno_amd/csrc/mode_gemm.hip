@@ -18,6 +18,7 @@
 // through LDS so the stores are 128-byte runs again.  The next K chunk is prefetched into registers
 // while the current one is multiplied.
 #include "uno_common.h"
+#include <algorithm>
 
 namespace uno {
 
@@ -26,16 +27,18 @@ constexpr int KC = 8;           // reduction chunk staged in LDS
 // QC = modes per workgroup: 16 (128-byte runs along the mode axis) or 8 (64-byte runs, twice the workgroups: layers with few
 // modes and many channels - 2 x 64 modes x 256 x 256 channels - give only 128 workgroups of 16 modes, and a workgroup's phases
 // (stage to LDS, issue loads, multiply) do not overlap with one wave per SIMD: the time was the sum of the three)
-template <int QC>
+// PIPE: software-pipelined K loop over two LDS buffers (8-mode variant on layers with few mode chunks, see the launcher)
+template <int QC, bool PIPE>
 __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     constexpr int TILE_ELEMS = 16 * KC * QC;        // complex elements of one operand chunk
     constexpr int EPT = TILE_ELEMS / 256;           // elements per thread per operand: 8 / 4
     constexpr int KSTEP = 16 / QC;                  // k rows covered by one pass of the 256 threads: 1 / 2
     constexpr int PLANE = KC * 16 + 64 / QC;        // floats per (mode) plane; the pad makes the transposing writes conflict-free (lane -> bank 4 q + x / 8 q + x)
-    // [operand A|B][re|im][QC][PLANE] floats; reused as the [16 m][16 n][QC] c64 output tile
-    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * QC * PLANE > 16 * 16 * (QC + 1) * 2 ? 2 * 2 * QC * PLANE : 16 * 16 * (QC + 1) * 2];
-    float* sA = sm;
-    float* sB = sm + 2 * QC * PLANE;
+    // two buffers of [operand A|B][re|im][QC][PLANE] floats (chunk c is multiplied out of one while chunk c + 1 is staged into
+    // the other: one barrier per chunk); reused as the [16 m][16 n][QC] c64 output tile
+    constexpr int SB = 2 * 2 * QC * PLANE;
+    static_assert((PIPE ? 2 : 1) * SB >= 16 * 16 * (QC + 1) * 2 || !PIPE, "output tile must fit the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     // this is q = tid % QC, x = (tid / QC) % 16, k-local = KSTEP * u + tid / (16 QC): a thread walks K with a fixed (x, q), so
     // its addresses are one base per operand plus k * stride (computing the general form per load cost 20-40 integer
     // instructions each)
-    float2 ra[EPT], rb[EPT];
+    float2 ra[2][EPT], rb[2][EPT];           // two register stages: loads run two chunks ahead of the multiply
     const int q_t = tid & (QC - 1), x_t = (tid / QC) & 15, kb_t = tid / (16 * QC);
     const bool okA = q_t < nmodes && m0 + x_t < p.M, okB = q_t < nmodes && n0 + x_t < p.N;
     // raw buffer loads: per-thread byte offset (fixed) + scalar offset k * stride - no per-load vector address arithmetic
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     const unsigned voA = okA ? (unsigned)(((long long)(m0 + x_t) * p.A.s0 + q_t + (long long)kb_t * p.A.s1) * 8) : 0u;
     const unsigned voB = okB ? (unsigned)(((long long)(n0 + x_t) * p.B.s1 + q_t + (long long)kb_t * p.B.s0) * 8) : 0u;
     const unsigned strideA = (unsigned)(p.A.s1 * 8), strideB = (unsigned)(p.B.s0 * 8);
-    auto load_chunk = [&](int k0) {
+    auto load_chunk = [&](float2* da, float2* db, int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             // clamped (wave-uniform) row: unconditional loads; the zero-fill of invalid entries happens on the way to LDS,
@@ -75,17 +78,19 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
             const unsigned kb = (unsigned)max(min(k0 + KSTEP * u, p.K - KSTEP), 0);
             const u32x2 ta = __builtin_amdgcn_raw_buffer_load_b64(rA, voA, kb * strideA, 0);
             const u32x2 tb = __builtin_amdgcn_raw_buffer_load_b64(rB, voB, kb * strideB, 0);
-            ra[u] = make_float2(__uint_as_float(ta[0]), __uint_as_float(ta[1]));
-            rb[u] = make_float2(__uint_as_float(tb[0]), __uint_as_float(tb[1]));
+            da[u] = make_float2(__uint_as_float(ta[0]), __uint_as_float(ta[1]));
+            db[u] = make_float2(__uint_as_float(tb[0]), __uint_as_float(tb[1]));
         }
     };
-    auto store_chunk = [&](int k0) {
+    auto store_chunk = [&](float* buf, const float2* sa, const float2* sb, int k0) {
+        float* sA = buf;
+        float* sB = buf + 2 * QC * PLANE;
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             const int o = q_t * PLANE + (KSTEP * u + kb_t) * 16 + x_t;     // row = k-local * 16 + x
             const bool kv = k0 + KSTEP * u + kb_t < p.K;
-            const float2 va = (kv && okA) ? ra[u] : make_float2(0.f, 0.f);
-            const float2 vb = (kv && okB) ? rb[u] : make_float2(0.f, 0.f);
+            const float2 va = (kv && okA) ? sa[u] : make_float2(0.f, 0.f);
+            const float2 vb = (kv && okB) ? sb[u] : make_float2(0.f, 0.f);
             sA[o] = va.x; sA[QC * PLANE + o] = sgnA * va.y;
             sB[o] = vb.x; sB[QC * PLANE + o] = sgnB * vb.y;
         }
@@ -95,12 +100,9 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
 #pragma unroll
     for (int v = 0; v < QC / 4; ++v) { accr[v] = f32x4{0, 0, 0, 0}; acci[v] = f32x4{0, 0, 0, 0}; }
 
-    load_chunk(0);
-    for (int k0 = 0; k0 < p.K; k0 += KC) {
-        __syncthreads();                    // previous chunk fully consumed
-        store_chunk(k0);
-        __syncthreads();
-        if (k0 + KC < p.K) load_chunk(k0 + KC);
+    auto multiply = [&](const float* buf) {
+        const float* sA = buf;
+        const float* sB = buf + 2 * QC * PLANE;
 #pragma unroll
         for (int v = 0; v < QC / 4; ++v) {
             const int q = wave + 4 * v;
@@ -116,8 +118,44 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
                 acci[v] = mfma16(ai, br, acci[v]);
             }
         }
+    };
+    // Software pipeline over K chunks (straight-line stages, all loads unconditional with clamped rows, so the waits are
+    // s_waitcnt vmcnt(16) - not 0): while chunk c is multiplied out of LDS buffer c & 1, chunk c + 1 (in registers since the
+    // previous stage) is staged into the other buffer and the loads of chunk c + 2 are in flight.  Chunks past K hold zeros.
+    float* buf0 = sm;
+    float* buf1 = sm + SB;
+    if constexpr (PIPE) {
+        load_chunk(ra[0], rb[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(ra[1], rb[1], KC);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(buf0, ra[0], rb[0], 0);
+        __syncthreads();
+        for (int k0 = 0; k0 < p.K; k0 += 2 * KC) {
+            load_chunk(ra[0], rb[0], k0 + 2 * KC);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(buf0);
+            store_chunk(buf1, ra[1], rb[1], k0 + KC);
+            __syncthreads();
+            load_chunk(ra[1], rb[1], k0 + 3 * KC);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + KC < p.K) multiply(buf1);
+            store_chunk(buf0, ra[0], rb[0], k0 + 2 * KC);
+            __syncthreads();
+        }
+    } else {
+        // one buffer, the next chunk in registers while the current one is multiplied.  For 16 modes the pipelined form needs
+        // 68 KB of LDS (2 workgroups per CU instead of 4) and measured 15-25 % slower on the large grids that variant serves.
+        load_chunk(ra[0], rb[0], 0);
+        for (int k0 = 0; k0 < p.K; k0 += KC) {
+            __syncthreads();                    // previous chunk fully consumed
+            store_chunk(buf0, ra[0], rb[0], k0);
+            __syncthreads();
+            if (k0 + KC < p.K) load_chunk(ra[0], rb[0], k0 + KC);
+            multiply(buf0);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // result tile -> LDS as [m][n][QC+1] c64, then 128-byte runs along the mode axis
     float2* sO = reinterpret_cast<float2*>(sm);
@@ -140,6 +178,12 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     }
 }
 
+// 16 modes: one staging buffer (33.8 KB, also holds the 34.8 KB output tile); 8 modes: two (34.8 KB)
+static size_t mode_gemm_lds(int qc, bool pipe) {
+    const size_t sb = (size_t)2 * 2 * qc * (KC * 16 + 64 / qc), out = (size_t)16 * 16 * (qc + 1) * 2;
+    return std::max((pipe ? 2 : 1) * sb, out) * sizeof(float);
+}
+
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
     if (p.ncorner < 1 || p.ncorner > 4 || p.Mc < 1 || p.M < 1 || p.N < 1 || p.K < 1) {
         set_error("mode_gemm: bad sizes M=%d N=%d K=%d corners=%d modes=%d", p.M, p.N, p.K, p.ncorner, p.Mc);
@@ -160,8 +204,12 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         // each operand counted once: A (M x K), B (K x N), out (M x N) complex64 per mode
         const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
         ProfScope prof("uno::mode_gemm_kernel", per_mode * p.ncorner * p.Mc, s);
-        if (narrow) hipLaunchKernelGGL(mode_gemm_kernel<8>, grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(mode_gemm_kernel<16>, grid, dim3(256), 0, s, p);
+        // pipelined K loop: measured better with few mode chunks per layer (2 x 36 / 2 x 64 modes: 26 -> 22, 34 -> 29 us) and
+        // worse with many (2 x 196 / 2 x 324 modes: 41 -> 50, 58 -> 67 us)
+        const bool pipe = narrow && p.ncorner * nq <= 32;
+        if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
+        else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
+        else hipLaunchKernelGGL((mode_gemm_kernel<16, false>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }
