@@ -17,7 +17,7 @@ tensor that is not on a HIP device raises ``RuntimeError``.
 The rest of an operator block runs on the same library for float32 device tensors: the point-wise branch (1x1
 convolution = channel-mix kernels, bicubic anti-aliased resampling = banded separable kernels) accumulates into the
 spectral branch's output buffer, InstanceNorm (+ GELU) is one kernel; only the GELU of non-normalised blocks and the
-FFT-based resampling of pointwise_op_3D are stock PyTorch-ROCm ops.  CPU tensors take stock torch ops in these helper
+FFT-based resampling of pointwise_op_3D are stock PyTorch-ROCm ops (SpectralConv1d_Uno runs on the 2-D kernels, one row).  CPU tensors take stock torch ops in these helper
 layers (they are not part of the spectral path and the CPU-side harness tests use them with the oracle blocks).
 """
 from __future__ import annotations
@@ -698,6 +698,13 @@ class SpectralConv1d_Uno(nn.Module):
     def forward(self, x, dim1=None):
         if dim1 is not None:
             self.dim1 = dim1
+        if x.is_cuda:
+            # the 1-D layer is the 2-D one on a grid of one row: the row DFT of length 1 is the identity, both "corners" are the
+            # row of frequency 0 and the later-wins rule keeps the second one - weights1 in both slots, the masked slot's
+            # gradient is exactly zero
+            _check_input(x, 3, self.in_channels, "SpectralConv1d_Uno")
+            w = self.weights1.unsqueeze(2)
+            return spectral_conv2d(x.unsqueeze(2), w, w, 1, self.dim1).squeeze(2)
         spec = torch.fft.rfft(x, norm="forward")
         out = torch.zeros(x.shape[0], self.out_channels, self.dim1 // 2 + 1, dtype=torch.cfloat, device=x.device)
         out[:, :, : self.modes1] = torch.einsum("bix,iox->box", spec[:, :, : self.modes1], self.weights1)
