@@ -48,14 +48,23 @@ __device__ __forceinline__ void store4_guard(float* row, int px, int n, const fl
 // ------------------------------------------------------------------------------------------------ K11
 constexpr int GP_MAXC = 1024;
 
+// SPLIT: small tensors (a 64 x 64 grid at batch 32 gives 512 one-wave pixel tiles for 256 CUs, each walking all C channels): the
+// four waves of a workgroup share ONE 256-pixel tile and take a quarter of the channels each; partial sums meet in LDS and are
+// added in wave order (fixed -> bit-reproducible).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ out, int C, int P) {
     __shared__ float sw[GP_MAXC];
+    __shared__ float sred[SPLIT ? 4 * 64 * 4 : 1];
     for (int c = threadIdx.x; c < C; c += blockDim.x) sw[c] = w[c];
     __syncthreads();
     const int b = blockIdx.y;
-    const int px = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (px >= P) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = SPLIT ? (blockIdx.x * 64 + lane) * 4 : (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const bool live = px < P;
+    if (!SPLIT && !live) return;
+    const int Cs = SPLIT ? (C + 3) / 4 : C;
+    const int c_lo = SPLIT ? min(wave * Cs, C) : 0, c_hi = SPLIT ? min(c_lo + Cs, C) : C;
     const float* src = pre + (size_t)b * C * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // channels in groups of 4, the next group's loads issued before the current one is consumed (-11 % against the
@@ -63,29 +72,39 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __re
     // backward kernel 12 % slower - it keeps the plain loop)
     auto load = [&](int c0, float v[4][4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load4_guard(src + (size_t)min(c0 + j, C - 1) * P, px, P, v[j]);
+        for (int j = 0; j < 4; ++j) load4_guard(src + (size_t)max(min(c0 + j, c_hi - 1), 0) * P, px, P, v[j]);
     };
     auto use = [&](int c0, const float v[4][4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (c0 + j < C) {
+            if (c0 + j < c_hi) {
                 const float wc = sw[c0 + j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = fmaf(wc, gelu_f(v[j][i]), acc[i]);
             }
         }
     };
-    float va[4][4], vb[4][4];
-    load(0, va);
-    for (int c = 0; c < C; c += 8) {
-        load(c + 4, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        use(c, va);
-        load(c + 8, va);
-        __builtin_amdgcn_sched_barrier(0);
-        use(c + 4, vb);
+    if (live && c_lo < c_hi) {
+        float va[4][4], vb[4][4];
+        load(c_lo, va);
+        for (int c = c_lo; c < c_hi; c += 8) {
+            load(c + 4, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            use(c, va);
+            load(c + 8, va);
+            __builtin_amdgcn_sched_barrier(0);
+            use(c + 4, vb);
+        }
     }
     const float bv = bias ? bias[0] : 0.f;
+    if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sred[(wave * 64 + lane) * 4 + i] = acc[i];
+        __syncthreads();
+        if (wave != 0 || !live) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = ((sred[lane * 4 + i] + sred[(64 + lane) * 4 + i]) + sred[(128 + lane) * 4 + i]) + sred[(192 + lane) * 4 + i];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] += bv;
     store4_guard(out + (size_t)b * P, px, P, acc);
@@ -174,10 +193,12 @@ static int gelu_project_threads(int B, long long P) { return (long long)B * ((P 
 int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s) {
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
     const int threads = gelu_project_threads(B, P);
+    const bool split = threads == 64 && C >= 16;
     const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     {
         ProfScope prof("uno::gelu_project_fwd_kernel", 4.0 * B * (double)P * (C + 1), s);
-        hipLaunchKernelGGL(gelu_project_fwd_kernel, dim3(nb, B), dim3(threads), 0, s, pre, w, bias, out, C, (int)P);
+        if (split) hipLaunchKernelGGL(gelu_project_fwd_kernel<true>, dim3(nb, B), dim3(256), 0, s, pre, w, bias, out, C, (int)P);
+        else hipLaunchKernelGGL(gelu_project_fwd_kernel<false>, dim3(nb, B), dim3(threads), 0, s, pre, w, bias, out, C, (int)P);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gelu_project launch: %s", hipGetErrorString(e)); return -5; }
