@@ -68,6 +68,20 @@ int uno_spectral_conv2d_backward_bf16(const void* gy, const float* xtrunc, const
                                       int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1,
                                       int m2, void* stream);
 
+/* The FFT crop / resample of pointwise_op_3D (reference integral_operators.py:448-463: unnormalised rfftn, four corners of
+ * half the OUTPUT size copied into an INPUT-sized zero spectrum, irfftn(s = output size)) as a pruned DFT - pruned inverse DFT
+ * pair with explicit frequency tables: along a complex axis the reference keeps spectrum indices r_j and reads index r_j as
+ * frequency r_j of the output-length transform (irfftn trims / zero-pads at the END of the axis - bug-compatible, including
+ * the misplaced negative frequencies when sizes differ).
+ *   x (n_vol, D1, D2, D3) f32 -> y (n_vol, M1, M2, M3) f32;  f1_in / f1_out (J1 ints, device), f2_in / f2_out (J2 ints, device):
+ *   forward / inverse frequency of kept row j along axes 1 / 2 (J1, J2 even; J1 <= 80, J2 <= 48); m3 kept half-spectrum bins;
+ *   herm_in / herm_out: Hermitian column weights on the forward / inverse side (0 / 1 for the operator, 1 / 0 for its adjoint,
+ *   which is the same call with sizes and tables swapped).  Planes of 16 ... 1792 (in) / 2048 (out) elements, D3, M3 <= 64. */
+long long uno_fft_resample3d_ws_bytes(int n_vol, int D1, int M1, int J1, int J2, int m3);
+int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
+                       int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
+                       float scale, int herm_in, int herm_out, void* stream);
+
 /* SpectralConv3d_Uno.forward - reference integral_operators.py:385-427
  *   x (B, Ci, H, W, T) f32;  w[0..3] = weights1..4 (Ci, Co, m1, m2, m3) c64 in the reference's corner
  *   order (lo,lo), (hi,lo), (lo,hi), (hi,hi);  y (B, Co, Ho, Wo, To) f32 [out]

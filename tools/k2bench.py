@@ -10,6 +10,8 @@ SHAPES = [  # B, Ci, Co, modes per corner, corners, label
     (32, 32, 48, 22 * 22, 2, "ns2d L1"), (32, 48, 96, 14 * 14, 2, "ns2d L2"), (32, 96, 192, 36, 2, "ns2d L3"),
     (32, 192, 192, 36, 2, "ns2d L4"), (32, 192, 48, 14 * 14, 2, "ns2d L6"),
     (8, 32, 32, 16 * 16 * 8, 4, "C4 block"),
+    (8, 32, 64, 22 * 22 * 5, 4, "ns3d32 L1"), (8, 64, 128, 14 * 14 * 5, 4, "ns3d32 L2"), (8, 128, 256, 180, 4, "ns3d32 L3"),
+    (8, 256, 512, 216, 4, "ns3d32 L4"), (8, 512, 128, 216, 4, "ns3d32 L5"),
 ]
 def timeit(fn, reps=30):
     for _ in range(3):

@@ -30,6 +30,8 @@ _SIGNATURES = {
     "uno_spectral_conv2d_backward": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
     "uno_spectral_conv2d_forward_bf16": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
     "uno_spectral_conv2d_backward_bf16": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
+    "uno_fft_resample3d_ws_bytes": (C.c_longlong, [_i] * 6),
+    "uno_fft_resample3d": (C.c_int, [_fp] * 3 + [_i] * 8 + [_fp, _fp, _i, _fp, _fp, _i, C.c_float, _i, _i, _fp]),
     "uno_dft2d_forward": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_forward_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
@@ -160,6 +162,30 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
                                             _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(gy))
     _check(rc, "uno_spectral_conv2d_backward")
     return gx, gw1, gw2
+
+
+def fft_resample3d(x, out_size, f1, f2, m3: int, scale: float, adjoint: bool):
+    """x (..., D1, D2, D3) f32 -> (..., M1, M2, M3): pruned DFT with row frequencies f1[0] / f2[0] (int32 device tensors) along
+    axes 1 / 2 and m3 half-spectrum bins, pruned inverse DFT with f1[1] / f2[1]; adjoint=True: Hermitian weights on the
+    forward side instead of the inverse side (the transpose of the operator with sizes and tables swapped)."""
+    _require(x, torch.float32, "x")
+    *lead, D1, D2, D3 = x.shape
+    M1, M2, M3 = (int(v) for v in out_size)
+    n = 1
+    for d in lead:
+        n *= d
+    for t in (*f1, *f2):
+        if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("uno_amd: frequency tables must be contiguous int32 device tensors")
+    J1, J2 = f1[0].numel(), f2[0].numel()
+    L = lib()
+    with torch.cuda.device(x.device):
+        y = torch.empty((*lead, M1, M2, M3), dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(1, L.uno_fft_resample3d_ws_bytes(n, D1, M1, J1, J2, int(m3))), dtype=torch.uint8, device=x.device)
+        rc = L.uno_fft_resample3d(_ptr(x), _ptr(y), _ptr(ws), n, D1, D2, D3, M1, M2, M3, J1, _ptr(f1[0]), _ptr(f1[1]), J2,
+                                  _ptr(f2[0]), _ptr(f2[1]), int(m3), float(scale), int(adjoint), int(not adjoint), _stream(x))
+    _check(rc, "uno_fft_resample3d")
+    return y
 
 
 def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=False, out=None, channel_offset=0):

@@ -113,7 +113,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     if (n_img == 0) return 0;
     Dft2dParams p;
     p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
-    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0;
+    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0; p.rowfreq = nullptr;
     if (sp_group <= 0) { sp_group = n_img; sp_stride = 0; sp_offset = 0; }          // plain layout: spectrum i of image i
     if (sp_offset < 0 || sp_stride < sp_offset + sp_group || n_img % sp_group) {
         if (!(sp_stride == 0 && sp_offset == 0 && sp_group == n_img)) {
@@ -422,10 +422,61 @@ int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, in
     if (!in || !out) { set_error("uno_cdft_axis: null pointer"); return -1; }
     CdftParams p;
     p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.C = 2 * m2 * m3; p.m1 = m1; p.m2 = m2; p.m3 = m3;
-    p.scale = scale; p.mask = mask_overlap ? 1 : 0;
+    p.scale = scale; p.mask = mask_overlap ? 1 : 0; p.rowfreq = nullptr;
     p.tw = twiddle_table(H);
     if (!p.tw) return -6;
     return launch_cdft(p, inverse != 0, (hipStream_t)stream);
+}
+
+// ---- FFT crop / resample of pointwise_op_3D (reference integral_operators.py:448-463) as pruned transforms with explicit
+// frequency tables.  Along a complex axis of length N resampled to M the reference keeps the spectrum INDICES
+// r in ([0, M/2) u [N - M/2, N)) n [0, min(N, M)) and irfftn reads index r as frequency r of a length-M transform (its trimming /
+// zero-padding happens at the end of the axis): forward frequency f_in[j] = r_j on N points, inverse frequency f_out[j] = r_j on
+// M points - the binding builds the tables, so this entry point is the general "pruned DFT - pruned inverse DFT" pair.
+long long uno_fft_resample3d_ws_bytes(int n_vol, int D1, int M1, int J1, int J2, int m3) {
+    const long long C = (long long)J2 * m3;
+    return 8LL * n_vol * ((long long)D1 * C + (long long)M1 * C + (long long)J1 * C);
+}
+
+int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
+                       int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
+                       float scale, int herm_in, int herm_out, void* stream) {
+    const char* who = "uno_fft_resample3d";
+    if (n_vol < 0 || D1 < 1 || D2 < 1 || D3 < 1 || M1 < 1 || M2 < 1 || M3 < 1) { set_error("%s: bad sizes", who); return -1; }
+    if (J1 < 2 || (J1 & 1) || J2 < 2 || (J2 & 1) || J1 > 80 || J2 > 48 || m3 < 1 || m3 > D3 / 2 + 1 || m3 > M3 / 2 + 1) {
+        set_error("%s: row counts must be even (J1=%d <= 80, J2=%d <= 48) and 1 <= modes3=%d <= n/2+1", who, J1, J2, m3);
+        return -1;
+    }
+    if (n_vol == 0) return 0;
+    if (!x || !y || !ws || !f1_in || !f1_out || !f2_in || !f2_out) { set_error("%s: null pointer", who); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const long long C = (long long)J2 * m3;
+    float* Z1 = static_cast<float*>(ws);                          // (n_vol * D1, J2, m3) c64
+    float* Z2 = Z1 + 2LL * n_vol * D1 * C;                        // (n_vol * M1, J2, m3) c64
+    float* S = Z2 + 2LL * n_vol * M1 * C;                         // (n_vol, 4, J1/2, J2/2, m3) c64
+    Dft2dParams p;
+    p.n_img = n_vol * D1; p.H = D2; p.W = D3; p.m1 = J2 / 2; p.m2 = m3; p.scale = 1.0f; p.herm = herm_in ? 1 : 0; p.mask = 0; p.bf16 = 0;
+    p.sp_group = p.n_img; p.sp_stride = 0; p.sp_offset = 0;
+    p.in = x; p.out = Z1; p.rowfreq = f2_in;
+    p.twH = twiddle_table(D2); p.twW = twiddle_table(D3);
+    if (!p.twH || !p.twW) return -6;
+    if (!dft2d_fwd_plane_applies(p)) { set_error("%s: input planes %d x %d (%d of them) are outside the plane-batched kernels' range", who, D2, D3, p.n_img); return -2; }
+    if (int rc = launch_dft2d_fwd_plane(p, s)) return rc;
+    CdftParams c;
+    c.n_img = n_vol; c.C = (int)C; c.m1 = J1 / 2; c.m2 = J2 / 2; c.m3 = m3; c.mask = 0; c.scale = 1.0f;
+    c.in = Z1; c.out = S; c.H = D1; c.rowfreq = f1_in; c.tw = twiddle_table(D1);
+    if (!c.tw) return -6;
+    if (int rc = launch_cdft(c, false, s)) return rc;
+    c.in = S; c.out = Z2; c.H = M1; c.rowfreq = f1_out; c.tw = twiddle_table(M1);
+    if (!c.tw) return -6;
+    if (int rc = launch_cdft(c, true, s)) return rc;
+    p.n_img = n_vol * M1; p.H = M2; p.W = M3; p.scale = scale; p.herm = herm_out ? 1 : 0;
+    p.sp_group = p.n_img;
+    p.in = Z2; p.out = y; p.rowfreq = f2_out;
+    p.twH = twiddle_table(M2); p.twW = twiddle_table(M3);
+    if (!p.twH || !p.twW) return -6;
+    if (!dft2d_inv_plane_applies(p)) { set_error("%s: output planes %d x %d (%d of them) are outside the plane-batched kernels' range", who, M2, M3, p.n_img); return -2; }
+    return launch_dft2d_inv_plane(p, s);
 }
 
 static int check_modes3d(const char* who, int H, int W, int T, int Ho, int Wo, int To, int m1, int m2, int m3) {

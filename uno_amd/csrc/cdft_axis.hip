@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void cdft_fwd_kernel(CdftParams p) {
     for (int mt = 0; mt < MT; ++mt) {
         const int j = 16 * mt + r16;
         jvalid[mt] = j < 2 * m1;
-        const int K = jvalid[mt] ? corner_freq(j, m1, H) : 0;
+        const int K = jvalid[mt] ? (p.rowfreq ? p.rowfreq[j] : corner_freq(j, m1, H)) : 0;
         idx[mt] = 8u * (unsigned)(((long long)K * kk) % H);
         step4[mt] = 8u * (unsigned)(((long long)4 * K) % H);
     }
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void cdft_inv_kernel(CdftParams p) {
 #pragma unroll
         for (int ks = 0; ks < KSJ; ++ks) {
             const int j = 4 * ks + kk;
-            const unsigned id = (j >= m1) ? wrap_sub(aj, b2, H8) : aj;
+            unsigned id = (j >= m1) ? wrap_sub(aj, b2, H8) : aj;
+            if (p.rowfreq) id = 8u * (unsigned)(((long long)p.rowfreq[min(j, 2 * m1 - 1)] * hA) % H);
             const float2 tw = lds_tw(sTw, id);
             // e^{+i theta} (or + i oi) = (c or - s oi) + i (c oi + s or)
             Zr = mfma16(tw.x, Or[ks], Zr);

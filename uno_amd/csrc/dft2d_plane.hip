@@ -32,7 +32,7 @@ namespace uno {
 
 constexpr int PL_WAVES = 4;                 // waves per workgroup
 constexpr int PL_MAX_ELEMS = 2048;          // largest image (floats) taken by K3p
-constexpr int PL_FWD_MAX_ELEMS = 1536;      // ... by K1p (the next image waits in registers: 6 x 16 bytes per lane)
+constexpr int PL_FWD_MAX_ELEMS = 1792;      // ... by K1p (the next image waits in registers: 7 x 16 bytes per lane)
 constexpr int PL_MIN_IMAGES = 128;          // below this K1 / K3 are as good (the chip is not filled either way)
 constexpr size_t PL_MAX_LDS = 64 * 1024;
 constexpr int PL_IMG_PAD = 8;                // zero floats behind a wave's image copy (stage A reads rows in 8-column steps)
@@ -61,7 +61,7 @@ static bool plane_shape_ok(const Dft2dParams& p) {
     static const bool off = getenv("UNO_NO_PLANE_KERNELS") != nullptr;          // developer A/B switch
     if (off || p.bf16) return false;
     const long long hw = (long long)p.H * p.W;
-    return p.n_img >= PL_MIN_IMAGES && hw >= 16 && hw <= PL_MAX_ELEMS && p.W <= 64 && 2 * p.m1 <= 48 && 2 * p.m2 <= 32 &&
+    return (p.n_img >= PL_MIN_IMAGES || p.rowfreq) && hw >= 16 && hw <= PL_MAX_ELEMS && p.W <= 64 && 2 * p.m1 <= 48 && 2 * p.m2 <= 32 &&
            p.m1 >= 1 && p.m2 >= 1;
 }
 bool dft2d_fwd_plane_applies(const Dft2dParams& p) { return plane_shape_ok(p) && p.H * p.W <= PL_FWD_MAX_ELEMS && fwd_plane_lds(p) <= PL_MAX_LDS; }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_fwd_plane_kernel(Dft2d
         const int ln = e & 63, step = (e >> 6) % (nrt * 4), mt = (e >> 6) / (nrt * 4);
         const int j = 16 * mt + (ln & 15), h = 16 * (step >> 2) + 4 * (ln >> 4) + (step & 3);
         float2 v = make_float2(0.f, 0.f);
-        if (j < 2 * m1 && h < H) v = p.twH[(unsigned)(corner_freq(j, m1, H) * h) % (unsigned)H];
+        if (j < 2 * m1 && h < H) v = p.twH[(unsigned)((p.rowfreq ? p.rowfreq[j] : corner_freq(j, m1, H)) * h) % (unsigned)H];
         sTwB[e] = v;
     }
     for (int e = tid; e < 2 * kw2 * NTN * 64; e += 64 * PL_WAVES) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2d
         const int ln = e & 63, ks = (e >> 6) % KSJ, t = (e >> 6) / KSJ;
         const int h = 16 * t + (ln & 15), j = 4 * ks + (ln >> 4);
         float2 v = make_float2(0.f, 0.f);
-        if (j < 2 * m1 && h < H) v = p.twH[(unsigned)(corner_freq(j, m1, H) * h) % (unsigned)H];
+        if (j < 2 * m1 && h < H) v = p.twH[(unsigned)((p.rowfreq ? p.rowfreq[j] : corner_freq(j, m1, H)) * h) % (unsigned)H];
         sTwB[e] = v;
     }
     for (int e = tid; e < nwt * NTN * 4 * 64; e += 64 * PL_WAVES) {

@@ -97,6 +97,7 @@ struct Dft2dParams {
     // images can face channels [sp_offset, sp_offset + C1) of a (B, sp_stride) spectrum tensor (two-source blocks)
     int sp_group, sp_stride, sp_offset;
     int bf16;               // 1: the images (forward input / inverse output) are bfloat16; spectra stay complex64
+    const int* rowfreq;     // optional (plane-batched kernels only): frequency of spectrum row j, j < 2*m1, instead of the corner rule
 };
 
 __device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {
@@ -126,6 +127,7 @@ struct CdftParams {
     int n_img, H, C, m1, m2, m3;
     float scale;
     int mask;               // zero lo-corner rows overwritten by the hi corner (on the spectrum side)
+    const int* rowfreq;     // optional: frequency of spectrum row j, j < 2*m1, instead of the corner rule
 };
 
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure

@@ -628,6 +628,57 @@ class SpectralConv3d_Uno(nn.Module):
                                self.dim1, self.dim2, self.dim3)
 
 
+def _kept_indices(n_in: int, n_out: int):
+    """Spectrum indices along a complex axis that survive the reference's corner copies into an input-sized zero spectrum
+    (`ft_u[:h] = ft[:h]`, `ft_u[-h:] = ft[-h:]`, h = n_out // 2 - with Python's `-0:` meaning everything) and irfftn's trimming
+    to n_out entries (integral_operators.py:450-463)."""
+    h = n_out // 2
+    idx = set(range(0, min(h, n_in)))
+    idx |= set(range(n_in)) if h == 0 else set(range(max(n_in - h, 0), n_in))
+    return sorted(r for r in idx if r < min(n_in, n_out))
+
+
+_RESAMPLE3D_TABLES = {}
+
+
+def _resample3d_plan(din, dout, device):
+    """(f1, f2, m3) for _native.fft_resample3d, or None when the shape is outside the kernels' range (odd row counts, too many
+    rows or bins, planes too large): the caller then takes the stock FFT path."""
+    key = (tuple(din), tuple(dout), str(device))
+    if key not in _RESAMPLE3D_TABLES:
+        plan = None
+        k1, k2 = _kept_indices(din[0], dout[0]), _kept_indices(din[1], dout[1])
+        m3 = min(dout[2] // 2, din[2] // 2 + 1)
+        ok = (len(k1) >= 2 and len(k1) % 2 == 0 and len(k1) <= 80 and len(k2) >= 2 and len(k2) % 2 == 0 and len(k2) <= 48
+              and 1 <= m3 <= 16 and 16 <= din[1] * din[2] <= 1792 and 16 <= dout[1] * dout[2] <= 1792
+              and din[2] <= 64 and dout[2] <= 64)
+        if ok:
+            t1 = torch.tensor(k1, dtype=torch.int32, device=device)
+            t2 = torch.tensor(k2, dtype=torch.int32, device=device)
+            plan = (t1, t2, m3)
+        _RESAMPLE3D_TABLES[key] = plan
+    return _RESAMPLE3D_TABLES[key]
+
+
+class _FftResample3dFn(torch.autograd.Function):
+    """irfftn(corner-copy(rfftn(x)), s=size) of pointwise_op_3D on the pruned-DFT kernels (K1p, K5, K6, K3p with explicit
+    frequency tables); backward is the transpose: the same kernels with sizes swapped and the Hermitian weights on the other side."""
+
+    @staticmethod
+    def forward(ctx, x, size, plan):
+        t1, t2, m3 = plan
+        ctx.plan, ctx.din, ctx.dout = plan, tuple(x.shape[-3:]), tuple(size)
+        scale = 1.0 / (size[0] * size[1] * size[2])
+        return _native.fft_resample3d(_plain(x), size, (t1, t1), (t2, t2), m3, scale, adjoint=False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        t1, t2, m3 = ctx.plan
+        scale = 1.0 / (ctx.dout[0] * ctx.dout[1] * ctx.dout[2])
+        return _native.fft_resample3d(_plain(gy), ctx.din, (t1, t1), (t2, t2), m3, scale, adjoint=True), None, None
+
+
 class pointwise_op_3D(nn.Module):
     """1x1x1 convolution + the reference's FFT crop/resample (quirks kept bug-for-bug: unnormalised
     forward transform, corners copied into an INPUT-sized zero spectrum, irfftn(s=output dims) that
@@ -659,6 +710,10 @@ class pointwise_op_3D(nn.Module):
             dim1, dim2, dim3 = self.dim1, self.dim2, self.dim3
         on_device = x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
         out = channel_mix(x.contiguous(), self.conv.weight, self.conv.bias) if on_device else self.conv(x)
+        if on_device:
+            plan = _resample3d_plan(out.shape[-3:], (dim1, dim2, dim3), out.device)
+            if plan is not None:
+                return _FftResample3dFn.apply(out, (dim1, dim2, dim3), plan)
         spec = torch.fft.rfftn(out, dim=[-3, -2, -1])
         h1, h2, h3 = dim1 // 2, dim2 // 2, dim3 // 2
         if on_device:
