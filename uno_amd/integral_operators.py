@@ -17,7 +17,8 @@ tensor that is not on a HIP device raises ``RuntimeError``.
 The rest of an operator block runs on the same library for float32 device tensors: the point-wise branch (1x1
 convolution = channel-mix kernels, bicubic anti-aliased resampling = banded separable kernels) accumulates into the
 spectral branch's output buffer, InstanceNorm (+ GELU) is one kernel; only the GELU of non-normalised blocks and the
-FFT-based resampling of pointwise_op_3D are stock PyTorch-ROCm ops (SpectralConv1d_Uno runs on the 2-D kernels, one row).  CPU tensors take stock torch ops in these helper
+skip concatenations are stock PyTorch-ROCm ops (SpectralConv1d_Uno runs on the 2-D kernels, one row; pointwise_op_3D's FFT
+resampling on the pruned-DFT kernels with explicit frequency tables).  CPU tensors take stock torch ops in these helper
 layers (they are not part of the spectral path and the CPU-side harness tests use them with the oracle blocks).
 """
 from __future__ import annotations
@@ -685,7 +686,7 @@ class pointwise_op_3D(nn.Module):
     trims/zero-pads at the END of each axis, identity trilinear resize) - reference
     integral_operators.py:430-468.  The convolution runs on the channel-mix kernels (K8 / K9) for float32 device
     tensors - MIOpen executes a 1x1x1 Conv3d with its naive direct kernels, 0.9 s of a 2.2 s first NS-3D step - the
-    FFT resampling is stock torch (rocFFT); the trilinear resize to the size the tensor already has is an exact
+    FFT resampling runs on the pruned-DFT kernels (_FftResample3dFn; stock rocFFT outside their shape range); the trilinear resize to the size the tensor already has is an exact
     identity under align_corners=True and is skipped on the device."""
 
     def __init__(self, in_codim, out_codim, dim1, dim2, dim3):
