@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) on a machine without a HIP device; an explicit `-m gpu` run on a box that HAS a
+    device but lacks the native library still fails loudly inside the tests (no silent fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no HIP device visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 class Case:
     """Attribute view over the '<case>.<field>' keys of one golden npz."""
 

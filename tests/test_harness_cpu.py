@@ -201,3 +201,47 @@ def test_flat_gradients_rebind_after_zero_grad_set_to_none():
     lin(torch.ones(2, 4)).sum().backward()
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(lin.parameters(), fg.views))
     assert torch.allclose(fg.flat[:12].view(3, 4), torch.full((3, 4), 2.0)) and torch.allclose(fg.flat[12:], torch.full((3,), 2.0))
+
+
+def test_flat_gradients_odd_real_prefix_before_complex_param():
+    """A complex parameter behind an odd number of real entries still gets a valid complex view."""
+    from uno_amd.harness.train import FlatGradients
+    a = torch.nn.Parameter(torch.zeros(3))
+    z = torch.nn.Parameter(torch.zeros(2, 2, dtype=torch.cfloat))
+    b = torch.nn.Parameter(torch.zeros(5))
+    z2 = torch.nn.Parameter(torch.zeros(3, dtype=torch.cfloat))
+    fg = FlatGradients([a, z, b, z2], bucket_mb=1e-5)
+    assert z.grad.is_complex() and tuple(z.grad.shape) == (2, 2) and tuple(z2.grad.shape) == (3,)
+    loss = (a * 2).sum() + (z * (1 + 2j)).real.sum() + (b * 3).sum() + (z2 * (0 + 1j)).imag.sum()
+    loss.backward()
+    assert torch.allclose(a.grad, torch.full((3,), 2.0)) and torch.allclose(b.grad, torch.full((5,), 3.0))
+    assert torch.allclose(z.grad, torch.full((2, 2), 1 - 2j, dtype=torch.cfloat))
+    # every view lies inside the flat buffer and the buckets cover all of them
+    lo = min(s for s, _ in fg.buckets)
+    hi = max(e for _, e in fg.buckets)
+    assert lo == 0 and hi <= fg.flat.numel()
+    fg.zero_()
+    assert float(z.grad.abs().sum()) == 0.0 and float(a.grad.abs().sum()) == 0.0
+
+
+def test_complex_adam_per_parameter_step_counts():
+    """A parameter whose grad is None on some steps keeps its own step count and bias correction (reference Adam.py keeps
+    `state['step']` per parameter) instead of tripping an assertion."""
+    torch.manual_seed(0)
+    p1 = torch.nn.Parameter(torch.randn(4))
+    p2 = torch.nn.Parameter(torch.randn(3, dtype=torch.cfloat))
+    q1, q2 = (torch.nn.Parameter(p.detach().clone()) for p in (p1, p2))
+    opt = ComplexAdam([p1, p2], lr=1e-2)
+    ref1, ref2 = ComplexAdam([q1], lr=1e-2), ComplexAdam([q2], lr=1e-2)
+    for t in range(4):
+        g1, g2 = torch.randn(4), torch.randn(3, dtype=torch.cfloat)
+        p1.grad, q1.grad = g1.clone(), g1.clone()
+        ref1.step()
+        if t % 2 == 0:                      # p2 takes part in every other step only
+            p2.grad, q2.grad = g2.clone(), g2.clone()
+            ref2.step()
+        else:
+            p2.grad = None
+        opt.step()
+    assert opt.state[p1]["step"] == 4 and opt.state[p2]["step"] == 2
+    assert torch.allclose(p1, q1) and torch.allclose(p2, q2)

@@ -40,6 +40,33 @@ def test_operator_block_2d_golden(name):
         assert np.linalg.norm((got - g).ravel()) <= 2e-4 * np.linalg.norm(g.ravel()) + floor, k
 
 
+@pytest.mark.parametrize("name", ["pw3d_shrink", "pw3d_grow"])
+def test_pointwise_op_3d_golden(name):
+    """The product pointwise_op_3D (K8 1x1x1 convolution + bug-compatible FFT crop / resample) against the reference's output:
+    `pw3d_grow` runs on the pruned-DFT kernels (uno_fft_resample3d), `pw3d_shrink` has an odd kept-row count and takes the
+    stock-FFT branch of the same module - both must reproduce reference integral_operators.py:448-467."""
+    from uno_amd.integral_operators import pointwise_op_3D, _resample3d_plan
+    c = Case(ZB, name)
+    B, Ci, Co, *dims = [int(v) for v in c.meta]
+    din, dout = tuple(dims[:3]), tuple(dims[3:])
+    pw = pointwise_op_3D(Ci, Co, *dout)
+    with torch.no_grad():
+        pw.conv.weight.copy_(torch.from_numpy(c.weight))
+        pw.conv.bias.copy_(torch.from_numpy(c.bias))
+    pw = pw.to(dev())
+    assert (_resample3d_plan(din, dout, dev()) is not None) == (name == "pw3d_grow")
+    x = torch.from_numpy(c.x).to(dev()).requires_grad_(True)
+    y = pw(x)
+    assert tuple(y.shape) == tuple(c.y.shape)
+    assert rel_err(y.detach().cpu().numpy(), c.y) < 1e-4
+    # adjoint identity of the (linear) operator: <pw(x) - pw(0), g> == <x, pw^T g>
+    g = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, g)
+    lhs = float(((y - pw(torch.zeros_like(x))).detach() * g).double().sum())
+    rhs = float((x.detach() * gx).double().sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1e-6)
+
+
 def test_dim_mutation_quirk():
     from uno_amd.integral_operators import OperatorBlock_2D
     c = Case(ZB, "dimmut")
@@ -59,26 +86,45 @@ def test_uno9_training_steps_match_reference():
     c = Case(ZH, "uno9")
     S, B, width, pad = [int(v) for v in c.meta]
     model = UNO_9(3, width, pad=pad)
-    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    sd0 = {k: v.copy() for k, v in c.sub("sd").items()}
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd0.items()}, strict=True)
     model = model.to(dev())
     a, u = torch.from_numpy(c.a).to(dev()), torch.from_numpy(c.u).to(dev())
     with torch.no_grad():
         pred = model(a).reshape(B, S, S)
-    assert rel_err(pred.cpu().numpy(), c.pred0) < 1e-3
+    assert rel_err(pred.cpu().numpy(), c.pred0) < 1e-4
     tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
     losses = []
     gmax = max(float(getattr(c, f"gradnorm.{k}")) for k, _ in model.named_parameters())
+    # a convolution bias in front of an InstanceNorm has an exactly-zero true gradient: what the reference stores for it is
+    # rounding residue, and Adam turns that residue into +-lr steps of arbitrary sign
+    noise = {"conv1.w.conv.bias", "conv4.w.conv.bias"}
     for step in range(3):
         losses.append(float(tr.step(a, u)))
         if step == 0:
             for k, p in model.named_parameters():
                 ref = float(getattr(c, f"gradnorm.{k}"))
-                # floor: conv biases in front of an InstanceNorm have a zero true gradient (pure rounding noise)
-                assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-3 * ref + 1e-6 * gmax, k
-    assert np.allclose(losses, c.losses, rtol=1e-3)
+                assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-4 * ref + 1e-6 * gmax, k
+            # element-wise gradients of every small tensor the reference stored (oracle/gen_golden.py: numel <= 4096)
+            params = dict(model.named_parameters())
+            for k, g in c.sub("grad").items():
+                got = params[k].grad.cpu().numpy()
+                assert np.linalg.norm((got - g).ravel()) <= 2e-4 * np.linalg.norm(g.ravel()) + 1e-6 * gmax, k
+    assert np.allclose(losses, c.losses, rtol=2e-4)
+    params = dict(model.named_parameters())
     for k, p in model.named_parameters():
         ref = float(getattr(c, f"after3.norm.{k}"))
-        assert abs(float(torch.linalg.vector_norm(p)) - ref) <= 1e-3 * ref + 1e-8, k
+        assert abs(float(torch.linalg.vector_norm(p)) - ref) <= 1e-4 * ref + 1e-8, k
+    # the UPDATE itself, element by element: a parameter moves ~3e-3 in three Adam steps, so compare (after - before)
+    checked = 0
+    for k, v in c.sub("after3").items():
+        if k.startswith("norm.") or k.startswith("sum.") or k in noise:
+            continue
+        got = params[k].detach().cpu().numpy()
+        d_ref, d_got = v - sd0[k], got - sd0[k]
+        assert np.linalg.norm((d_got - d_ref).ravel()) <= 2e-2 * np.linalg.norm(d_ref.ravel()), k
+        checked += 1
+    assert checked >= 15
 
 
 def test_model_product_vs_oracle_blocks_same_weights():

@@ -23,7 +23,7 @@ class ComplexAdam(Optimizer):
         """K10 over all device tensors of the group in one native call; the pointer tables are rebuilt only when a
         parameter or gradient buffer moved (FlatGradients keeps them fixed)."""
         from .. import _native
-        gid = next(i for i, g in enumerate(self.param_groups) if g is group)
+        gid = (next(i for i, g in enumerate(self.param_groups) if g is group), len(params))
         plan = self._plans.get(gid)
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
                     for p in params)       # rebuilt if any buffer moved (e.g. load_state_dict replaces the moments)
@@ -46,9 +46,9 @@ class ComplexAdam(Optimizer):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
-            ps, gs, ms, vs, steps = [], [], [], [], set()
-            cplx = []
-            dev_p, dev_steps = [], set()
+            # parameters are bucketed by their own step count (the reference keeps a per-parameter step and bias correction,
+            # Adam.py:27-52): a parameter whose grad was None on some steps simply lands in another bucket
+            host, devb = {}, {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -60,35 +60,30 @@ class ComplexAdam(Optimizer):
                     st["exp_avg_sq"] = torch.zeros(p.shape, dtype=st["exp_avg"].dtype, device=p.device)
                 st["step"] += 1
                 if p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous() and p.grad.is_contiguous():
-                    dev_p.append(p)
-                    dev_steps.add(st["step"])
-                    continue
-                steps.add(st["step"])
-                ps.append(self._real(p))
-                gs.append(self._real(p.grad))
-                ms.append(st["exp_avg"])
-                vs.append(st["exp_avg_sq"])
-                cplx.append(p.is_complex())
-            if dev_p:
-                assert len(dev_steps) == 1, "parameters of one group must be stepped together"
-                self._device_step(group, dev_p, dev_steps.pop(), lr, beta1, beta2, eps, wd)
-            if not ps:
-                continue
-            assert len(steps) == 1, "parameters of one group must be stepped together"
-            t = steps.pop()
-            bc1 = 1 - beta1 ** t
-            bc2 = 1 - beta2 ** t
-            if wd != 0:
-                gs = torch._foreach_add(gs, ps, alpha=wd)
-            torch._foreach_mul_(ms, beta1)
-            torch._foreach_add_(ms, gs, alpha=1 - beta1)
-            sq = torch._foreach_mul(gs, gs)
-            sq = [s.sum(-1) if c else s for s, c in zip(sq, cplx)]       # |g|^2 for complex entries
-            torch._foreach_mul_(vs, beta2)
-            torch._foreach_add_(vs, sq, alpha=1 - beta2)
-            denom = torch._foreach_sqrt(vs)
-            torch._foreach_div_(denom, math.sqrt(bc2))
-            torch._foreach_add_(denom, eps)
-            denom = [d.unsqueeze(-1) if c else d for d, c in zip(denom, cplx)]
-            torch._foreach_addcdiv_(ps, ms, denom, value=-lr / bc1)
+                    devb.setdefault(st["step"], []).append(p)
+                else:
+                    host.setdefault(st["step"], []).append(p)
+            for t, dev_p in devb.items():
+                self._device_step(group, dev_p, t, lr, beta1, beta2, eps, wd)
+            for t, plist in host.items():
+                ps = [self._real(p) for p in plist]
+                gs = [self._real(p.grad) for p in plist]
+                ms = [self.state[p]["exp_avg"] for p in plist]
+                vs = [self.state[p]["exp_avg_sq"] for p in plist]
+                cplx = [p.is_complex() for p in plist]
+                bc1 = 1 - beta1 ** t
+                bc2 = 1 - beta2 ** t
+                if wd != 0:
+                    gs = torch._foreach_add(gs, ps, alpha=wd)
+                torch._foreach_mul_(ms, beta1)
+                torch._foreach_add_(ms, gs, alpha=1 - beta1)
+                sq = torch._foreach_mul(gs, gs)
+                sq = [s.sum(-1) if c else s for s, c in zip(sq, cplx)]       # |g|^2 for complex entries
+                torch._foreach_mul_(vs, beta2)
+                torch._foreach_add_(vs, sq, alpha=1 - beta2)
+                denom = torch._foreach_sqrt(vs)
+                torch._foreach_div_(denom, math.sqrt(bc2))
+                torch._foreach_add_(denom, eps)
+                denom = [d.unsqueeze(-1) if c else d for d, c in zip(denom, cplx)]
+                torch._foreach_addcdiv_(ps, ms, denom, value=-lr / bc1)
         return loss

@@ -41,11 +41,14 @@ class FlatGradients:
         self.params = [p for p in params if p.requires_grad]
         sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
         dev = self.params[0].device
-        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        n_cplx = sum(1 for p in self.params if p.is_complex())
+        self.flat = torch.zeros(sum(sizes) + n_cplx, dtype=torch.float32, device=dev)      # + room for the alignment gaps
         offsets = []
         self.views = []
         off = 0
         for p, n in zip(self.params, sizes):
+            if p.is_complex() and off % 2:
+                off += 1                    # view_as_complex needs an even element offset (odd count of real entries in front)
             seg = self.flat[off:off + n]
             if p.is_complex():
                 view = torch.view_as_complex(seg.view(*p.shape, 2))
@@ -162,6 +165,7 @@ def ns3d_loss(model, x, y):
 class GraphedStep:
     """Forward + loss + backward of one training step captured ONCE into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm)
     and replayed per step; the optimiser update stays eager (its bias correction takes the step count as a kernel argument).
+    Single rank only: no gradient all-reduce is issued between the replay and the update (DarcyTrainer is the data-parallel step).
 
     For launch-bound steps: the NS-2D roll-out (reference ns_train_2d.py:46-68) issues ~7400 kernels of 5-40 us per step and
     the host needs ~95 ms to enqueue them - as long as the device needs to run them.  A replay has no per-launch host work.
@@ -197,7 +201,7 @@ class GraphedStep:
             dst.copy_(src, non_blocking=True)
         self.graph.replay()                             # gradients are overwritten by the captured backward
         self.opt.step()
-        return self.static_loss
+        return self.static_loss.detach().clone()        # the graph-owned scalar is overwritten by the next replay
 
 
 class DarcyTrainer:
