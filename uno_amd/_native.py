@@ -13,7 +13,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UNO_AMD_LIB") or os.path.join(_HERE, "lib", "libuno_spectral.so")   # env override: developer A/B builds
+LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
 ABI_VERSION = 3
 
 _lib = None

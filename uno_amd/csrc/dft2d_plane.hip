@@ -20,13 +20,8 @@
 #include "uno_common.h"
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <mutex>
 #include <vector>
-
-#ifndef UNO_ABLATE
-#define UNO_ABLATE 0        // developer ablation builds only (tools/ablate.sh); 0 = product
-#endif
 
 namespace uno {
 
@@ -58,8 +53,7 @@ static size_t inv_plane_lds(const Dft2dParams& p) {
     return (size_t)g.nrt * 4 * g.mt * 64 * 8 + (size_t)g.nwt * g.ntn * 4 * 64 * 4;
 }
 static bool plane_shape_ok(const Dft2dParams& p) {
-    static const bool off = getenv("UNO_NO_PLANE_KERNELS") != nullptr;          // developer A/B switch
-    if (off || p.bf16) return false;
+    if (p.bf16) return false;
     const long long hw = (long long)p.H * p.W;
     return (p.n_img >= PL_MIN_IMAGES || p.rowfreq) && hw >= 16 && hw <= PL_MAX_ELEMS && p.W <= 64 && 2 * p.m1 <= 48 && 2 * p.m2 <= 32 &&
            p.m1 >= 1 && p.m2 >= 1;
@@ -115,7 +109,6 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_fwd_plane_kernel(Dft2d
         cs[tn] = l < m2 ? p.scale * (p.herm ? herm_weight(l, W) : 1.0f) : 0.f;
     }
 
-    if (UNO_ABLATE & 64) return;
     // The image (contiguous, 4-byte aligned) is fetched in 16-byte pieces, <= PL_PIECES per lane, one image AHEAD: the loads
     // of image i+1 are issued before image i is transformed and are written to the wave's LDS buffer when image i is done.
     // Piece q starts at float min(4 q, HW - 4): the last one is pulled back inside the image instead of running past it.
@@ -126,7 +119,7 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_fwd_plane_kernel(Dft2d
         const float* src = p.in + (size_t)min(img, p.n_img - 1) * HW;
 #pragma unroll
         for (int i = 0; i < PL_PIECES; ++i)
-            if (i < pieces && !(UNO_ABLATE & 128)) pre[i] = *reinterpret_cast<const f4u*>(src + min(4 * min(lane + 64 * i, nq - 1), HW - 4));
+            if (i < pieces) pre[i] = *reinterpret_cast<const f4u*>(src + min(4 * min(lane + 64 * i, nq - 1), HW - 4));
     };
     const int img0 = blockIdx.x * PL_WAVES + wave, img_step = gridDim.x * PL_WAVES;
     // LDS executes a wave's instructions in order, so the wave needs no barrier around its private buffer - only the
@@ -164,7 +157,7 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_fwd_plane_kernel(Dft2d
 #pragma unroll
             for (int tn = 0; tn < NTN; ++tn) { X[mt][tn] = f32x4{0, 0, 0, 0}; X2[mt][tn] = f32x4{0, 0, 0, 0}; }
 
-        const int nrt_run = (UNO_ABLATE & 256) ? 1 : nrt;
+        const int nrt_run = nrt;
         for (int t = 0; t < nrt_run; ++t) {
             // rows past H: finite data of the last row, zero twiddle in stage B; columns past W: the next row's (finite) data
             // or the zero pad behind the image, zero twiddle in the table
@@ -265,7 +258,6 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2d
         cs[tn] = l < m2 ? p.scale * (p.herm ? herm_weight(l, W) : 1.0f) : 0.f;
     }
 
-    if (UNO_ABLATE & 64) return;
     // The spectrum of image i+1 is fetched (raw, clamped addresses) while image i is transformed; scale, Hermitian weight
     // and the later-wins row mask are applied when it becomes the current operand.
     float Ov[KSJ][NTN], O2[KSJ][NTN], On[KSJ][NTN];
@@ -324,7 +316,6 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2d
             const int h = 16 * t + r16;
             auto put = [&](const f32x4& Y, int wt) {
                 const int w0 = 16 * wt + 4 * kk;
-                if (UNO_ABLATE & 128) { asm volatile("" ::"v"(Y[0]), "v"(Y[1]), "v"(Y[2]), "v"(Y[3])); return; }
                 if (h < H) {
                     float* row = dst + (size_t)h * W;
                     if (w0 + 3 < W) {
@@ -336,7 +327,7 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2d
                     }
                 }
             };
-            const int nwt_run = (UNO_ABLATE & 256) ? 1 : nwt;
+            const int nwt_run = nwt;
             int wt = 0;
             for (; wt + 2 <= nwt_run; wt += 2) {          // two column tiles at a time: two independent MFMA chains
                 f32x4 Y0 = f32x4{0, 0, 0, 0}, Y1 = f32x4{0, 0, 0, 0};

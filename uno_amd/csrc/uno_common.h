@@ -98,6 +98,7 @@ struct Dft2dParams {
     int sp_group, sp_stride, sp_offset;
     int bf16;               // 1: the images (forward input / inverse output) are bfloat16; spectra stay complex64
     const int* rowfreq;     // optional (plane-batched kernels only): frequency of spectrum row j, j < 2*m1, instead of the corner rule
+    int nw;                 // set by the K1 / K3 launchers: waves per image (a workgroup holds blockDim / (64 nw) images)
 };
 
 __device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {
