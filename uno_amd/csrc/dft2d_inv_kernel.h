@@ -275,6 +275,210 @@ __global__ __launch_bounds__(64 * INV_MAX_WAVES) void dft2d_inv_kernel(Dft2dPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- K3, full-tile form
+// What bounds the chunked kernel above is not arithmetic but the SHAPE of its stores (tools/probes/store_probe.hip, 1024
+// images of 416 x 421 floats, no arithmetic at all): 256-byte row segments at 4-byte alignment stream at 3.1 TB/s, the same
+// segments snapped to 64-byte boundaries at 4.0, and a wave that writes its 16-row tile as ONE contiguous run of whole,
+// 128-byte-aligned cache lines at 5.6 TB/s.  Every partially written line costs about as much as a whole one.  Rows of an odd
+// length start at 4-byte alignment, so whole lines straddle rows: this form builds the complete 16 x W tile in LDS (the tile
+// is one contiguous 16 W float run of the image) at the same offset modulo 128 bytes as in memory and writes it out as 1 KB
+// per instruction, whole lines only.  With one wave per image the partial line at the end of a tile is carried into the next
+// tile's buffer, so an image is written with two partial lines in total.  27 KB of LDS per wave (421 columns) allow four waves
+// per CU - one per SIMD, which is what the MFMA chains need when the stores are asynchronous; the kernel is then bound by HBM
+// writes at the contiguous-stream rate.
+template <int KS, int JT>
+__global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
+    constexpr int NT = (KS + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = p.H, W = p.W, m1 = p.m1, m2 = p.m2;
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int NWT = nthreads >> 6;
+    const int NW = p.nw;
+    const int Wh = W >> 1;
+    const int nwt = (Wh + 16) >> 4;
+    float2* sTabA = reinterpret_cast<float2*>(smem);                      // [nwt][KS][64]
+    float2* sTwH = sTabA + nwt * KS * 64;
+    float* sTile = reinterpret_cast<float*>(sTwH + ((H + 1) & ~1));        // [NWT][tile_stride], 16-byte aligned
+    const int tile_stride = (16 * W + 32 + 64 + 3) & ~3;                   // tile + alignment phase + one dump slot per lane
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int r16 = lane & 15;
+    const int kk = lane >> 4;
+    const unsigned H8 = 8u * H;
+
+    for (int n = tid; n < H; n += nthreads) sTwH[n] = p.twH[n];
+    for (int e = tid; e < nwt * KS * 64; e += nthreads) {
+        const int ln = e & 63, q = e >> 6;
+        const int sp = q % KS, wt = q / KS;
+        const unsigned l = (unsigned)min(4 * sp + (ln >> 4), m2 - 1);
+        const unsigned w = (unsigned)(16 * wt + (ln & 15));
+        sTabA[e] = p.twW[(l * w) % (unsigned)W];
+    }
+    __syncthreads();
+
+    const int slot = wave / NW, wsub = wave - slot * NW;
+    const int image = blockIdx.x * (NWT / NW) + slot;
+    if (image >= p.n_img) return;               // no barrier below
+
+    constexpr int KSK = 2 * JT + 1;
+    const int ksk = (m1 + 4) >> 2;
+    const float2* O = reinterpret_cast<const float2*>(p.in) + spectrum_index(p, image) * 2 * m1 * m2;
+    float Pr[NT][KSK], Pi[NT][KSK], Mr[NT][KSK], Mi[NT][KSK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int l = 16 * t + 4 * (r16 & 3) + (r16 >> 2);
+        const float cs = p.scale * ((p.herm && l < m2) ? herm_weight(l, W) : 1.0f);
+#pragma unroll
+        for (int ks = 0; ks < KSK; ++ks) {
+            const int k = 4 * ks + kk;
+            float2 vp = make_float2(0.f, 0.f), vm = make_float2(0.f, 0.f);
+            if (l < m2 && k < m1 && !(p.mask && !row_survives(k, m1, H))) vp = O[(size_t)k * m2 + l];
+            if (l < m2 && k >= 1 && k <= m1) vm = O[(size_t)(2 * m1 - k) * m2 + l];
+            Pr[t][ks] = (vp.x + vm.x) * cs; Pi[t][ks] = (vp.y + vm.y) * cs;
+            Mr[t][ks] = (vp.x - vm.x) * cs; Mi[t][ks] = (vp.y - vm.y) * cs;
+        }
+    }
+
+    float* img = p.out + (size_t)image * H * W;
+    const int nrt = (H + 15) >> 4;
+    float* buf = sTile + (size_t)wave * tile_stride;
+    const int dump = 16 * W + 32 + lane;                    // where guarded-out elements go
+    const float2* tabLane = sTabA + lane;
+    const int wfast_hi = W - Wh - 1;                        // largest w whose mirror column W - w lies in the right half
+    const bool chain = NW == 1;                             // consecutive tiles by one wave: carry the partial line
+
+    for (int rt = wsub; rt < nrt; rt += NW) {
+        float* tile = img + (size_t)rt * 16 * W;
+        const int rows = min(16, H - 16 * rt);
+        const int phase = (int)((reinterpret_cast<uintptr_t>(tile) >> 2) & 31);       // LDS index == memory offset (mod 128 B)
+        // ---- stage B'
+        const unsigned hB = (unsigned)min(16 * rt + r16, H - 1);
+        const unsigned a4 = 8u * ((4u * hB) % (unsigned)H);
+        unsigned aj = 8u * (((unsigned)kk * hB) % (unsigned)H);
+        f32x4 Ur[NT], Ui[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { Ur[t] = f32x4{0, 0, 0, 0}; Ui[t] = f32x4{0, 0, 0, 0}; }
+        float2 twb = lds_tw(sTwH, aj);
+#pragma unroll
+        for (int ks = 0; ks < KSK; ++ks) {
+            aj = wrap_add(aj, a4, H8);
+            const float2 twn = lds_tw(sTwH, aj);
+            if (ks < ksk) {
+                const float ns = -twb.y;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    Ur[t] = mfma16(Pr[t][ks], twb.x, Ur[t]);
+                    Ui[t] = mfma16(Pi[t][ks], twb.x, Ui[t]);
+                    Ur[t] = mfma16(Mi[t][ks], ns, Ur[t]);
+                    Ui[t] = mfma16(Mr[t][ks], twb.y, Ui[t]);
+                }
+            }
+            twb = twn;
+        }
+
+        // ---- stage A' into the LDS tile: lane (h = r16, g = kk) owns columns 16 wt + 4 g + e and their mirrors W - (...).
+        // One wave per SIMD: the MFMA pipe only stays busy if nothing in the instruction stream waits for the MFMAs just
+        // issued, so the results of a column tile are staged while the NEXT tile's chain runs (two accumulator sets,
+        // ping-pong, no copies), and interior tiles take a branch-free path.
+        const int rowbase = phase + r16 * W;
+        const bool row_ok = r16 < rows;
+        auto chain_mfma = [&](int wt, f32x4& Ey, f32x4& Dy) {
+            const float2* cur = tabLane + (size_t)wt * (KS * 64);
+            float2 tw[KS];
+#pragma unroll
+            for (int sp = 0; sp < KS; ++sp) tw[sp] = cur[sp * 64];
+            Ey = f32x4{0, 0, 0, 0}; Dy = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int sp = 0; sp < KS; ++sp) {
+                Ey = mfma16(tw[sp].x, Ur[sp >> 2][sp & 3], Ey);
+                Dy = mfma16(tw[sp].y, Ui[sp >> 2][sp & 3], Dy);
+            }
+        };
+        auto stage_fast = [&](int wt, const f32x4& Ey, const f32x4& Dy) {
+            const int w0 = 16 * wt + 4 * kk;
+            const f32x4 yl = Ey - Dy;
+            const f32x4 yr = Ey + Dy;
+            float* pl = buf + rowbase + w0;
+            float* pr = buf + rowbase + W - w0 - 3;
+            pl[0] = yl[0]; pl[1] = yl[1]; pl[2] = yl[2]; pl[3] = yl[3];
+            pr[3] = yr[0]; pr[2] = yr[1]; pr[1] = yr[2]; pr[0] = yr[3];
+        };
+        auto stage_guarded = [&](int wt, const f32x4& Ey, const f32x4& Dy) {
+            const int w0 = 16 * wt + 4 * kk;
+            const f32x4 yl = Ey - Dy;
+            const f32x4 yr = Ey + Dy;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int w = w0 + e;
+                buf[(row_ok && w <= Wh) ? rowbase + w : dump] = yl[e];
+                buf[(row_ok && w >= 1 && w <= wfast_hi) ? rowbase + W - w : dump] = yr[e];
+            }
+        };
+        // column tiles [1, nfast) need no guards when all 16 rows exist
+        const int nfast = rows == 16 ? max(1, min(nwt, (wfast_hi + 1) >> 4)) : 1;
+        f32x4 E0, D0, E1, D1;
+        chain_mfma(0, E0, D0);
+        int wt = 1;
+        for (; wt + 1 < nfast; wt += 2) {
+            chain_mfma(wt, E1, D1);
+            if (wt == 1) stage_guarded(0, E0, D0); else stage_fast(wt - 1, E0, D0);
+            chain_mfma(wt + 1, E0, D0);
+            stage_fast(wt, E1, D1);
+        }
+        // tail: the tile held in (E0, D0) is wt - 1; the remaining tiles take the guarded path
+        for (; wt < nwt; ++wt) {
+            chain_mfma(wt, E1, D1);
+            if (wt - 1 >= 1 && wt - 1 < nfast) stage_fast(wt - 1, E0, D0); else stage_guarded(wt - 1, E0, D0);
+            E0 = E1; D0 = D1;
+        }
+        if (nwt - 1 >= 1 && nwt - 1 < nfast) stage_fast(nwt - 1, E0, D0); else stage_guarded(nwt - 1, E0, D0);
+
+        // ---- the tile goes out as whole 128-byte lines: LDS index i <-> memory gbase[i]
+        float* gbase = tile - phase;
+        const int total = phase + rows * W;
+        const bool first = !chain || rt == 0, last = !chain || rt + NW >= nrt;
+        const int lo = first ? phase : 0;                   // chained tiles start with the carried head of the line
+        const int hi = last ? total : (total & ~31);
+        auto store_guarded = [&](int i) {
+            if (i >= hi) return;
+            if (i >= lo && i + 3 < hi) {
+                *reinterpret_cast<f32x4*>(gbase + i) = *reinterpret_cast<const f32x4*>(buf + i);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e >= lo && i + e < hi) gbase[i + e] = buf[i + e];
+            }
+        };
+        const int nfull = hi >> 8;                          // instructions [1, nfull) cover whole 1 KB runs inside [lo, hi)
+        store_guarded(4 * lane);
+        int it = 1;
+        for (; it + 4 <= nfull; it += 4) {
+            const float* src = buf + 256 * it + 4 * lane;
+            float* dst = gbase + 256 * it + 4 * lane;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 256);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 512);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + 768);
+            *reinterpret_cast<f32x4*>(dst) = v0;
+            *reinterpret_cast<f32x4*>(dst + 256) = v1;
+            *reinterpret_cast<f32x4*>(dst + 512) = v2;
+            *reinterpret_cast<f32x4*>(dst + 768) = v3;
+        }
+        for (; it < nfull; ++it)
+            *reinterpret_cast<f32x4*>(gbase + 256 * it + 4 * lane) = *reinterpret_cast<const f32x4*>(buf + 256 * it + 4 * lane);
+        if (nfull >= 1) store_guarded(256 * nfull + 4 * lane);
+        if (!last) {
+            // carry the partial last line to the head of the next tile's image (same buffer, next phase = total & 31)
+            const int rem = total & 31;
+            float v = 0.f;
+            if (lane < rem) v = buf[(total & ~31) + lane];
+            if (lane < rem) buf[lane] = v;
+        }
+    }
+}
+
 // Workgroup geometry: NW waves per image, G images per workgroup (NW * G <= 12 waves).  All workgroups take the same time, so
 // the launch runs in ceil(groups / (CUs * workgroups per CU)) rounds of ceil(row tiles / NW) tile times each; choose the
 // (NW, G) with the fewest tile times, more waves per image on a tie.
@@ -339,8 +543,59 @@ static int launch_inv_k(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     return 0;
 }
 
+// full-tile form: up to 4 waves per workgroup (NW per image x G images), whole tiles in LDS
+static size_t inv_ft_lds_bytes(const Dft2dParams& p, int KS, int waves) {
+    const int nwt = ((p.W >> 1) + 16) >> 4;
+    const size_t tile_stride = (size_t)((16 * p.W + 32 + 64 + 3) & ~3);
+    return (size_t)nwt * KS * 64 * sizeof(float2) + (size_t)((p.H + 1) & ~1) * sizeof(float2) + (size_t)waves * tile_stride * sizeof(float);
+}
+
+static bool inv_ft_geometry(const Dft2dParams& p, int KS, InvGeometry* out) {
+    // the staging writes walk 16 rows at a stride of W floats: W % 8 == 0 puts them on 4 or fewer LDS banks
+    if (p.bf16 || p.W % 8 == 0 || p.W < 16) return false;
+    const int nrt = (p.H + 15) / 16, cus = device_cu_count();
+    long long best_cost = -1;
+    for (int nw = 1; nw <= 4 && nw <= nrt; nw *= 2) {
+        int g = 4 / nw;
+        while (g > 1 && (long long)(p.n_img + g - 1) / g < cus) --g;
+        const size_t lds = inv_ft_lds_bytes(p, KS, nw * g);
+        if (lds > INV_LDS_BUDGET) continue;
+        // a CU should hold at least four waves (one per SIMD)
+        const long long per_cu = std::max<long long>(1, std::min<long long>((long long)(INV_LDS_BUDGET / lds), 16 / (nw * g)));
+        if (per_cu * nw * g < 4 && (long long)p.n_img * nw >= 4LL * cus) continue;
+        const long long groups = (p.n_img + g - 1) / g;
+        const long long rounds = (groups + cus * per_cu - 1) / (cus * per_cu);
+        const long long cost = rounds * ((nrt + nw - 1) / nw);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; *out = InvGeometry{nw, g, lds, true}; }
+    }
+    return best_cost >= 0;
+}
+
+template <int KS, int JT>
+static int launch_inv_ft(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
+    auto k = dft2d_inv_ft_kernel<KS, JT>;
+    if (g.lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) {
+            set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds);
+            return -4;
+        }
+    }
+    p.nw = g.nw;
+    char name[64];
+    snprintf(name, sizeof(name), "uno::dft2d_inv_ft_kernel<%d, %d>", KS, JT);
+    {
+        ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
+        hipLaunchKernelGGL(k, dim3((p.n_img + g.g - 1) / g.g), dim3(64 * g.nw * g.g), g.lds, s, p);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dft2d_inv launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
 template <int KS, int JT>
 static int launch_inv_t(const Dft2dParams& p, hipStream_t s) {
+    InvGeometry ft;
+    if (inv_ft_geometry(p, KS, &ft)) return launch_inv_ft<KS, JT>(p, ft, s);
     const InvGeometry g = inv_geometry(p, KS, !p.bf16);
     if (g.lds == 0 || g.lds > INV_LDS_BUDGET) { set_error("dft2d_inv: grid %dx%d needs %zu B of LDS", p.H, p.W, g.lds); return -3; }
     if (p.bf16) return launch_inv_k<KS, JT, true, false>(p, g, s);
