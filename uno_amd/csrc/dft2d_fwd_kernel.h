@@ -19,6 +19,7 @@
 // combines them and wave 0 writes the 2*m1*m2 complex results.
 #pragma once
 #include "uno_common.h"
+#include "dft2d_fwd_ft_kernel.h"
 #include <cstdio>
 
 #ifndef UNO_ABLATE
@@ -399,6 +400,10 @@ static int launch_fwd_b(const Dft2dParams& p, hipStream_t s) {
 
 template <int NT, int MT, bool VEC, int R4>
 static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
+    if constexpr (VEC) {
+        FwdFtGeometry ft;
+        if (fwd_ft_geometry(p, NT, MT, R4, &ft)) return launch_fwd_ft<NT, MT, R4>(p, ft, s);
+    }
     return p.bf16 ? launch_fwd_b<NT, MT, VEC, R4, true>(p, s) : launch_fwd_b<NT, MT, VEC, R4, false>(p, s);
 }
 
