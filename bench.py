@@ -1,29 +1,28 @@
 #!/usr/bin/env python
-"""Headline benchmark: U-NO training samples/s on synthetic 421x421 Darcy (BASELINE.json configs[1])
-+ live HBM-roofline figure of the dominant spectral kernel + the CPU baseline timed beside it.
+"""Headline benchmark: U-NO training samples/s on synthetic 421x421 Darcy (BASELINE.json configs[1]) + the HBM-roofline
+fraction of the spectral block, measured live, + the CPU baseline timed beside it.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = forward + relative-L2 loss + backward + gradient all-reduce (N > 1) + complex-modulus Adam
-update on one minibatch of 16 synthetic samples per GPU (weak scaling).  Inputs are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line.
+A step = forward + relative-L2 loss + backward + gradient all-reduce (N > 1, RCCL) + complex-modulus Adam update on one
+minibatch of 16 synthetic samples per GPU (weak scaling; --strong splits a global batch of 16).  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch
-import torch.distributed as dist
 
 S, WIDTH, PAD, BATCH = 421, 64, 5, 16          # BASELINE.json configs[1]: Darcy 421^2, 64 ch, batch 16
 BLOCK_MODES = 20                               # block-level roofline config: modes = 20
@@ -35,42 +34,53 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--strong", action="store_true", help="strong scaling: a global batch of 16 split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host CPU leg (developer runs)")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="samples in the bounded CPU-baseline step")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (C3 / C4 / C5, reference-style caller)")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="samples per CPU-baseline step")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int):
-    """The oracle's FFT-sequence restatement of the reference step (rfft2 -> einsum -> irfft2 blocks,
-    same loss, reference-Adam arithmetic) timed on the host cores: one step on `batch` samples of the
-    same 421^2 workload (the full 16-sample step costs ~30 s on 8 cores)."""
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(batch: int, steps: int, threads: int):
+    """The oracle's FFT-sequence restatement of the reference step (rfft2 -> einsum -> irfft2 blocks, same loss, reference-Adam
+    arithmetic - BASELINE.md section 3) timed on the host cores: `steps` timed steps on `batch` samples of the same 421^2
+    workload after one untimed step."""
+    import torch
     from oracle import spectral_oracle as so            # checker/baseline only - never the product path
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
-    # measured on the GPU box (2 x EPYC 9575F, 256 hw threads): 16 threads 0.74 samples/s, 32 -> 0.64,
-    # 64 -> 0.37, all 256 -> did not finish in 20 min.  Use the best setting, report what was used.
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = UNO_9(3, WIDTH, pad=PAD, block_cls=so.OracleOperatorBlock2d)
     tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
     a1, u1 = synthetic_darcy_batch(1, S, 99, "cpu")
-    tr.step(a1, u1)                                     # untimed: thread pool, allocator, MKL plans
+    tr.step(a1, u1)                                     # untimed: thread pool, allocator, FFT plans
     a, u = synthetic_darcy_batch(batch, S, 1234, "cpu")
     t0 = time.perf_counter()
-    tr.step(a, u)
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step on {batch} synthetic 421x421 samples ({dt:.1f} s), UNO_9(3,{WIDTH},pad={PAD}), "
-                      f"torch {torch.__version__} CPU FFT path, {cores} threads of {os.cpu_count()} hw threads"}
+    for _ in range(steps):
+        tr.step(a, u)
+    dt = (time.perf_counter() - t0) / steps
+    return {"samples_per_s": batch / dt, "s_per_step": dt, "batch": batch, "steps": steps, "threads": threads}
 
 
-def cpu_baseline_bounded(batch: int, limit_s: int = 300):
-    """Run the CPU leg in a child process so a pathological host (thread oversubscription) can never
-    stall the bench: the child is killed by PID after `limit_s`."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch", str(batch)]
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+def _cpu_child(batch, steps, threads, limit_s):
+    """Run one CPU leg in a child process (killed by PID after `limit_s`: a pathological host can never stall the bench)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch", str(batch), "--cpu-steps", str(steps),
+           "--cpu-threads", str(threads)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
@@ -79,17 +89,86 @@ def cpu_baseline_bounded(batch: int, limit_s: int = 300):
     except subprocess.TimeoutExpired:
         proc.kill()
         proc.communicate()
-        return {"value": None, "unit": "samples/s", "cores": min(os.cpu_count() or 1, 16), "kind": "port",
-                "sample": f"CPU step on {batch} samples did not finish within {limit_s} s"}
+        return None
     for line in reversed(out.strip().splitlines()):
         if line.startswith("{"):
             return json.loads(line)
     return None
 
 
-def spectral_block_roofline(dev, iters=10):
-    """BASELINE's second figure: SpectralConv2d(64,64,421,421,20,20), batch 16, forward and backward
-    against the algorithmic bytes of SURVEY.md section 8(d) (fwd 1478.2 MB, bwd 1504.4 MB)."""
+def cpu_baseline_bounded(batch: int, steps: int):
+    """N-thread leg (B = 16, >= 3 timed steps: BASELINE.md section 3) + a 1-thread figure on a smaller sample.
+    Thread count: measured on the GPU box (2 x EPYC 9575F, 256 hw threads): 16 threads 0.74-1.0 samples/s, 32 -> 0.64,
+    64 -> 0.37, all 256 did not finish in 20 min (oversubscribed FFT / GEMM thread pools) - 16 is the best setting."""
+    import torch
+    hw = os.cpu_count() or 1
+    cores = min(hw, 16)
+    main = _cpu_child(batch, steps, cores, 420)
+    one = _cpu_child(2, 1, 1, 240)
+    out = {"value": main["samples_per_s"] if main else None, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": (f"{steps} timed training steps (after 1 untimed) on {batch} synthetic 421x421 samples each, UNO_9(3,{WIDTH},pad={PAD}), "
+                      f"oracle FFT path (torch.fft.rfft2 -> einsum -> irfft2, reference op sequence), torch {torch.__version__} CPU, "
+                      f"{cores} threads of {hw} hw threads, {_cpu_model()}"
+                      + (f", {main['s_per_step']:.1f} s/step" if main else ", DID NOT FINISH in 420 s")),
+           "one_thread": ({"value": one["samples_per_s"], "unit": "samples/s", "sample": f"1 step on 2 samples, 1 thread ({one['s_per_step']:.1f} s)"}
+                          if one else None)}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- spectral-block roofline
+def _timed(fn, dev, iters=10, reps=3):
+    """median over `reps` groups of `iters` back-to-back calls, HIP events on the launch stream (torch's current stream is
+    the stream every kernel of the library is launched on)."""
+    import torch
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out.append(e0.elapsed_time(e1) / iters * 1e-3)
+    out.sort()
+    return out[len(out) // 2]
+
+
+def _kernel_table(fn, n=5):
+    """per-kernel mean duration of `n` calls of fn from the library's own HIP-event pairs (recorded on the launch stream)."""
+    import torch
+    from uno_amd import _native
+    _native.profile_begin(4096)
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    agg = {}
+    for name, ms, by in _native.profile_end():
+        if ms < 0:
+            continue
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += by
+    return {k: {"launches_per_call": v[0] / n, "avg_us": v[1] / v[0] * 1e3, "bytes_per_launch": v[2] / v[0],
+                "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in agg.items()}
+
+
+def _traffic(names):
+    """HBM bytes per launch (PMC passes, profiles/hbm_traffic.json) summed over the kernels of one call, or None."""
+    tfile = os.path.join(ROOT, "profiles", "block_traffic.json")     # standalone C2 / C4 block runs (tools/profile_round.sh)
+    try:
+        table = json.load(open(tfile))
+        vals = [table[n]["bytes_per_launch"] for n in names]
+        return float(sum(vals))
+    except Exception:
+        return None
+
+
+def spectral_block_roofline(dev):
+    """BASELINE's second figure: SpectralConv2d(64,64,421,421,20,20), batch 16, forward and backward against the algorithmic
+    bytes of SURVEY.md section 8(d) (fwd 1478.2 MB, bwd 1504.4 MB)."""
+    import torch
     from uno_amd import _native
     g = torch.Generator().manual_seed(0)
     C, m = WIDTH, BLOCK_MODES
@@ -100,30 +179,23 @@ def spectral_block_roofline(dev, iters=10):
     gy = torch.randn(BATCH, C, S, S, generator=g).to(dev)
     y, xt = _native.spectral_conv2d_forward(x, w1, w2, S, S)
     _native.spectral_conv2d_backward(gy, xt, w1, w2, S, S)
-
-    def timed(fn):
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / iters * 1e-3
-
-    tf = timed(lambda: _native.spectral_conv2d_forward(x, w1, w2, S, S))
-    tb = timed(lambda: _native.spectral_conv2d_backward(gy, xt, w1, w2, S, S))
+    fwd = lambda: _native.spectral_conv2d_forward(x, w1, w2, S, S)
+    bwd = lambda: _native.spectral_conv2d_backward(gy, xt, w1, w2, S, S)
+    tf, tb = _timed(fwd, dev), _timed(bwd, dev)
+    kf, kb = _kernel_table(fwd), _kernel_table(bwd)
     img = BATCH * C * S * S * 4
     wb = 2 * C * C * m * m * 8
     fwd_b, bwd_b = 2 * img + wb, 2 * img + 2 * wb
     return {"config": f"SpectralConv2d({C},{C},{S},{S},{m},{m}) batch {BATCH} f32",
             "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_bytes": fwd_b, "bwd_bytes": bwd_b,
-            "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS}
+            "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS,
+            "fwd_kernels": kf, "bwd_kernels": kb}
 
 
-def spectral_block3d_roofline(dev, iters=10):
+def spectral_block3d_roofline(dev):
     """Config C4 of SURVEY.md section 8(d): SpectralConv3d(32, 32, 64, 64, 20, modes 16, 16, 8), batch 8, forward and
     backward against the algorithmic bytes (fwd = in + out + 4 corner weights; bwd = in + out + 2 x weights)."""
+    import torch
     from uno_amd import _native
     g = torch.Generator().manual_seed(0)
     B, C, H, W, T, m1, m2, m3 = 8, 32, 64, 64, 20, 16, 16, 8
@@ -133,39 +205,167 @@ def spectral_block3d_roofline(dev, iters=10):
     gy = torch.randn(B, C, H, W, T, generator=g).to(dev)
     y, xt = _native.spectral_conv3d_forward(x, ws, H, W, T)
     _native.spectral_conv3d_backward(gy, xt, ws, H, W, T)
-
-    def timed(fn):
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / iters * 1e-3
-
-    tf = timed(lambda: _native.spectral_conv3d_forward(x, ws, H, W, T))
-    tb = timed(lambda: _native.spectral_conv3d_backward(gy, xt, ws, H, W, T))
+    fwd = lambda: _native.spectral_conv3d_forward(x, ws, H, W, T)
+    bwd = lambda: _native.spectral_conv3d_backward(gy, xt, ws, H, W, T)
+    tf, tb = _timed(fwd, dev), _timed(bwd, dev)
     vol = B * C * H * W * T * 4
     wb = 4 * C * C * m1 * m2 * m3 * 8
     fwd_b, bwd_b = 2 * vol + wb, 2 * vol + 2 * wb
     return {"config": f"SpectralConv3d({C},{C},{H},{W},{T},{m1},{m2},{m3}) batch {B} f32",
             "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_bytes": fwd_b, "bwd_bytes": bwd_b,
-            "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS}
+            "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS,
+            "fwd_kernels": _kernel_table(fwd), "bwd_kernels": _kernel_table(bwd)}
+
+
+# ----------------------------------------------------------------------------------------------- secondary workloads
+def _train_ms(step, dev, steps=5, warmup=2):
+    import torch
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    lv = float(loss)
+    assert lv == lv, "training produced NaN"
+    return dt * 1e3
+
+
+def extra_workloads(dev):
+    """The other configs of BASELINE.json on one GPU (short runs; the headline stays configs[1]): the reference-style caller of
+    the Darcy model, C3 NS-2D roll-out, C4 NS-3D, C5 1024^2 block / model."""
+    import torch
+    from uno_amd import _native
+    from uno_amd.harness import (ComplexAdam, DarcyTrainer, GraphedStep, UNO, UNO_9, UNO_9_ReferenceStyle, Uno3D_T20,
+                                 ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch)
+    out = {}
+
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as e:        # a secondary workload never takes the headline down
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
+
+    def ref_style():
+        torch.manual_seed(0)
+        model = UNO_9_ReferenceStyle(3, WIDTH, pad=PAD).to(dev)
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+        a, u = synthetic_darcy_batch(BATCH, S, 1234, dev)
+        ms = _train_ms(lambda: tr.step(a, u), dev)
+        return {"config": "UNO_9(3,64,pad=5) 421^2 batch 16 driven as darcy_flow_uno2d.py:94-133 drives it (channels-last nn.Linear, "
+                          "F.gelu, permute, F.pad, torch.cat, host-built grid) on the product operator blocks",
+                "ms_per_step": ms, "samples_per_s": BATCH / ms * 1e3}
+
+    def ns2d():
+        torch.manual_seed(0)
+        m = UNO(14, 32).to(dev)
+        xx, yy = torch.randn(32, 64, 64, 10, device=dev), torch.randn(32, 64, 64, 40, device=dev)
+        opt = ComplexAdam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        gs = GraphedStep(m, opt, lambda a_, b_: ns2d_rollout_loss(m, a_, b_, T_f=40, step=1), (xx, yy))
+        ms = _train_ms(lambda: gs.step(xx, yy), dev, steps=4, warmup=1)
+        return {"config": "C3: UNO(14,32), 64^2, batch 32, T 10 -> 40 autoregressive roll-out, one backward, HIP-graph replay + eager Adam",
+                "ms_per_step": ms, "samples_per_s": 32 / ms * 1e3}
+
+    def ns3d(width):
+        def run():
+            torch.manual_seed(0)
+            m3 = Uno3D_T20(6, width, pad=3).to(dev)
+            x, y = torch.randn(8, 64, 64, 10, 1, device=dev), torch.randn(8, 64, 64, 20, device=dev)
+            opt = ComplexAdam(m3.parameters(), lr=1e-3, weight_decay=1e-4)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = ns3d_loss(m3, x, y)
+                loss.backward()
+                opt.step()
+                return loss
+            ms = _train_ms(step, dev)
+            return {"config": f"C4: Uno3D_T20(6,{width},pad=3), 64x64x10 -> 64x64x20, batch 8", "ms_per_step": ms,
+                    "samples_per_s": 8 / ms * 1e3}
+        return run
+
+    def c5_block():
+        g = torch.Generator().manual_seed(0)
+        C, S5, m, B = 64, 1024, 32, 4
+        x = torch.randn(B, C, S5, S5, generator=g).to(dev)
+        sc = (1 / (2 * C)) ** 0.5
+        w1 = (sc * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)).to(dev)
+        w2 = (sc * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)).to(dev)
+        gy = torch.randn(B, C, S5, S5, generator=g).to(dev)
+        y, xt = _native.spectral_conv2d_forward(x, w1, w2, S5, S5)
+        tf = _timed(lambda: _native.spectral_conv2d_forward(x, w1, w2, S5, S5), dev, iters=5)
+        tb = _timed(lambda: _native.spectral_conv2d_backward(gy, xt, w1, w2, S5, S5), dev, iters=5)
+        img, wb = B * C * S5 * S5 * 4, 2 * C * C * m * m * 8
+        res = {"config": f"C5 block: SpectralConv2d(64,64,1024,1024,32,32) batch {B}",
+               "f32": {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_frac_of_8TBs": (2 * img + wb) / tf / 8e12,
+                       "bwd_frac_of_8TBs": (2 * img + 2 * wb) / tb / 8e12}}
+        xb, gyb = x.bfloat16(), gy.bfloat16()
+        del x, gy
+        yb, xtb = _native.spectral_conv2d_forward(xb, w1, w2, S5, S5)
+        tf = _timed(lambda: _native.spectral_conv2d_forward(xb, w1, w2, S5, S5), dev, iters=5)
+        tb = _timed(lambda: _native.spectral_conv2d_backward(gyb, xtb, w1, w2, S5, S5), dev, iters=5)
+        imgb, wh = img // 2, wb // 2          # SURVEY 8(d): s_a = 2 (bf16 activations), s_w = 4 (complex-half weight storage)
+        res["bf16_activations"] = {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_frac_of_8TBs": (2 * imgb + wh) / tf / 8e12,
+                                   "bwd_frac_of_8TBs": (2 * imgb + 2 * wh) / tb / 8e12,
+                                   "rel_err_vs_f32": float((yb.float() - y).norm() / y.norm())}
+        return res
+
+    def c5_model():
+        torch.manual_seed(0)
+        B = 4
+        model = UNO_9(3, 64, pad=5).to(dev)
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+        a, u = synthetic_darcy_batch(B, 1024, 1234, dev)
+        ms = _train_ms(lambda: tr.step(a, u), dev, steps=4, warmup=2)
+        return {"config": f"C5 model: UNO_9(3,64,pad=5) at 1024^2 (padded 1089^2), batch {B}, f32", "ms_per_step": ms,
+                "samples_per_s": B / ms * 1e3, "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+
+    guarded("darcy_reference_style_caller", ref_style)
+    guarded("c3_ns2d", ns2d)
+    guarded("c4_ns3d_w8", ns3d(8))
+    guarded("c4_ns3d_w32", ns3d(32))
+    guarded("c5_block", c5_block)
+    guarded("c5_model_f32", c5_model)
+    try:
+        from uno_amd.harness.mixed import c5_mixed_model_bench
+        guarded("c5_model_mixed", lambda: c5_mixed_model_bench(dev))
+    except ImportError:
+        pass
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU under torch.distributed.run and relay rank 0's
+    JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.cpu_batch)))
+        print(json.dumps(cpu_baseline(args.cpu_batch, args.cpu_steps, args.cpu_threads or min(os.cpu_count() or 1, 16))))
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
-                     f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback for the product path")
@@ -173,22 +373,29 @@ def main():
     # developer check of the N > 1 code path on a one-GPU box: UNO_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses
     # gloo (RCCL refuses two ranks on one device); the driver never sets it
     share = os.environ.get("UNO_BENCH_SHARE_GPU") == "1"
+    if world > 1 and not share and torch.cuda.device_count() < world:
+        sys.exit(f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()}")
     dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
+        backend = dist.get_backend()
 
     from uno_amd import _native
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
 
+    per_rank = BATCH // world if args.strong else BATCH
+    if args.strong and BATCH % world:
+        sys.exit(f"--strong needs a world size that divides {BATCH}")
     torch.manual_seed(0)                                    # same init everywhere (then broadcast from rank 0)
     model = UNO_9(3, WIDTH, pad=PAD).to(dev)
     trainer = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
-    a, u = synthetic_darcy_batch(BATCH, S, 1234 + rank, dev)   # per-rank shard of the global batch, in HBM
+    a, u = synthetic_darcy_batch(per_rank, S, 1234 + rank, dev)   # per-rank shard of the global batch, in HBM
 
     def sync_all():
         if world > 1:
@@ -206,23 +413,32 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    # Per-kernel durations for the roofline figure: the same K steps once more with the library's HIP events on the
-    # launch stream around every kernel.  Kept out of the timed region above because the event pairs serialise the
-    # queue (~10 us per kernel, ~5 % of the step); every rank runs it so the collectives stay matched.
+    # Per-kernel durations of the training step: the same K steps once more with the library's HIP events on the launch
+    # stream around every kernel.  Kept out of the timed region above because the event pairs serialise the queue (~10 us per
+    # kernel, ~5 % of the step); every rank runs it so the collectives stay matched.
     _native.profile_begin(200000)
     for _ in range(args.steps):
         trainer.step(a, u)
     sync_all()
     records = _native.profile_end()
+    comm = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the exchange alone: one blocking SUM over the flat gradient buffer (not overlapped with anything)
+        sync_all()
+        tc = time.perf_counter()
+        for _ in range(5):
+            trainer.grads.all_reduce_sum()
+        sync_all()
+        comm = {"backend": backend, "ranks": dist.get_world_size(), "grad_bytes": trainer.grads.flat.numel() * 4,
+                "buckets": len(trainer.grads.buckets), "bucket_mb": 32.0,
+                "blocking_allreduce_ms": (time.perf_counter() - tc) / 5 * 1e3}
     loss_val = float(loss)
     assert loss_val == loss_val, "training produced NaN"
 
     if rank == 0:
-        # live per-kernel timing (HIP events on the launch stream, recorded inside the library)
         agg = {}
         for name, ms, by in records:
             if ms < 0:
@@ -231,37 +447,45 @@ def main():
             a_[0] += 1
             a_[1] += ms
             a_[2] += by
-        roofline = None
-        if agg:
-            dom = max(agg, key=lambda k: agg[k][1])
-            n, ms, by = agg[dom]
-            achieved = by / (ms * 1e-3) / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tfile):
-                try:
-                    traffic = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n,
-                        "avg_launch_us": ms / n * 1e3, "algorithmic_bytes_per_launch": by / n,
-                        "kernels": {k: {"launches": v[0], "total_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9}
-                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
-        block = spectral_block_roofline(dev) if world == 1 else None
+        step_kernels = {k: {"launches": v[0], "total_ms": v[1], "GBps": v[2] / (v[1] * 1e-3) / 1e9}
+                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        # The roofline object answers BASELINE.json's question: the spectral block (rFFT -> mode mixing -> iRFFT =
+        # K1 + K2 + K3) at SpectralConv2d(64,64,421,421,20,20), batch 16, against SURVEY 8(d)'s algorithmic bytes.
+        block = spectral_block_roofline(dev)
+        kf = block["fwd_kernels"]
+        dom = max(kf, key=lambda k: kf[k]["avg_us"] * kf[k]["launches_per_call"])
+        roofline = {
+            "bound": "hbm", "kernel": "spectral block forward = " + " + ".join(sorted(kf)),
+            "achieved": block["fwd_bytes"] / (block["fwd_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": block["fwd_frac_of_8TBs"], "traffic": _traffic(list(kf)),
+            "avg_launch_us": block["fwd_us"], "algorithmic_bytes_per_launch": block["fwd_bytes"],
+            "backward": {"achieved": block["bwd_bytes"] / (block["bwd_us"] * 1e-6) / 1e9, "frac": block["bwd_frac_of_8TBs"],
+                         "avg_launch_us": block["bwd_us"], "algorithmic_bytes_per_launch": block["bwd_bytes"],
+                         "traffic": _traffic(list(block["bwd_kernels"])), "kernels": block["bwd_kernels"]},
+            "kernels": kf,
+            "dominant_kernel": {"name": dom, "avg_launch_us": kf[dom]["avg_us"], "achieved": kf[dom]["GBps"],
+                                "frac": kf[dom]["GBps"] / HBM_PEAK_GBS, "traffic": _traffic([dom])},
+            "mfma_note": "v_mfma_f32_16x16x4_f32 / 4x4x1_16b also run the pruned DFT stages (not only the per-mode GEMM): a truncated "
+                         "DFT against a constant twiddle matrix is a tall-skinny GEMM at ~20 flop/B, the f32 ridge of the chip",
+            "step_kernels": step_kernels,
+        }
         block3d = spectral_block3d_roofline(dev) if world == 1 else None
+        extras = extra_workloads(dev) if world == 1 and not args.no_extras else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline_bounded(args.cpu_batch)
+            cpu = cpu_baseline_bounded(args.cpu_batch, args.cpu_steps)
+        gb = world * per_rank
         out = {
-            "metric": "UNO training samples/s (421^2 Darcy)", "value": world * BATCH * args.steps / elapsed,
+            "metric": "UNO training samples/s (421^2 Darcy)", "value": gb * args.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Darcy 2D {S}x{S}, UNO_9(3,{WIDTH},pad={PAD}) 64ch, batch {BATCH}/GPU, train step "
-                                   "(fwd+loss+bwd+allreduce+Adam)", "global_batch": world * BATCH,
+            "config": {"workload": f"Darcy 2D {S}x{S}, UNO_9(3,{WIDTH},pad={PAD}) 64ch, batch {per_rank}/GPU, train step "
+                                   "(fwd+loss+bwd+allreduce+Adam)", "global_batch": gb,
                        "parallelism": f"dp{world}", "final_loss": loss_val},
-            "roofline": roofline, "spectral_block": block, "spectral_block_3d": block3d, "cpu_baseline": cpu,
+            "roofline": roofline, "spectral_block": {k: v for k, v in block.items() if not k.endswith("_kernels")},
+            "spectral_block_3d": block3d, "comm": comm, "rccl_ranks": comm["ranks"] if comm and backend == "nccl" else (1 if world == 1 else None),
+            "extras": extras, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

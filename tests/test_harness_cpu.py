@@ -245,3 +245,15 @@ def test_complex_adam_per_parameter_step_counts():
         opt.step()
     assert opt.state[p1]["step"] == 4 and opt.state[p2]["step"] == 2
     assert torch.allclose(p1, q1) and torch.allclose(p2, q2)
+
+
+def test_reference_style_caller_reproduces_the_reference_on_cpu():
+    """harness/reference_style.py (the reference's calling convention: channels-last Linear, permute, F.pad, torch.cat) with the
+    oracle blocks on the host reproduces the reference's prediction - it is the same op sequence."""
+    from uno_amd.harness import UNO_9_ReferenceStyle
+    c = Case(ZH, "uno9")
+    S, B, width, pad = [int(v) for v in c.meta]
+    model = UNO_9_ReferenceStyle(3, width, pad=pad, block_cls=so.OracleOperatorBlock2d)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    pred = model(torch.from_numpy(c.a)).reshape(B, S, S)
+    assert rel_err(pred.detach().numpy(), c.pred0) < 1e-6

@@ -127,6 +127,32 @@ def test_uno9_training_steps_match_reference():
     assert checked >= 15
 
 
+def test_uno9_reference_style_caller_matches_golden():
+    """The reference's OWN calling convention (channels-last nn.Linear, F.gelu, permute, F.pad, torch.cat, positional block
+    calls - darcy_flow_uno2d.py:94-133, restated in harness/reference_style.py) on the product blocks: prediction, loss and
+    every stored gradient against the reference-generated golden.  This is the drop-in path a user of the reference gets."""
+    from uno_amd.harness import UNO_9_ReferenceStyle, lp_loss_rel_sum
+    c = Case(ZH, "uno9")
+    S, B, width, pad = [int(v) for v in c.meta]
+    model = UNO_9_ReferenceStyle(3, width, pad=pad)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
+    model = model.to(dev())
+    a, u = torch.from_numpy(c.a).to(dev()), torch.from_numpy(c.u).to(dev())
+    pred = model(a).reshape(B, S, S)
+    assert rel_err(pred.detach().cpu().numpy(), c.pred0) < 1e-4
+    loss = lp_loss_rel_sum(pred.view(B, -1), u.view(B, -1))
+    assert abs(float(loss) - float(c.losses[0])) < 2e-4 * abs(float(c.losses[0]))
+    loss.backward()
+    gmax = max(float(getattr(c, f"gradnorm.{k}")) for k, _ in model.named_parameters())
+    params = dict(model.named_parameters())
+    for k, p in params.items():
+        ref = float(getattr(c, f"gradnorm.{k}"))
+        assert abs(float(torch.linalg.vector_norm(p.grad)) - ref) <= 2e-4 * ref + 1e-6 * gmax, k
+    for k, g in c.sub("grad").items():
+        got = params[k].grad.cpu().numpy()
+        assert np.linalg.norm((got - g).ravel()) <= 2e-4 * np.linalg.norm(g.ravel()) + 1e-6 * gmax, k
+
+
 def test_model_product_vs_oracle_blocks_same_weights():
     """Same UNO_9 weights, product blocks on the GPU vs the oracle's FFT blocks on the host, at a
     non-golden size (S=100 -> padded 110, scale=2)."""

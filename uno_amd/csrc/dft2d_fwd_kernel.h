@@ -388,7 +388,7 @@ static int launch_fwd_b(const Dft2dParams& p, hipStream_t s) {
         }
     }
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d%s>", NT, MT, VEC ? "true" : "false", R4, BF16 ? ", bf16" : "");
+    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d, %s>", NT, MT, VEC ? "true" : "false", R4, BF16 ? "true" : "false");
     {
         ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * (BF16 ? 2.0 : 4.0) + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);

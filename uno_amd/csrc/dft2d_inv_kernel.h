@@ -540,7 +540,7 @@ static int launch_inv_k(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     }
     p.nw = g.nw;
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d%s%s>", KS, JT, BF16 ? ", bf16" : "", TAB ? ", tab" : "");
+    snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d, %s, %s>", KS, JT, BF16 ? "true" : "false", TAB ? "true" : "false");
     {
         ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * (BF16 ? 2.0 : 4.0) + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3((p.n_img + g.g - 1) / g.g), dim3(64 * g.nw * g.g), g.lds, s, p);
