@@ -23,6 +23,9 @@ namespace uno {
 
 constexpr int FT_TAILMAX = 5;           // tail <= 15 pairs + w = 0 + Nyquist column = 17 elements = 5 k-steps
 constexpr size_t FT_LDS_BUDGET = 160 * 1024 - 2048;
+#ifndef UNO_FT_MAXW
+#define UNO_FT_MAXW 160                // widest image the full-tile form takes (see fwd_ft_geometry)
+#endif
 
 __device__ __forceinline__ f32x4 ft_mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);      // lane layout: dft2d_fwd_kernel.h
@@ -399,7 +402,7 @@ static bool fwd_ft_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtG
     // 421^2 243 / 212: with one wave per SIMD the row stage's LDS / VALU work and its MFMAs run back to back instead of
     // overlapping (ablations: 64 us of operand traffic + 83 us of row-stage MFMAs + 40 us of column stage + 60 us of exposed
     // tile loads), which the three waves per SIMD of the register path hide.  Large tiles therefore stay on that kernel.
-    if (p.W > 160) return false;
+    if (p.W > UNO_FT_MAXW) return false;
     if ((size_t)MT * NT * 8 * 64 > (size_t)16 * p.W) return false;             // reduction slots must fit a tile buffer
     const int nrt = (p.H + 15) / 16, cus = ft_device_cu_count();
     long long best_cost = -1;
