@@ -19,13 +19,13 @@
 #include <algorithm>
 #include <cstdio>
 
-#ifndef UNO_EXP
-#define UNO_EXP 0
-#endif
 namespace uno {
 
 constexpr int FT_TAILMAX = 5;           // tail <= 15 pairs + w = 0 + Nyquist column = 17 elements = 5 k-steps
 constexpr size_t FT_LDS_BUDGET = 160 * 1024 - 2048;
+#ifndef UNO_FT_MAXW
+#define UNO_FT_MAXW 160                // widest image the full-tile form takes (see fwd_ft_geometry)
+#endif
 
 __device__ __forceinline__ f32x4 ft_mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);      // lane layout: dft2d_fwd_kernel.h
@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
     const int tile_stride = (16 * W + 32 + 3) & ~3;                            // tile + alignment phase
     float* sTile = reinterpret_cast<float*>(smem);                             // [NWT][tile_stride]
     float2* sTabF = reinterpret_cast<float2*>(sTile + (size_t)NWT * tile_stride);   // [nk][NTF][64]
-    float2* sTab4 = sTabF + (size_t)nk * NTF * 64;                             // [nk][R4][16]
-    float2* sTwH = sTab4 + (size_t)nk * R4 * 16;
+    const int nka = 4 * nfull + FT_TAILMAX;                                    // allocated k-steps (prefetches run to the fifth tail step)
+    float2* sTab4 = sTabF + (size_t)nka * NTF * 64;                            // [nk][R4][16]
+    float2* sTwH = sTab4 + (size_t)nka * R4 * 16;
     int* sTailW = reinterpret_cast<int*>(sTwH + H);                            // [FT_TAILMAX][2][64]: left / right column of a tail element (-1 = none)
 
     const int slot = wave / NW, wsub = wave - slot * NW;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
         const int total = (toff & 31) + rows * W;
         const int npiece = (total + 255) >> 8;
         const unsigned v0 = (unsigned)(((toff & ~31) + 4 * lane) * 4);
-        for (int i = 0; i < ((UNO_EXP & 1) ? 0 : npiece); ++i)
+        for (int i = 0; i < npiece; ++i)
             if (256 * i + 4 * lane < total)         // the last piece stops at the end of the tile (lanes beyond it are masked off)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(buf + 256 * i), 16, v0 + 1024u * (unsigned)i, 0, 0, 0);
     };
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
 #pragma unroll
             for (int g = 0; g < NQ; ++g) { Qr[g] = f32x4{0, 0, 0, 0}; Qn[g] = f32x4{0, 0, 0, 0}; }
 #define UNO_FT_MFMA(E_, D_, TWF_, TW4_)                                                   \
-    do { if (UNO_EXP & 2) { Tr[0][0] += (E_) * (TWF_)[0].x; Tn[0][1] += (D_) * (TW4_)[0].y; break; }                     \
+    do {                                                                                  \
         _Pragma("unroll") for (int t = 0; t < NTF; ++t) {                                 \
             Tr[t] = mfma16((E_), (TWF_)[t].x, Tr[t]);                                     \
             Tn[t] = mfma16((D_), (TWF_)[t].y, Tn[t]);                                     \
@@ -175,50 +176,77 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
         }                                                                                 \
     } while (0)
 
-            // ---- stage A, full chunks: lane (row r16, k-slot kk) owns column pairs w = 1 + 16 c + 4 kk + s, s = 0..3
-            float xl[4], xr[4], nl[4], nr[4];
+            // ---- stage A, full chunks: lane (row r16, k-slot kk) owns column pairs w = 1 + 16 c + 4 kk + s, s = 0..3.
+            // One wave per SIMD: image operands AND twiddles of chunk c + 1 are requested before the MFMAs of chunk c are issued
+            // (sched_barrier keeps the requests there), so no LDS latency sits in front of an MFMA.
+            float xl[4], xr[4];
+            float2 twF[4][NTFA], tw4[4][NQ];
             const float* pl = row + 1 + 4 * kk;                 // left columns of chunk 0
             const float* pr = row + W - 4 - 4 * kk;             // mirrored columns of chunk 0 (ascending address)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { xl[s] = pl[s]; xr[s] = pr[s]; }
+            for (int s = 0; s < 4; ++s) {
+                xl[s] = pl[s]; xr[s] = pr[s];
+#pragma unroll
+                for (int t = 0; t < NTF; ++t) twF[s][t] = tabF[(s * NTF + t) * 64];
+#pragma unroll
+                for (int g = 0; g < R4; ++g) tw4[s][g] = tab4[(s * R4 + g) * 16];
+            }
             for (int c = 0; c < nfull; ++c) {
                 const int cn = min(c + 1, nfull - 1);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { nl[s] = pl[16 * cn + s]; nr[s] = pr[-16 * cn + s]; }
-                const float2* tf = tabF + (size_t)(4 * c) * (NTF * 64);
-                const float2* t4 = tab4 + (size_t)(4 * c) * (R4 * 16);
+                float nl[4], nr[4];
+                float2 ntwF[4][NTFA], ntw4[4][NQ];
+                // k-steps 4 (c + 1) .. 4 (c + 1) + 3: the next chunk, or (after the last chunk) the first tail k-steps
+                const float2* tf = tabF + (size_t)(4 * (c + 1)) * (NTF * 64);
+                const float2* t4 = tab4 + (size_t)(4 * (c + 1)) * (R4 * 16);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    float2 twF[NTFA], tw4[NQ];
+                    nl[s] = pl[16 * cn + s]; nr[s] = pr[-16 * cn + s];
 #pragma unroll
-                    for (int t = 0; t < NTF; ++t) twF[t] = tf[(s * NTF + t) * 64];
+                    for (int t = 0; t < NTF; ++t) ntwF[s][t] = tf[(s * NTF + t) * 64];
 #pragma unroll
-                    for (int g = 0; g < R4; ++g) tw4[g] = t4[(s * R4 + g) * 16];
+                    for (int g = 0; g < R4; ++g) ntw4[s][g] = t4[(s * R4 + g) * 16];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
                     const float E = xl[s] + xr[3 - s];
                     const float D = xl[s] - xr[3 - s];
-                    UNO_FT_MFMA(E, D, twF, tw4);
+                    UNO_FT_MFMA(E, D, twF[s], tw4[s]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { xl[s] = nl[s]; xr[s] = nr[s]; }
+                for (int s = 0; s < 4; ++s) {
+                    xl[s] = nl[s]; xr[s] = nr[s];
+#pragma unroll
+                    for (int t = 0; t < NTF; ++t) twF[s][t] = ntwF[s][t];
+#pragma unroll
+                    for (int g = 0; g < R4; ++g) tw4[s][g] = ntw4[s][g];
+                }
             }
-            // ---- tail k-steps: pairs beyond the last full chunk, then w = 0, then the Nyquist column
+            // ---- tail k-steps: pairs beyond the last full chunk, then w = 0, then the Nyquist column; the twiddles of the first
+            // four are already in twF / tw4
             {
                 const float2* tf = tabF + (size_t)(4 * nfull) * (NTF * 64);
                 const float2* t4 = tab4 + (size_t)(4 * nfull) * (R4 * 16);
+                float TL[FT_TAILMAX], TR[FT_TAILMAX];
+#pragma unroll
+                for (int s = 0; s < FT_TAILMAX; ++s) {
+                    const int wl = sTailW[(s * 2 + 0) * 64 + lane], wr = sTailW[(s * 2 + 1) * 64 + lane];
+                    const float vl = row[max(wl, 0)], vr = row[max(wr, 0)];
+                    TL[s] = wl >= 0 ? vl : 0.f; TR[s] = wr >= 0 ? vr : 0.f;
+                }
+                float2 twF5[NTFA], tw45[NQ];
+#pragma unroll
+                for (int t = 0; t < NTF; ++t) twF5[t] = tf[(4 * NTF + t) * 64];
+#pragma unroll
+                for (int g = 0; g < R4; ++g) tw45[g] = t4[(4 * R4 + g) * 16];
 #pragma unroll
                 for (int s = 0; s < FT_TAILMAX; ++s) {
                     if (s < tailsteps) {
-                        const int wl = sTailW[(s * 2 + 0) * 64 + lane], wr = sTailW[(s * 2 + 1) * 64 + lane];
-                        const float vl = row[max(wl, 0)], vr = row[max(wr, 0)];
-                        const float TL = wl >= 0 ? vl : 0.f, TR = wr >= 0 ? vr : 0.f;
-                        float2 twF[NTFA], tw4[NQ];
-#pragma unroll
-                        for (int t = 0; t < NTF; ++t) twF[t] = tf[(s * NTF + t) * 64];
-#pragma unroll
-                        for (int g = 0; g < R4; ++g) tw4[g] = t4[(s * R4 + g) * 16];
-                        const float E = TL + TR;
-                        const float D = TL - TR;
-                        UNO_FT_MFMA(E, D, twF, tw4);
+                        const float E = TL[s] + TR[s];
+                        const float D = TL[s] - TR[s];
+                        if (s < 4) UNO_FT_MFMA(E, D, twF[s], tw4[s]);
+                        else UNO_FT_MFMA(E, D, twF5, tw45);
                     }
                 }
             }
@@ -259,7 +287,7 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
                 idxB[mt] = wrap_add(i0, 8u * (unsigned)Kj[mt], H8);
             }
 #pragma unroll
-            for (int s = 0; s < ((UNO_EXP & 4) ? 1 : 4); ++s) {
+            for (int s = 0; s < 4; ++s) {
                 const bool hvalid = (16 * rt + 4 * kk + s) < H;
                 float2 twBn[MT];
 #pragma unroll
@@ -358,7 +386,8 @@ static int ft_device_cu_count() {
 static size_t fwd_ft_lds_bytes(const Dft2dParams& p, int NTF, int R4, int waves) {
     const int P = (p.W - 1) >> 1, nfull = P >> 4, prem = P - (nfull << 4);
     const int tailsteps = (prem + 1 + ((p.W & 1) ? 0 : 1) + 3) >> 2;
-    const size_t nk = (size_t)4 * nfull + tailsteps;
+    const size_t nk = (size_t)4 * nfull + FT_TAILMAX;      // allocated k-steps
+    (void)tailsteps;
     const size_t tile_stride = (size_t)((16 * p.W + 32 + 3) & ~3);
     const size_t red = (size_t)0;       // the reduction reuses the tile buffers
     return (size_t)waves * tile_stride * 4 + nk * ((size_t)NTF * 512 + (size_t)R4 * 128) + (size_t)p.H * 8 + FT_TAILMAX * 2 * 64 * 4 + red;
@@ -369,6 +398,11 @@ static bool fwd_ft_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtG
     const int NTF = R4 > 0 ? NT - 1 : NT;
     // the tile's rows sit W floats apart: W % 8 == 0 puts the 16 rows of an operand read on 4 or fewer LDS banks
     if (p.bf16 || p.rowfreq || p.W % 8 == 0 || ((p.W - 1) >> 1) < 16) return false;
+    // Measured (tools/kbench.py, 1024 images x 64 ch): 111^2 18.5 us against 21.5 for the register-path kernel, 223^2 47.9 / 47.3,
+    // 421^2 243 / 212: with one wave per SIMD the row stage's LDS / VALU work and its MFMAs run back to back instead of
+    // overlapping (ablations: 64 us of operand traffic + 83 us of row-stage MFMAs + 40 us of column stage + 60 us of exposed
+    // tile loads), which the three waves per SIMD of the register path hide.  Large tiles therefore stay on that kernel.
+    if (p.W > UNO_FT_MAXW) return false;
     if ((size_t)MT * NT * 8 * 64 > (size_t)16 * p.W) return false;             // reduction slots must fit a tile buffer
     const int nrt = (p.H + 15) / 16, cus = ft_device_cu_count();
     long long best_cost = -1;

@@ -22,6 +22,9 @@
 #include <algorithm>
 #include <cstdio>
 
+#ifndef UNO_EXP
+#define UNO_EXP 0
+#endif
 namespace uno {
 
 constexpr size_t HT_LDS_LIMIT = 160 * 1024;         // a workgroup may own the whole LDS of the CU
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
     // boundary below m, so element e of the run lands at dst + (m & 3) + e
     auto fetch_run = [&](int m, int len, float* dst) {
         const int ph = m & 3;
-        if (4 * lane < ph + len)
+        if (!(UNO_EXP & 1) && 4 * lane < ph + len)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, (unsigned)((m - ph + 4 * lane) * 4), 0, 0, 0);
     };
     auto request_outer = [&](int rt) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
 #pragma unroll
             for (int g = 0; g < NQ; ++g) { Qr[g] = f32x4{0, 0, 0, 0}; Qn[g] = f32x4{0, 0, 0, 0}; }
 #define UNO_HT_MFMA(E_, D_, TWF_, TW4_)                                                   \
-    do {                                                                                  \
+    do { if (UNO_EXP & 2) { Tr[0][0] += (E_) * (TWF_)[0].x; Tn[0][1] += (D_) * (TW4_)[0].y; break; }                     \
         _Pragma("unroll") for (int t = 0; t < NTF; ++t) {                                 \
             Tr[t] = mfma16((E_), (TWF_)[t].x, Tr[t]);                                     \
             Tn[t] = mfma16((D_), (TWF_)[t].y, Tn[t]);                                     \
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
                 idxB[mt] = wrap_add(i0, 8u * (unsigned)Kj[mt], H8);
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < ((UNO_EXP & 4) ? 1 : 4); ++s) {
                 const bool hvalid = (16 * rt + 4 * kk + s) < H;
                 float2 twBn[MT];
 #pragma unroll
@@ -421,9 +424,6 @@ static bool fwd_ht_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtG
     const int NTF = R4 > 0 ? NT - 1 : NT;
     const int P = (p.W - 1) >> 1, nfull = P >> 4;
     if (p.bf16 || p.rowfreq || nfull < 2 || p.W <= UNO_FT_MAXW) return false;
-    // measured (1024 images, in-block, input cold): 421^2 227 us against 257 for the register path, 446^2 218 / 230, 223^2 51 / 47:
-    // short rows make short runs (a run of the inner half of a 223-wide row is 0.4 KB), the register path keeps those
-    if (p.W < 300) return false;
     const HtSplit sp = ht_split(p.W);
     if (sp.QL + sp.QR + 3 > 256 || sp.len_in + 3 > 256 || sp.len_in < 8) return false;      // a run is one 64-lane x 16-byte fetch
     if ((size_t)MT * NT * 8 * 64 > (size_t)(sp.s0 + 15 * sp.seg)) return false;          // reduction slots must fit a buffer

@@ -20,6 +20,7 @@
 #pragma once
 #include "uno_common.h"
 #include "dft2d_fwd_ft_kernel.h"
+#include "dft2d_fwd_ht_kernel.h"
 #include <cstdio>
 
 #ifndef UNO_ABLATE
@@ -388,7 +389,7 @@ static int launch_fwd_b(const Dft2dParams& p, hipStream_t s) {
         }
     }
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d%s>", NT, MT, VEC ? "true" : "false", R4, BF16 ? ", bf16" : "");
+    snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d, %s>", NT, MT, VEC ? "true" : "false", R4, BF16 ? "true" : "false");
     {
         ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * (BF16 ? 2.0 : 4.0) + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3(p.n_img), dim3(64 * NW), lds, s, p);
@@ -403,6 +404,7 @@ static int launch_fwd_t(const Dft2dParams& p, hipStream_t s) {
     if constexpr (VEC) {
         FwdFtGeometry ft;
         if (fwd_ft_geometry(p, NT, MT, R4, &ft)) return launch_fwd_ft<NT, MT, R4>(p, ft, s);
+        if (fwd_ht_geometry(p, NT, MT, R4, &ft)) return launch_fwd_ht<NT, MT, R4>(p, ft, s);
     }
     return p.bf16 ? launch_fwd_b<NT, MT, VEC, R4, true>(p, s) : launch_fwd_b<NT, MT, VEC, R4, false>(p, s);
 }
