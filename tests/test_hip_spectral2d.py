@@ -297,3 +297,42 @@ def test_spectral_conv1d_runs_on_the_2d_kernels(cfg):
     assert rel_err(yg.detach().cpu().numpy(), yr.detach().numpy()) < TOL
     assert rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) < TOL
     assert rel_err(gpu.weights1.grad.cpu().numpy(), ref.weights1.grad.numpy()) < TOL
+
+
+# ------------------------------------------------------------------ mode counts beyond the MFMA kernels' compiled range
+@pytest.mark.parametrize("cfg", [
+    # B, Ci, Co, H, W, Ho, Wo, m1, m2
+    (2, 3, 4, 100, 100, 100, 100, 49, 50),      # the reference's DEFAULT modes: dim1//2 - 1, dim2//2 (integral_operators.py:153-158)
+    (1, 2, 2, 90, 120, 96, 110, 44, 20),        # only modes1 beyond 40
+    (1, 2, 3, 64, 130, 64, 140, 8, 60),         # only modes2 beyond 48
+    (1, 1, 2, 50, 50, 42, 44, 42, 10),          # overlap 2*m1 > H' with the any-mode form (later-wins mask)
+])
+def test_any_mode_count_vs_dense_oracle(cfg):
+    from uno_amd.integral_operators import spectral_conv2d
+    B, Ci, Co, H, W, Ho, Wo, m1, m2 = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w1 = 0.2 * torch.randn(Ci, Co, m1, m2, dtype=torch.cfloat, generator=g)
+    w2 = 0.2 * torch.randn(Ci, Co, m1, m2, dtype=torch.cfloat, generator=g)
+    gy = torch.randn(B, Co, Ho, Wo, generator=g)
+    xd, w1d, w2d = (t.to(dev()).requires_grad_(True) for t in (x, w1, w2))
+    y = spectral_conv2d(xd, w1d, w2d, Ho, Wo)
+    y.backward(gy.to(dev()))
+    y_ref, X = so.spectral_conv2d_dense(x.numpy(), w1.numpy(), w2.numpy(), Ho, Wo)
+    gx_ref, gw1_ref, gw2_ref, _, _ = so.spectral_conv2d_dense_bwd(gy.numpy(), X, w1.numpy(), w2.numpy(), H, W)
+    assert rel_err(y.detach().cpu().numpy(), y_ref) < TOL
+    assert rel_err(xd.grad.cpu().numpy(), gx_ref) < TOL
+    assert rel_err(w1d.grad.cpu().numpy(), gw1_ref) < TOL
+    assert rel_err(w2d.grad.cpu().numpy(), gw2_ref) < TOL
+
+
+def test_default_modes_module_runs_like_the_reference():
+    """SpectralConv2d_Uno built WITHOUT modes (reference defaults dim1//2 - 1, dim2//2) against the reference's op sequence."""
+    from uno_amd.integral_operators import SpectralConv2d_Uno
+    torch.manual_seed(11)
+    conv = SpectralConv2d_Uno(3, 2, 120, 120)
+    assert (conv.modes1, conv.modes2) == (59, 60)
+    x = torch.randn(2, 3, 120, 120)
+    y_ref = so.spectral_conv2d_fft(x, conv.weights1.detach(), conv.weights2.detach(), 120, 120)
+    y = conv.to(dev())(x.to(dev()))
+    assert rel_err(y.detach().cpu().numpy(), y_ref.numpy()) < TOL

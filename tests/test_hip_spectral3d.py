@@ -171,3 +171,24 @@ def test_fft_resample3d_matches_the_reference_op_sequence(cfg):
     assert y.shape == yr.shape
     assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL
     assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < TOL
+
+
+def test_3d_any_mode_count_vs_dense_oracle():
+    """modes beyond the MFMA kernels' range on every axis role: modes1 = 42 (> 40, leading axis: any-mode K5 / K6) and plane modes
+    (m2, m3) = (4, 50) (> 48 half-spectrum bins: any-mode plane transforms)."""
+    from uno_amd.spectral3d import spectral_conv3d
+    for (B, Ci, Co, H, W, T, Ho, Wo, To, m1, m2, m3) in [(1, 1, 2, 44, 8, 6, 44, 8, 6, 42, 4, 3), (1, 2, 1, 6, 10, 100, 6, 10, 100, 3, 4, 50)]:
+        g = torch.Generator().manual_seed(H + T)
+        x = torch.randn(B, Ci, H, W, T, generator=g)
+        ws = [0.2 * torch.randn(Ci, Co, m1, m2, m3, dtype=torch.cfloat, generator=g) for _ in range(4)]
+        gy = torch.randn(B, Co, Ho, Wo, To, generator=g)
+        xd = x.to(dev()).requires_grad_(True)
+        wd = [w.to(dev()).requires_grad_(True) for w in ws]
+        y = spectral_conv3d(xd, wd, Ho, Wo, To)
+        y.backward(gy.to(dev()))
+        y_ref, X = so.spectral_conv3d_dense(x.numpy(), [w.numpy() for w in ws], Ho, Wo, To)
+        gx_ref, gws_ref = so.spectral_conv3d_dense_bwd(gy.numpy(), X, [w.numpy() for w in ws], H, W, T)[:2]
+        assert rel_err(y.detach().cpu().numpy(), y_ref) < 2e-5
+        assert rel_err(xd.grad.cpu().numpy(), gx_ref) < 2e-5
+        for got, ref in zip(wd, gws_ref):
+            assert rel_err(got.grad.cpu().numpy(), ref) < 2e-5

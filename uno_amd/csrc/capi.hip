@@ -125,6 +125,8 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     p.twH = twiddle_table(H);
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
+    // mode counts beyond the compiled MFMA range (the reference's default modes, integral_operators.py:153-158): any-mode form
+    if (m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, s);
     // many small images (3-D planes, coarse 2-D levels): plane-batched kernels (dft2d_plane.hip)
     if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
         return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);
@@ -425,6 +427,7 @@ int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, in
     p.scale = scale; p.mask = mask_overlap ? 1 : 0; p.rowfreq = nullptr;
     p.tw = twiddle_table(H);
     if (!p.tw) return -6;
+    if (m1 > 40) return launch_cdft_generic(p, inverse != 0, (hipStream_t)stream);
     return launch_cdft(p, inverse != 0, (hipStream_t)stream);
 }
 

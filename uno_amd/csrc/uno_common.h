@@ -150,6 +150,8 @@ int launch_dft2d_fwd_plane(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv_plane(const Dft2dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
+int launch_dft2d_generic(const Dft2dParams& p, bool inverse, hipStream_t s);      // dft_generic.hip: any mode count
+int launch_cdft_generic(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
                       const float* tile_w, int NP, int accumulate, hipStream_t s);
