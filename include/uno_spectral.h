@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 3
+#define UNO_SPECTRAL_ABI_VERSION 4
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -215,6 +215,46 @@ int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int
 int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                         const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Mixed precision (BASELINE.json configs[4]: bf16 activations, half-precision weight storage, f32 accumulation).
+ * The reference has no behaviour here (integral_operators.py:187 raises on bfloat16 input); the contract is "the float32
+ * operator applied to the values the kernels read (inputs rounded once to bf16 / fp16), output rounded once to bf16".
+ * `_bf16` entry points are their float32 namesakes with ACTIVATION tensors (x, y, grad tensors, `dgelu_of`) stored as
+ * bfloat16 (void*); weights, biases, statistics, weight gradients, spectra and every accumulation stay float32 / complex64.
+ * `_f16w` / `_mixed`: the complex weights are read as (re, im) float16 pairs; weight gradients come back complex64 (they
+ * belong to the float32 master copy an optimiser keeps).
+ */
+int uno_spectral_conv2d_forward_mixed(const void* x_bf16, const void* w1_f16, const void* w2_f16, void* y_bf16,
+                                      float* xtrunc, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                      int modes1, int modes2, void* stream);
+int uno_spectral_conv2d_backward_mixed(const void* gy_bf16, const float* xtrunc, const void* w1_f16, const void* w2_f16,
+                                       void* gx_bf16, float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W,
+                                       int Ho, int Wo, int modes1, int modes2, void* stream);
+int uno_mode_mix_f16w(const float* in, const void* const* w_f16, float* out, int op, int B, int Ci, int Co, int ncorner,
+                      int modes_per_corner, void* stream);
+int uno_dft2d_forward_grouped_bf16(const void* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
+                                   int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream);
+int uno_dft2d_inverse_grouped_bf16(const float* spec, void* images, int n_img, int H, int W, int m1, int m2, float scale,
+                                   int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream);
+int uno_resample2d_bf16(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+                        const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                        const float* tile_w, int NP, int accumulate, void* stream);
+int uno_channel_mix_bf16(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
+                         int transpose_w, int accumulate, int act_in, const void* dgelu_of, void* stream);
+int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
+                           int act_x, void* stream);
+int uno_gelu_project_forward_bf16(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P,
+                                  void* stream);
+int uno_gelu_project_backward_bf16(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb,
+                                   void* ws, int B, int C, long long P, void* stream);
+int uno_gelu_pad_bf16(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward,
+                      void* stream);
+int uno_instnorm_forward_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                              long long rows, int C, long long N, float eps, int gelu, void* stream);
+int uno_instnorm_backward_bf16(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean,
+                               const float* rstd, void* gx, float* s1, float* s2, long long rows, int C, long long N,
+                               int gelu, void* stream);
 
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.

@@ -100,3 +100,20 @@ def test_c5_model_training_step_float32():
     assert all(v > 0 for k, v in gn.items() if k not in zero_ok), [k for k, v in gn.items() if v == 0]
     l0b, l1b, _ = run()
     assert (l0, l1) == (l0b, l1b)
+
+
+def test_c5_model_training_step_mixed_precision():
+    """The configs[4] workload itself: UNO_9(3, 64, pad=5) at S = 1024 with bf16 activations + fp16 spectral weights (f32
+    accumulation, f32 master weights / Adam), batch 2: finite decreasing loss that tracks the float32 step from the same init
+    (2 %), deterministic repeat."""
+    from uno_amd.harness import DarcyTrainer, MixedDarcyTrainer, UNO_9, synthetic_darcy_batch
+    a, u = synthetic_darcy_batch(2, S, 77, dev())
+    def run(cls):
+        torch.manual_seed(0)
+        model = UNO_9(3, 64, pad=5).to(dev())
+        tr = cls(model, lr=1e-3, weight_decay=1e-3)
+        return [float(tr.step(a, u)) for _ in range(2)]
+    lm, lf = run(MixedDarcyTrainer), run(DarcyTrainer)
+    assert all(np.isfinite(lm)) and lm[1] < lm[0]
+    assert np.allclose(lm, lf, rtol=2e-2)
+    assert run(MixedDarcyTrainer) == lm

@@ -173,6 +173,7 @@ def test_fft_resample3d_matches_the_reference_op_sequence(cfg):
     assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < TOL
 
 
+@pytest.mark.gpu
 def test_3d_any_mode_count_vs_dense_oracle():
     """modes beyond the MFMA kernels' range on every axis role: modes1 = 42 (> 40, leading axis: any-mode K5 / K6) and plane modes
     (m2, m3) = (4, 50) (> 48 half-spectrum bins: any-mode plane transforms)."""

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _lock = threading.Lock()
@@ -58,6 +58,19 @@ _SIGNATURES = {
     "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
     "uno_adam_step_multi": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
                                       C.POINTER(_i)] + [C.c_double] * 5 + [_i, _fp]),
+    "uno_spectral_conv2d_forward_mixed": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
+    "uno_spectral_conv2d_backward_mixed": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
+    "uno_mode_mix_f16w": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
+    "uno_dft2d_forward_grouped_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
+    "uno_dft2d_inverse_grouped_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
+    "uno_resample2d_bf16": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _fp]),
+    "uno_channel_mix_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
+    "uno_channel_wgrad_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_gelu_project_forward_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
+    "uno_gelu_project_backward_bf16": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
+    "uno_gelu_pad_bf16": (C.c_int, [_fp, _fp, _fp] + [_i] * 6 + [_fp]),
+    "uno_instnorm_forward_bf16": (C.c_int, [_fp] * 6 + [C.c_longlong, _i, C.c_longlong, C.c_float, _i, _fp]),
+    "uno_instnorm_backward_bf16": (C.c_int, [_fp] * 9 + [C.c_longlong, _i, C.c_longlong, _i, _fp]),
     "uno_profile_begin": (C.c_int, [_i]),
     "uno_profile_end": (C.c_int, []),
     "uno_profile_get": (C.c_int, [_i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -117,13 +130,27 @@ def _act_dtype(t, name):
     return bf16
 
 
+def _weights_half(w1, w2, bf16):
+    """True when the complex weights come as (..., 2) float16 (re, im) storage (mixed precision: bf16 activations only)."""
+    if w1.dtype == torch.float16:
+        if not bf16:
+            raise RuntimeError("uno_amd: half-precision weight storage goes with bfloat16 activations")
+        for w, name in ((w1, "weights1"), (w2, "weights2")):
+            _require(w, torch.float16, name)
+            if w.dim() != 5 or w.shape[-1] != 2:
+                raise RuntimeError("uno_amd: half-precision weights are stored as (Ci, Co, m1, m2, 2) = (re, im)")
+        return True
+    _require(w1, torch.complex64, "weights1")
+    _require(w2, torch.complex64, "weights2")
+    return False
+
+
 def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
     """-> (y (B,Co,Ho,Wo) in x's dtype (f32 | bf16), xtrunc (B,Ci,2*m1,m2) c64)."""
     bf16 = _act_dtype(x, "x")
-    _require(w1, torch.complex64, "weights1")
-    _require(w2, torch.complex64, "weights2")
+    wh = _weights_half(w1, w2, bf16)
     B, Ci, H, W = x.shape
-    Ci2, Co, m1, m2 = w1.shape
+    Ci2, Co, m1, m2 = w1.shape[:4]
     if Ci2 != Ci or tuple(w2.shape) != tuple(w1.shape):
         raise RuntimeError(f"uno_amd: weight shapes {tuple(w1.shape)} / {tuple(w2.shape)} do not match input channels {Ci}")
     L = lib()
@@ -131,7 +158,7 @@ def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
         y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
         xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x.device)
         ws = torch.empty(max(1, L.uno_spectral_conv2d_fwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=x.device)
-        fn = L.uno_spectral_conv2d_forward_bf16 if bf16 else L.uno_spectral_conv2d_forward
+        fn = L.uno_spectral_conv2d_forward_mixed if wh else (L.uno_spectral_conv2d_forward_bf16 if bf16 else L.uno_spectral_conv2d_forward)
         rc = fn(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws),
                                            B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(x))
     _check(rc, "uno_spectral_conv2d_forward")
@@ -142,20 +169,19 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
     """-> (gx or None (gy's dtype: f32 | bf16), gw1 or None, gw2 or None (c64))."""
     bf16 = _act_dtype(gy, "grad_output")
     _require(xt, torch.complex64, "xtrunc")
-    _require(w1, torch.complex64, "weights1")
-    _require(w2, torch.complex64, "weights2")
+    wh = _weights_half(w1, w2, bf16)
     B, Co, Ho, Wo = gy.shape
-    Ci, Co2, m1, m2 = w1.shape
+    Ci, Co2, m1, m2 = w1.shape[:4]
     if Co2 != Co:
         raise RuntimeError("uno_amd: grad_output channels do not match the weights")
     L = lib()
     with torch.cuda.device(gy.device):
         gx = torch.empty((B, Ci, H, W), dtype=gy.dtype, device=gy.device) if need_gx else None
-        gw1 = torch.empty_like(w1) if need_gw else None
-        gw2 = torch.empty_like(w2) if need_gw else None
+        gw1 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
+        gw2 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
         ws = torch.empty(max(1, L.uno_spectral_conv2d_bwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=gy.device)
         null = C.c_void_p(0)
-        fn = L.uno_spectral_conv2d_backward_bf16 if bf16 else L.uno_spectral_conv2d_backward
+        fn = L.uno_spectral_conv2d_backward_mixed if wh else (L.uno_spectral_conv2d_backward_bf16 if bf16 else L.uno_spectral_conv2d_backward)
         rc = fn(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2),
                                             _ptr(gx) if need_gx else null,
                                             _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
@@ -192,8 +218,6 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
     """images (..., H, W) f32 -> spectra (..., 2*m1, m2) c64.  With `out` (B, Ctot, 2*m1, m2) and images (B, C1, H, W) the
     spectra go to channels [channel_offset, channel_offset + C1) of `out`.  bf16 images: plain form only."""
     bf16 = _act_dtype(images, "images")
-    if bf16 and out is not None:
-        raise RuntimeError("uno_amd: the grouped spectrum layout takes float32 images")
     *lead, H, W = images.shape
     n = 1
     for d in lead:
@@ -210,8 +234,9 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
             or channel_offset < 0 or channel_offset + images.shape[1] > out.shape[1]:
         raise RuntimeError("uno_amd: out must be (B, Ctot, 2*m1, m2) with room for the image channels at channel_offset")
     with torch.cuda.device(images.device):
-        rc = lib().uno_dft2d_forward_grouped(_ptr(images), _ptr(out), n, H, W, m1, m2, float(scale), int(hermitian_cols),
-                                             int(mask_overlap), images.shape[1], out.shape[1], int(channel_offset), _stream(images))
+        fn = lib().uno_dft2d_forward_grouped_bf16 if bf16 else lib().uno_dft2d_forward_grouped
+        rc = fn(_ptr(images), _ptr(out), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                int(mask_overlap), images.shape[1], out.shape[1], int(channel_offset), _stream(images))
     _check(rc, "uno_dft2d_forward_grouped")
     return out
 
@@ -235,15 +260,16 @@ def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True,
             rc = fn(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(spec))
         _check(rc, "uno_dft2d_inverse")
         return img
-    if dtype != torch.float32:
-        raise RuntimeError("uno_amd: the grouped spectrum layout produces float32 images")
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("uno_amd: images are float32 or bfloat16")
     if spec.dim() != 4 or channel_offset < 0 or channels < 1 or channel_offset + channels > spec.shape[1]:
         raise RuntimeError("uno_amd: spec must be (B, Ctot, 2*m1, m2) holding the requested channel range")
     B = spec.shape[0]
-    img = torch.empty((B, channels, H, W), dtype=torch.float32, device=spec.device)
+    img = torch.empty((B, channels, H, W), dtype=dtype, device=spec.device)
     with torch.cuda.device(spec.device):
-        rc = lib().uno_dft2d_inverse_grouped(_ptr(spec), _ptr(img), B * channels, H, W, m1, m2, float(scale), int(hermitian_cols),
-                                             int(mask_overlap), int(channels), spec.shape[1], int(channel_offset), _stream(spec))
+        fn = lib().uno_dft2d_inverse_grouped_bf16 if dtype == torch.bfloat16 else lib().uno_dft2d_inverse_grouped
+        rc = fn(_ptr(spec), _ptr(img), B * channels, H, W, m1, m2, float(scale), int(hermitian_cols),
+                int(mask_overlap), int(channels), spec.shape[1], int(channel_offset), _stream(spec))
     _check(rc, "uno_dft2d_inverse_grouped")
     return img
 
@@ -255,16 +281,18 @@ def _ptr_array(ts):
 def mode_mix(inp, weights, op: int):
     """inp (B, Cin, ncorner, modes) c64; weights: list of (Ci, Co, modes...) c64."""
     _require(inp, torch.complex64, "spectrum")
+    half = weights[0].dtype == torch.float16
     for w in weights:
-        _require(w, torch.complex64, "weights")
+        _require(w, torch.float16 if half else torch.complex64, "weights")
     B = inp.shape[0]
     Ci, Co = weights[0].shape[:2]
     nc = len(weights)
-    Mc = weights[0][0, 0].numel()
+    Mc = weights[0][0, 0].numel() // (2 if half else 1)
     cout = Co if op == 0 else Ci
     out = torch.empty((B, cout, *inp.shape[2:]), dtype=torch.complex64, device=inp.device)
     with torch.cuda.device(inp.device):
-        rc = lib().uno_mode_mix(_ptr(inp), _ptr_array(weights), _ptr(out), op, B, Ci, Co, nc, Mc, _stream(inp))
+        fn = lib().uno_mode_mix_f16w if half else lib().uno_mode_mix
+        rc = fn(_ptr(inp), _ptr_array(weights), _ptr(out), op, B, Ci, Co, nc, Mc, _stream(inp))
     _check(rc, "uno_mode_mix")
     return out
 
@@ -333,7 +361,7 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
     """x (..., H, W) f32 -> (..., Ho, Wo); tabX = (start int32 [out], weights f32 [out, K]) band tables on x.device;
     tilesH = (p0 int32 [ntiles], dense weights f32 [ntiles, NP, 16]) enables the fused single-pass kernel.
     out: accumulate into this (..., Ho, Wo) tensor instead of allocating the result."""
-    _require(x, torch.float32, "x")
+    bf16 = _act_dtype(x, "x")
     *lead, H, W = x.shape
     n = 1
     for d in lead:
@@ -342,11 +370,11 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
     sW, wW = tabW
     accumulate = out is not None
     if accumulate:
-        _require(out, torch.float32, "out")
+        _require(out, x.dtype, "out")
         if tuple(out.shape) != (*lead, Ho, Wo):
             raise RuntimeError(f"uno_amd: out has shape {tuple(out.shape)}, expected {(*lead, Ho, Wo)}")
     else:
-        out = torch.empty((*lead, Ho, Wo), dtype=torch.float32, device=x.device)
+        out = torch.empty((*lead, Ho, Wo), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
         tmp = torch.empty(max(1, n * min(Ho * W, H * Wo)), dtype=torch.float32, device=x.device)
         if tilesH is not None:
@@ -354,8 +382,9 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
             targs = (_ptr(tp0), _ptr(tw), tw.shape[1])
         else:
             targs = (C.c_void_p(0), C.c_void_p(0), 0)
-        rc = lib().uno_resample2d(_ptr(x), _ptr(out), _ptr(tmp), n, H, W, Ho, Wo, _ptr(sH), _ptr(wH), wH.shape[1],
-                                  _ptr(sW), _ptr(wW), wW.shape[1], *targs, 1 if accumulate else 0, _stream(x))
+        fn = lib().uno_resample2d_bf16 if bf16 else lib().uno_resample2d
+        rc = fn(_ptr(x), _ptr(out), _ptr(tmp), n, H, W, Ho, Wo, _ptr(sH), _ptr(wH), wH.shape[1],
+                _ptr(sW), _ptr(wW), wW.shape[1], *targs, 1 if accumulate else 0, _stream(x))
     _check(rc, "uno_resample2d")
     return out
 
@@ -364,7 +393,7 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
     """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias;
     out: accumulate into this (B, Co, P) tensor instead; act_in: x := gelu(x) as it is read; dgelu_of (B, Co, P): the
     product is multiplied by gelu'(dgelu_of)."""
-    _require(x, torch.float32, "x")
+    bf16 = _act_dtype(x, "x")
     _require(w, torch.float32, "weight")
     if bias is not None:
         _require(bias, torch.float32, "bias")
@@ -374,18 +403,19 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
         raise RuntimeError(f"uno_amd: weight {tuple(w.shape)} does not match {Ci} input channels")
     accumulate = out is not None
     if accumulate:
-        _require(out, torch.float32, "out")
+        _require(out, x.dtype, "out")
         if tuple(out.shape) != (B, Co, P):
             raise RuntimeError(f"uno_amd: out has shape {tuple(out.shape)}, expected {(B, Co, P)}")
         y = out
     else:
-        y = torch.empty((B, Co, P), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, Co, P), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
         if dgelu_of is not None:
-            _require(dgelu_of, torch.float32, "dgelu_of")
+            _require(dgelu_of, x.dtype, "dgelu_of")
             if tuple(dgelu_of.shape) != (B, Co, P):
                 raise RuntimeError(f"uno_amd: dgelu_of has shape {tuple(dgelu_of.shape)}, expected {(B, Co, P)}")
-        rc = lib().uno_channel_mix(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y),
+        fn = lib().uno_channel_mix_bf16 if bf16 else lib().uno_channel_mix
+        rc = fn(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y),
                                    B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, 1 if act_in else 0,
                                    _ptr(dgelu_of) if dgelu_of is not None else C.c_void_p(0), _stream(x))
     _check(rc, "uno_channel_mix")
@@ -394,8 +424,8 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
 
 def channel_wgrad(gy, x, need_bias: bool = True, act_x: bool = False):
     """gy (B, Co, P), x (B, Ci, P) -> gw (Co, Ci), gb (Co) or None; act_x: x := gelu(x) as it is read."""
-    _require(gy, torch.float32, "grad_output")
-    _require(x, torch.float32, "x")
+    bf16 = _act_dtype(gy, "grad_output")
+    _require(x, gy.dtype, "x")
     B, Co, P = gy.shape
     B2, Ci, P2 = x.shape
     if (B2, P2) != (B, P):
@@ -405,7 +435,8 @@ def channel_wgrad(gy, x, need_bias: bool = True, act_x: bool = False):
     gb = torch.empty((Co,), dtype=torch.float32, device=x.device) if need_bias else None
     with torch.cuda.device(x.device):
         ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, P)), dtype=torch.uint8, device=x.device)
-        rc = L.uno_channel_wgrad(_ptr(gy), _ptr(x), _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws),
+        fn = L.uno_channel_wgrad_bf16 if bf16 else L.uno_channel_wgrad
+        rc = fn(_ptr(gy), _ptr(x), _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws),
                                  B, Ci, Co, P, 1 if act_x else 0, _stream(x))
     _check(rc, "uno_channel_wgrad")
     return gw, gb
@@ -428,16 +459,16 @@ def adam_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float, eps:
 
 def gelu_project_forward(pre, w, bias=None):
     """pre (B, C, P) f32, w (C,), bias (1,) or None -> out (B, P) = bias + sum_c w[c] gelu(pre[:, c])."""
-    _require(pre, torch.float32, "pre")
+    bf16 = _act_dtype(pre, "pre")
     _require(w, torch.float32, "weight")
     if bias is not None:
         _require(bias, torch.float32, "bias")
     B, Cc, P = pre.shape
     if w.numel() != Cc:
         raise RuntimeError(f"uno_amd: weight has {w.numel()} entries for {Cc} channels")
-    out = torch.empty((B, P), dtype=torch.float32, device=pre.device)
+    out = torch.empty((B, P), dtype=pre.dtype, device=pre.device)
     with torch.cuda.device(pre.device):
-        rc = lib().uno_gelu_project_forward(_ptr(pre), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(out),
+        rc = (lib().uno_gelu_project_forward_bf16 if bf16 else lib().uno_gelu_project_forward)(_ptr(pre), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(out),
                                             B, Cc, P, _stream(pre))
     _check(rc, "uno_gelu_project_forward")
     return out
@@ -445,9 +476,9 @@ def gelu_project_forward(pre, w, bias=None):
 
 def gelu_project_backward(pre, w, gout, need_bias=True):
     """-> gpre (B, C, P), gw (C,), gb (1,) or None."""
-    _require(pre, torch.float32, "pre")
+    bf16 = _act_dtype(pre, "pre")
     _require(w, torch.float32, "weight")
-    _require(gout, torch.float32, "grad_output")
+    _require(gout, pre.dtype, "grad_output")
     B, Cc, P = pre.shape
     if tuple(gout.shape) != (B, P):
         raise RuntimeError("uno_amd: grad_output shape does not match (batch, pixels)")
@@ -457,7 +488,7 @@ def gelu_project_backward(pre, w, gout, need_bias=True):
     gb = torch.empty((1,), dtype=torch.float32, device=pre.device) if need_bias else None
     with torch.cuda.device(pre.device):
         ws = torch.empty(max(1, L.uno_gelu_project_bwd_ws_bytes(B, Cc, P)), dtype=torch.uint8, device=pre.device)
-        rc = L.uno_gelu_project_backward(_ptr(pre), _ptr(w), _ptr(gout), _ptr(gpre), _ptr(gw),
+        rc = (L.uno_gelu_project_backward_bf16 if bf16 else L.uno_gelu_project_backward)(_ptr(pre), _ptr(w), _ptr(gout), _ptr(gpre), _ptr(gw),
                                          _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws), B, Cc, P, _stream(pre))
     _check(rc, "uno_gelu_project_backward")
     return gpre, gw, gb
@@ -465,22 +496,22 @@ def gelu_project_backward(pre, w, gout, need_bias=True):
 
 def gelu_pad(s, Hp: int, Wp: int):
     """s (..., H, W) f32 -> (..., Hp, Wp) = zero-pad(gelu(s)) at the end of both axes."""
-    _require(s, torch.float32, "s")
+    bf16 = _act_dtype(s, "s")
     *lead, H, W = s.shape
     n = 1
     for d in lead:
         n *= d
-    out = torch.empty((*lead, Hp, Wp), dtype=torch.float32, device=s.device)
+    out = torch.empty((*lead, Hp, Wp), dtype=s.dtype, device=s.device)
     with torch.cuda.device(s.device):
-        rc = lib().uno_gelu_pad(_ptr(s), C.c_void_p(0), _ptr(out), n, H, W, Hp, Wp, 0, _stream(s))
+        rc = (lib().uno_gelu_pad_bf16 if bf16 else lib().uno_gelu_pad)(_ptr(s), C.c_void_p(0), _ptr(out), n, H, W, Hp, Wp, 0, _stream(s))
     _check(rc, "uno_gelu_pad")
     return out
 
 
 def gelu_pad_backward(s, gy):
     """gs (..., H, W) = gelu'(s) * gy[..., :H, :W]."""
-    _require(s, torch.float32, "s")
-    _require(gy, torch.float32, "grad_output")
+    bf16 = _act_dtype(s, "s")
+    _require(gy, s.dtype, "grad_output")
     *lead, H, W = s.shape
     Hp, Wp = gy.shape[-2:]
     n = 1
@@ -488,14 +519,14 @@ def gelu_pad_backward(s, gy):
         n *= d
     out = torch.empty_like(s)
     with torch.cuda.device(s.device):
-        rc = lib().uno_gelu_pad(_ptr(s), _ptr(gy), _ptr(out), n, H, W, Hp, Wp, 1, _stream(s))
+        rc = (lib().uno_gelu_pad_bf16 if bf16 else lib().uno_gelu_pad)(_ptr(s), _ptr(gy), _ptr(out), n, H, W, Hp, Wp, 1, _stream(s))
     _check(rc, "uno_gelu_pad")
     return out
 
 
 def instnorm_forward(x, gamma, beta, eps: float, gelu: bool):
     """x (B, C, *grid) f32 -> y, mean (B*C), rstd (B*C)."""
-    _require(x, torch.float32, "x")
+    bf16 = _act_dtype(x, "x")
     for t, name in ((gamma, "weight"), (beta, "bias")):
         if t is not None:
             _require(t, torch.float32, name)
@@ -507,7 +538,7 @@ def instnorm_forward(x, gamma, beta, eps: float, gelu: bool):
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     null = C.c_void_p(0)
     with torch.cuda.device(x.device):
-        rc = lib().uno_instnorm_forward(_ptr(x), _ptr(gamma) if gamma is not None else null, _ptr(beta) if beta is not None else null,
+        rc = (lib().uno_instnorm_forward_bf16 if bf16 else lib().uno_instnorm_forward)(_ptr(x), _ptr(gamma) if gamma is not None else null, _ptr(beta) if beta is not None else null,
                                         _ptr(y), _ptr(mean), _ptr(rstd), rows, Cc, N, float(eps), 1 if gelu else 0, _stream(x))
     _check(rc, "uno_instnorm_forward")
     return y, mean, rstd
@@ -515,8 +546,8 @@ def instnorm_forward(x, gamma, beta, eps: float, gelu: bool):
 
 def instnorm_backward(x, gy, gamma, beta, mean, rstd, gelu: bool):
     """-> gx, s1 (B, C), s2 (B, C): sums over the batch of s1 / s2 are the bias / weight gradients."""
-    _require(x, torch.float32, "x")
-    _require(gy, torch.float32, "grad_output")
+    bf16 = _act_dtype(x, "x")
+    _require(gy, x.dtype, "grad_output")
     B, Cc = x.shape[0], x.shape[1]
     rows = B * Cc
     N = x.numel() // max(rows, 1)
@@ -525,7 +556,7 @@ def instnorm_backward(x, gy, gamma, beta, mean, rstd, gelu: bool):
     s2 = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
     null = C.c_void_p(0)
     with torch.cuda.device(x.device):
-        rc = lib().uno_instnorm_backward(_ptr(x), _ptr(gy), _ptr(gamma) if gamma is not None else null,
+        rc = (lib().uno_instnorm_backward_bf16 if bf16 else lib().uno_instnorm_backward)(_ptr(x), _ptr(gy), _ptr(gamma) if gamma is not None else null,
                                          _ptr(beta) if beta is not None else null, _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(s1), _ptr(s2),
                                          rows, Cc, N, 1 if gelu else 0, _stream(x))
     _check(rc, "uno_instnorm_backward")

@@ -135,7 +135,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
 
 // op 0: forward mix, op 1: grad wrt input spectrum, op 2: weight grad
 static int mode_gemm(int op, const float2* act, const float2* const* w, const float2* go, float2* out_act,
-                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s) {
+                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s, int w_half = 0) {
     if (B < 0 || Ci < 1 || Co < 1 || nc < 1 || nc > 4 || Mc < 1) {
         set_error("mode gemm: bad sizes B=%d Ci=%d Co=%d corners=%d modes=%d", B, Ci, Co, nc, Mc);
         return -1;
@@ -144,6 +144,7 @@ static int mode_gemm(int op, const float2* act, const float2* const* w, const fl
     const long long P = (long long)nc * Mc;
     ModeGemmParams p;
     p.ncorner = nc; p.Mc = Mc;
+    p.A.half = 0; p.B.half = (op != 2 && w_half) ? 1 : 0;
     for (int c = 0; c < 4; ++c) { p.A.base[c] = nullptr; p.B.base[c] = nullptr; p.out[c] = nullptr; }
     if (op == 0) {              // O[b,o] = sum_i X[b,i] W[i,o]
         p.M = B; p.N = Co; p.K = Ci;
@@ -279,21 +280,45 @@ int uno_dft2d_forward_grouped(const float* images, float* spec, int n_img, int H
     return dft2d(false, images, spec, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream, group, stride, offset);
 }
 
+int uno_dft2d_forward_grouped_bf16(const void* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
+                                   int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream) {
+    if (group < 1) { set_error("uno_dft2d_forward_grouped_bf16: group must be positive"); return -1; }
+    return dft2d(false, static_cast<const float*>(images), spec, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap,
+                 (hipStream_t)stream, group, stride, offset, 1);
+}
+
+int uno_dft2d_inverse_grouped_bf16(const float* spec, void* images, int n_img, int H, int W, int m1, int m2, float scale,
+                                   int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream) {
+    if (group < 1) { set_error("uno_dft2d_inverse_grouped_bf16: group must be positive"); return -1; }
+    return dft2d(true, spec, static_cast<float*>(images), n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap,
+                 (hipStream_t)stream, group, stride, offset, 1);
+}
+
 int uno_dft2d_inverse_grouped(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale,
                               int hermitian_cols, int mask_overlap, int group, int stride, int offset, void* stream) {
     if (group < 1) { set_error("uno_dft2d_inverse_grouped: group must be positive"); return -1; }
     return dft2d(true, spec, images, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream, group, stride, offset);
 }
 
-int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,
-                 int modes_per_corner, void* stream) {
+static int mode_mix_impl(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,
+                         int modes_per_corner, void* stream, int w_half) {
     if (!w || (B > 0 && (!in || !out))) { set_error("uno_mode_mix: null pointer"); return -1; }
     if (op != 0 && op != 1) { set_error("uno_mode_mix: op must be 0 or 1"); return -1; }
     if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_mix: ncorner=%d out of range", ncorner); return -1; }
     for (int c = 0; c < ncorner; ++c)
         if (!w[c]) { set_error("uno_mode_mix: null weight pointer %d", c); return -1; }
     return mode_gemm(op, reinterpret_cast<const float2*>(in), reinterpret_cast<const float2* const*>(w), nullptr,
-                     reinterpret_cast<float2*>(out), nullptr, B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream);
+                     reinterpret_cast<float2*>(out), nullptr, B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream, w_half);
+}
+
+int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,
+                 int modes_per_corner, void* stream) {
+    return mode_mix_impl(in, w, out, op, B, Ci, Co, ncorner, modes_per_corner, stream, 0);
+}
+
+int uno_mode_mix_f16w(const float* in, const void* const* w, float* out, int op, int B, int Ci, int Co, int ncorner,
+                      int modes_per_corner, void* stream) {
+    return mode_mix_impl(in, reinterpret_cast<const float* const*>(w), out, op, B, Ci, Co, ncorner, modes_per_corner, stream, 1);
 }
 
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
@@ -306,21 +331,43 @@ int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B
                      reinterpret_cast<float2* const*>(gw), B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream);
 }
 
-int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
-                   const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
-                   const float* tile_w, int NP, int accumulate, void* stream) {
+static int resample2d_impl(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+                           const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                           const float* tile_w, int NP, int accumulate, int bf16, void* stream) {
     if (n_img < 0 || H < 1 || W < 1 || Ho < 1 || Wo < 1) { set_error("uno_resample2d: bad sizes"); return -1; }
     if (n_img == 0) return 0;
     if (!in || !out || !tmp || !startH || !wtH || !startW || !wtW) { set_error("uno_resample2d: null pointer"); return -1; }
-    return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, accumulate, (hipStream_t)stream);
+    return launch_resample2d(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, accumulate, bf16, (hipStream_t)stream);
+}
+
+int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+                   const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                   const float* tile_w, int NP, int accumulate, void* stream) {
+    return resample2d_impl(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, accumulate, 0, stream);
+}
+
+int uno_resample2d_bf16(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+                        const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
+                        const float* tile_w, int NP, int accumulate, void* stream) {
+    return resample2d_impl(in, out, tmp, n_img, H, W, Ho, Wo, startH, wtH, KH, startW, wtW, KW, tile_p0, tile_w, NP, accumulate, 1, stream);
+}
+
+static int channel_mix_impl(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
+                            int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, void* stream) {
+    if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
+    if (B == 0 || P == 0) return 0;
+    if (!x || !w || !y) { set_error("uno_channel_mix: null pointer"); return -1; }
+    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, bf16, (hipStream_t)stream);
 }
 
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
                     int transpose_w, int accumulate, int act_in, const float* dgelu_of, void* stream) {
-    if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
-    if (B == 0 || P == 0) return 0;
-    if (!x || !w || !y) { set_error("uno_channel_mix: null pointer"); return -1; }
-    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, (hipStream_t)stream);
+    return channel_mix_impl(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 0, stream);
+}
+
+int uno_channel_mix_bf16(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
+                         int transpose_w, int accumulate, int act_in, const void* dgelu_of, void* stream) {
+    return channel_mix_impl(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 1, stream);
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
@@ -328,8 +375,8 @@ long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
     return 4LL * channel_wgrad_ws_floats(B, Ci, Co, P, nullptr);
 }
 
-int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
-                      int act_x, void* stream) {
+static int channel_wgrad_impl(const void* gy, const void* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
+                              int act_x, int bf16, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (!gw) { set_error("uno_channel_wgrad: null pointer"); return -1; }
     if (B == 0 || P == 0) {
@@ -338,7 +385,17 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
         return 0;
     }
     if (!gy || !x || !ws) { set_error("uno_channel_wgrad: null pointer"); return -1; }
-    return launch_channel_wgrad(gy, x, gw, gb, (float*)ws, B, Ci, Co, P, act_x, (hipStream_t)stream);
+    return launch_channel_wgrad(gy, x, gw, gb, (float*)ws, B, Ci, Co, P, act_x, bf16, (hipStream_t)stream);
+}
+
+int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
+                      int act_x, void* stream) {
+    return channel_wgrad_impl(gy, x, gw, gb, ws, B, Ci, Co, P, act_x, 0, stream);
+}
+
+int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
+                           int act_x, void* stream) {
+    return channel_wgrad_impl(gy, x, gw, gb, ws, B, Ci, Co, P, act_x, 1, stream);
 }
 
 int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
@@ -366,11 +423,19 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
     return 0;
 }
 
-int uno_gelu_project_forward(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, void* stream) {
+static int gelu_project_forward_impl(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, void* stream) {
     if (B < 0 || C < 1 || P < 0) { set_error("uno_gelu_project_forward: bad sizes B=%d C=%d P=%lld", B, C, P); return -1; }
     if (B == 0 || P == 0) return 0;
     if (!pre || !w || !out) { set_error("uno_gelu_project_forward: null pointer"); return -1; }
-    return launch_gelu_project_fwd(pre, w, bias, out, B, C, P, (hipStream_t)stream);
+    return launch_gelu_project_fwd(pre, w, bias, out, B, C, P, bf16, (hipStream_t)stream);
+}
+
+int uno_gelu_project_forward(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, void* stream) {
+    return gelu_project_forward_impl(pre, w, bias, out, B, C, P, 0, stream);
+}
+
+int uno_gelu_project_forward_bf16(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, void* stream) {
+    return gelu_project_forward_impl(pre, w, bias, out, B, C, P, 1, stream);
 }
 
 long long uno_gelu_project_bwd_ws_bytes(int B, int C, long long P) {
@@ -378,8 +443,8 @@ long long uno_gelu_project_bwd_ws_bytes(int B, int C, long long P) {
     return 4LL * gelu_project_ws_floats(B, C, P);
 }
 
-int uno_gelu_project_backward(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws, int B,
-                              int C, long long P, void* stream) {
+static int gelu_project_backward_impl(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, void* ws, int B,
+                                      int C, long long P, int bf16, void* stream) {
     if (B < 0 || C < 1 || P < 0) { set_error("uno_gelu_project_backward: bad sizes B=%d C=%d P=%lld", B, C, P); return -1; }
     if (!gw) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
     if (B == 0 || P == 0) {
@@ -388,30 +453,68 @@ int uno_gelu_project_backward(const float* pre, const float* w, const float* gou
         return 0;
     }
     if (!pre || !w || !gout || !gpre || !ws) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
-    return launch_gelu_project_bwd(pre, w, gout, gpre, gw, gb, (float*)ws, B, C, P, (hipStream_t)stream);
+    return launch_gelu_project_bwd(pre, w, gout, gpre, gw, gb, (float*)ws, B, C, P, bf16, (hipStream_t)stream);
 }
 
-int uno_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, void* stream) {
+int uno_gelu_project_backward(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws, int B,
+                              int C, long long P, void* stream) {
+    return gelu_project_backward_impl(pre, w, gout, gpre, gw, gb, ws, B, C, P, 0, stream);
+}
+
+int uno_gelu_project_backward_bf16(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, void* ws, int B,
+                                   int C, long long P, void* stream) {
+    return gelu_project_backward_impl(pre, w, gout, gpre, gw, gb, ws, B, C, P, 1, stream);
+}
+
+static int gelu_pad_impl(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward, int bf16, void* stream) {
     if (n_img < 0 || H < 1 || W < 1 || Hp < H || Wp < W) { set_error("uno_gelu_pad: bad sizes (%d, %d) -> (%d, %d)", H, W, Hp, Wp); return -1; }
     if (n_img == 0) return 0;
     if (!s || !out || (backward && !gy)) { set_error("uno_gelu_pad: null pointer"); return -1; }
-    return launch_gelu_pad(s, gy, out, n_img, H, W, Hp, Wp, backward, (hipStream_t)stream);
+    return launch_gelu_pad(s, gy, out, n_img, H, W, Hp, Wp, backward, bf16, (hipStream_t)stream);
+}
+
+int uno_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, void* stream) {
+    return gelu_pad_impl(s, gy, out, n_img, H, W, Hp, Wp, backward, 0, stream);
+}
+
+int uno_gelu_pad_bf16(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward, void* stream) {
+    return gelu_pad_impl(s, gy, out, n_img, H, W, Hp, Wp, backward, 1, stream);
+}
+
+static int instnorm_forward_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
+                                 long long N, float eps, int gelu, int bf16, void* stream) {
+    if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_forward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }
+    if (rows == 0) return 0;
+    if (!x || !y || !mean || !rstd) { set_error("uno_instnorm_forward: null pointer"); return -1; }
+    return launch_instnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, N, eps, gelu, bf16, (hipStream_t)stream);
 }
 
 int uno_instnorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
                          long long N, float eps, int gelu, void* stream) {
-    if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_forward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }
+    return instnorm_forward_impl(x, gamma, beta, y, mean, rstd, rows, C, N, eps, gelu, 0, stream);
+}
+
+int uno_instnorm_forward_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
+                              long long N, float eps, int gelu, void* stream) {
+    return instnorm_forward_impl(x, gamma, beta, y, mean, rstd, rows, C, N, eps, gelu, 1, stream);
+}
+
+static int instnorm_backward_impl(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                  void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, int bf16, void* stream) {
+    if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_backward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }
     if (rows == 0) return 0;
-    if (!x || !y || !mean || !rstd) { set_error("uno_instnorm_forward: null pointer"); return -1; }
-    return launch_instnorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, N, eps, gelu, (hipStream_t)stream);
+    if (!x || !gy || !mean || !rstd || !gx || !s1 || !s2) { set_error("uno_instnorm_backward: null pointer"); return -1; }
+    return launch_instnorm_bwd(x, gy, gamma, beta, mean, rstd, gx, s1, s2, rows, C, N, gelu, bf16, (hipStream_t)stream);
 }
 
 int uno_instnorm_backward(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
                           float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, void* stream) {
-    if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_backward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }
-    if (rows == 0) return 0;
-    if (!x || !gy || !mean || !rstd || !gx || !s1 || !s2) { set_error("uno_instnorm_backward: null pointer"); return -1; }
-    return launch_instnorm_bwd(x, gy, gamma, beta, mean, rstd, gx, s1, s2, rows, C, N, gelu, (hipStream_t)stream);
+    return instnorm_backward_impl(x, gy, gamma, beta, mean, rstd, gx, s1, s2, rows, C, N, gelu, 0, stream);
+}
+
+int uno_instnorm_backward_bf16(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, void* stream) {
+    return instnorm_backward_impl(x, gy, gamma, beta, mean, rstd, gx, s1, s2, rows, C, N, gelu, 1, stream);
 }
 
 int uno_cdft_axis(const float* in, float* out, int inverse, int n_img, int H, int m1, int m2, int m3, float scale,
@@ -559,7 +662,7 @@ int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const flo
 }
 
 static int spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
-                                   int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream, int bf16) {
+                                   int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream, int bf16, int w_half = 0) {
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_forward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
     if (int rc = check_modes2d("uno_spectral_conv2d_forward", H, W, Ho, Wo, m1, m2)) return rc;
     if (B == 0) return 0;           // empty batch: nothing to do (empty tensors carry null pointers)
@@ -570,7 +673,7 @@ static int spectral_conv2d_forward(const float* x, const float* w1, const float*
     if (int rc = dft2d(false, x, xtrunc, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s, 0, 0, 0, bf16)) return rc;
     // einsum("bixy,ioxy->boxy") with weights1 / weights2                  (reference :198-203)
     const float* wv[2] = {w1, w2};
-    if (int rc = uno_mode_mix(xtrunc, wv, O, 0, B, Ci, Co, 2, m1 * m2, stream)) return rc;
+    if (int rc = mode_mix_impl(xtrunc, wv, O, 0, B, Ci, Co, 2, m1 * m2, stream, w_half)) return rc;
     // irfft2(out_ft, s=(Ho, Wo), norm="forward"), later-wins on overlapping rows (reference :190-206)
     return dft2d(true, O, y, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s, 0, 0, 0, bf16);
 }
@@ -588,7 +691,7 @@ int uno_spectral_conv2d_forward_bf16(const void* x, const float* w1, const float
 
 static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
                                     float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
-                                    int m1, int m2, void* stream, int bf16) {
+                                    int m1, int m2, void* stream, int bf16, int w_half = 0) {
     if (B > 0 && (!gy || !xtrunc || !w1 || !w2 || !ws)) { set_error("uno_spectral_conv2d_backward: null pointer"); return -1; }
     if ((gw1 == nullptr) != (gw2 == nullptr)) { set_error("uno_spectral_conv2d_backward: gw1/gw2 must both be given or both be NULL"); return -1; }
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_backward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
@@ -625,7 +728,7 @@ static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const 
     int rc_x = 0;
     if (gx && rc_w == 0) {
         const float* wv[2] = {w1, w2};
-        rc_x = uno_mode_mix(gO, wv, gX, 1, B, Ci, Co, 2, m1 * m2, stream);
+        rc_x = mode_mix_impl(gO, wv, gX, 1, B, Ci, Co, 2, m1 * m2, stream, w_half);
         // gx = 1/(H W) Re iDFT_trunc(gX)                                   (adjoint of rfft2(norm="forward"))
         if (rc_x == 0) rc_x = dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s, 0, 0, 0, bf16);
     }
@@ -648,6 +751,19 @@ int uno_spectral_conv2d_backward_bf16(const void* gy, const float* xtrunc, const
                                       int m1, int m2, void* stream) {
     return spectral_conv2d_backward(static_cast<const float*>(gy), xtrunc, w1, w2, static_cast<float*>(gx), gw1, gw2, ws, B, Ci, Co,
                                     H, W, Ho, Wo, m1, m2, stream, 1);
+}
+
+int uno_spectral_conv2d_forward_mixed(const void* x, const void* w1, const void* w2, void* y, float* xtrunc, void* ws,
+                                      int B, int Ci, int Co, int H, int W, int Ho, int Wo, int m1, int m2, void* stream) {
+    return spectral_conv2d_forward(static_cast<const float*>(x), static_cast<const float*>(w1), static_cast<const float*>(w2),
+                                   static_cast<float*>(y), xtrunc, ws, B, Ci, Co, H, W, Ho, Wo, m1, m2, stream, 1, 1);
+}
+
+int uno_spectral_conv2d_backward_mixed(const void* gy, const float* xtrunc, const void* w1, const void* w2, void* gx,
+                                       float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                       int m1, int m2, void* stream) {
+    return spectral_conv2d_backward(static_cast<const float*>(gy), xtrunc, static_cast<const float*>(w1), static_cast<const float*>(w2),
+                                    static_cast<float*>(gx), gw1, gw2, ws, B, Ci, Co, H, W, Ho, Wo, m1, m2, stream, 1, 1);
 }
 
 }  // extern "C"

@@ -23,11 +23,12 @@ constexpr int CM_WS = CM_MT + 16;   // LDS row stride of the W chunk  [KC][MT] (
 // four consecutive floats starting at row[px] with zeros past the row end (row has P >= 4 valid floats):
 // one unconditional 16-byte load from a clamped address, then a select network (no branches -> the load
 // stays in flight across the MFMA block)
-__device__ __forceinline__ float4 load4_tail(const float* row, int px, int P) {
+template <typename T>
+__device__ __forceinline__ float4 load4_tail(const T* row, int px, int P) {
     const int pc = min(px, P - 4);
-    const f4u v = *reinterpret_cast<const f4u*>(row + pc);
+    const float4 v = io_ld4(row + pc);
     const int sh = px - pc;
-    float t0 = v.v[0], t1 = v.v[1], t2 = v.v[2], t3 = v.v[3];
+    float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
     if (sh & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
     if (sh & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
     if (sh >= 4) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
@@ -45,22 +46,22 @@ __device__ __forceinline__ float cm_dgelu(float x) {
 __device__ __forceinline__ float4 cm_gelu4(float4 v) { return make_float4(cm_gelu(v.x), cm_gelu(v.y), cm_gelu(v.z), cm_gelu(v.w)); }
 
 struct ChannelMixParams {
-    const float* x;         // (B, Ci, P)
+    const void* x;          // (B, Ci, P) f32 | bf16 (BF instantiations: activations bfloat16, weights / accumulation f32)
     const float* w;         // Wm(o, i) = w[o * w_so + i * w_si]
     const float* bias;      // (Co) or nullptr
-    float* y;               // (B, Co, P)
+    void* y;                // (B, Co, P), x's element type
     int B, Ci, Co, P;
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
     int accumulate;         // y += instead of y =
-    const float* dgelu_of;  // nullptr, or (B, Co, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
+    const void* dgelu_of;   // nullptr, or (B, Co, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
 };
 
 // MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
 //         32-bit offsets from a uniform base - the per-element clamps and selects of the guarded path cost more
 //         VALU issue slots than the tile has MFMAs;  MODE 1: guarded 16-byte loads (P >= 4);  MODE 0: guarded scalars.
-template <int MODE, int PT, bool ACT = false, bool DG = false>
+template <int MODE, int PT, bool ACT = false, bool DG = false, bool BF = false>
 __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, float (*sX)[CM_KC * (PT + 16)], float (*sW)[CM_KC * CM_WS],
                                                  int p0, int o0, int b) {
     constexpr int XS = PT + 16;         // LDS row stride of the X chunk [KC][PT]: 4 consecutive rows hit disjoint bank groups
@@ -69,7 +70,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     constexpr int NM = PT / 16;         // pixel tiles of 16 = accumulators per wave
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* xb = p.x + (size_t)b * p.Ci * p.P;
+    using T = typename IoElem<BF>::type;                // float | unsigned short (bf16 bits)
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P;
+    T* const yall = reinterpret_cast<T*>(p.y);
+    const T* const dall = reinterpret_cast<const T*>(p.dgelu_of);
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
     //               8 single elements (row e / 128, px e % 128);  W chunk = 16 k x 64 o -> 4 elements (k e % 16, o e / 16)
@@ -81,8 +85,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                const f4u v = *reinterpret_cast<const f4u*>(xb + (unsigned)((k0 + (e / F4R)) * p.P + p0 + (e % F4R) * 4));
-                rx[u] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+                rx[u] = io_ld4(xb + (unsigned)((k0 + (e / F4R)) * p.P + p0 + (e % F4R) * 4));
             }
             // W chunk as ONE 16-byte load per thread along whichever index is contiguous in memory (4 dword loads
             // per thread made W the most numerous vector-memory instruction of the tile; the address unit was the
@@ -110,7 +113,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
                 const int ci = k0 + e / PT, pp = p0 + e % PT;
-                r[u] = (ci < p.Ci && pp < p.P) ? xb[(size_t)ci * p.P + pp] : 0.f;
+                r[u] = (ci < p.Ci && pp < p.P) ? io_widen(xb[(size_t)ci * p.P + pp]) : 0.f;
             }
         }
 #pragma unroll
@@ -194,16 +197,16 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     *reinterpret_cast<float4*>(sO + (r16 & 7) * OS + 16 * mt + 4 * kk) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
             }
             __syncthreads();
-            f4u old[4], pre[DG ? 4 : 1];
-            float* dst[4];
+            float4 old[4], pre[DG ? 4 : 1];
+            T* dst[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
                 const size_t off = ((size_t)b * p.Co + o) * p.P + p0 + c4;
-                dst[it] = p.y + off;
-                if (p.accumulate) old[it] = *reinterpret_cast<const f4u*>(dst[it]);
-                else old[it].v[0] = old[it].v[1] = old[it].v[2] = old[it].v[3] = 0.f;
-                if constexpr (DG) pre[it] = *reinterpret_cast<const f4u*>(p.dgelu_of + off);
+                dst[it] = yall + off;
+                if (p.accumulate) old[it] = io_ld4(dst[it]);
+                else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (DG) pre[it] = io_ld4(dall + off);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -211,13 +214,17 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
                 const float bv = __shfl(bias_l, 8 * h + row);
                 float r4[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
-                f4u w4;
+                const float o4[4] = {old[it].x, old[it].y, old[it].z, old[it].w};
+                float w4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if constexpr (DG) r4[i] *= cm_dgelu(pre[it].v[i]);
-                    w4.v[i] = old[it].v[i] + r4[i];
+                    if constexpr (DG) {
+                        const float pr4[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
+                        r4[i] *= cm_dgelu(pr4[i]);
+                    }
+                    w4[i] = o4[i] + r4[i];
                 }
-                *reinterpret_cast<f4u*>(dst[it]) = w4;
+                io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
             }
             __syncthreads();
         }
@@ -226,24 +233,26 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     const int o = o0 + 16 * wave + r16;
     if (MODE == 2 || o < p.Co) {
         const float bv = p.bias ? p.bias[o] : 0.f;
-        float* yrow = p.y + ((size_t)b * p.Co + o) * p.P;
+        T* yrow = yall + ((size_t)b * p.Co + o) * p.P;
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk;
-            const float* drow = DG ? p.dgelu_of + ((size_t)b * p.Co + o) * p.P : nullptr;
+            const T* drow = DG ? dall + ((size_t)b * p.Co + o) * p.P : nullptr;
             if (MODE == 2 || px + 3 < p.P) {
-                f4u w4, pre;
-                if (p.accumulate) w4 = *reinterpret_cast<const f4u*>(yrow + px);
-                else w4.v[0] = w4.v[1] = w4.v[2] = w4.v[3] = 0.f;
-                if constexpr (DG) pre = *reinterpret_cast<const f4u*>(drow + px);
+                float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), pre = o4;
+                if (p.accumulate) o4 = io_ld4(yrow + px);
+                if constexpr (DG) pre = io_ld4(drow + px);
+                float w4[4] = {o4.x, o4.y, o4.z, o4.w};
+                const float pr4[4] = {pre.x, pre.y, pre.z, pre.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w4.v[r] += (acc[mt][r] + bv) * (DG ? cm_dgelu(pre.v[r]) : 1.f);
-                *reinterpret_cast<f4u*>(yrow + px) = w4;
+                for (int r = 0; r < 4; ++r) w4[r] += (acc[mt][r] + bv) * (DG ? cm_dgelu(pr4[r]) : 1.f);
+                io_store4(yrow + px, w4[0], w4[1], w4[2], w4[3]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (px + r < p.P)
-                        yrow[px + r] = (p.accumulate ? yrow[px + r] : 0.f) + (acc[mt][r] + bv) * (DG ? cm_dgelu(drow[px + r]) : 1.f);
+                        io_store1(yrow + px + r, (p.accumulate ? io_widen(yrow[px + r]) : 0.f) +
+                                                     (acc[mt][r] + bv) * (DG ? cm_dgelu(io_widen(drow[px + r])) : 1.f));
             }
         }
     }
@@ -257,7 +266,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 // stores) - the address unit (TA) was the busiest block of the CU at 63 %.
 // TINY: rows shorter than 4 pixels (scalar guarded path) - a kernel of its own so that its register needs do not set
 // the occupancy of the real one.  Also measured and dropped: two chunks in flight per workgroup (same time).
-template <int PT, bool TINY, bool ACT = false, bool DG = false>
+template <int PT, bool TINY, bool ACT = false, bool DG = false, bool BF = false>
 __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(ChannelMixParams p) {
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * (PT + 16)];
     __shared__ float sW[2][CM_KC * CM_WS];
@@ -268,10 +277,10 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
     if (tile >= p.ntile) return;
     const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
     if constexpr (TINY) {
-        channel_mix_tile<0, PT, ACT, DG>(p, sX, sW, p0, o0, b);
+        channel_mix_tile<0, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
     } else {
-        if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT, ACT, DG>(p, sX, sW, p0, o0, b);
-        else channel_mix_tile<1, PT, ACT, DG>(p, sX, sW, p0, o0, b);
+        if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
+        else channel_mix_tile<1, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
     }
 }
 
@@ -281,7 +290,9 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
 // pixel tiles only; the last (partial) pixel tile of a row runs the guarded 64-channel path twice.
 constexpr int CMW_WS = 128 + 16;
 
+template <bool BF>
 __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixParams p) {
+    using T = typename IoElem<BF>::type;
     constexpr int PT = CM_PT, XS = PT + 16, NM = PT / 16;
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * XS];
     __shared__ __attribute__((aligned(16))) float sW[2][CM_KC * CMW_WS];
@@ -290,14 +301,14 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = blockIdx.y;
     if (p0 + PT > p.P || (p.Ci & (CM_KC - 1)) != 0) {
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(&sW[0][0]);
-        channel_mix_tile<1, PT>(p, sX, sWn, p0, o0, b);
+        channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0, b);
         __syncthreads();
-        channel_mix_tile<1, PT>(p, sX, sWn, p0, o0 + 64, b);
+        channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0 + 64, b);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* xb = p.x + (size_t)b * p.Ci * p.P;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P;
     const bool tr = p.w_so == 1 && p.w_si != 1;
 
     float4 rx[2], rw[2];
@@ -305,8 +316,7 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
-            const f4u v = *reinterpret_cast<const f4u*>(xb + (unsigned)((k0 + (e >> 5)) * p.P + p0 + (e & 31) * 4));
-            rx[u] = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            rx[u] = io_ld4(xb + (unsigned)((k0 + (e >> 5)) * p.P + p0 + (e & 31) * 4));
             const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + 64 * u + (tid & 15) * 4)
                                      : (unsigned)((o0 + 64 * u + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
             const f4u wv = *reinterpret_cast<const f4u*>(p.w + woff);
@@ -370,32 +380,29 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
                         make_float4(acc[g][mt][0], acc[g][mt][1], acc[g][mt][2], acc[g][mt][3]);
             }
             __syncthreads();
-            f4u old[4];
-            float* dst[4];
+            float4 old[4];
+            T* dst[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = ob + 8 * h + 2 * it + (lane >> 5);
-                dst[it] = p.y + ((size_t)b * p.Co + o) * p.P + p0 + c4;
-                if (p.accumulate) old[it] = *reinterpret_cast<const f4u*>(dst[it]);
-                else old[it].v[0] = old[it].v[1] = old[it].v[2] = old[it].v[3] = 0.f;
+                dst[it] = reinterpret_cast<T*>(p.y) + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                if (p.accumulate) old[it] = io_ld4(dst[it]);
+                else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = 2 * it + (lane >> 5);
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
                 const float bv = __shfl(bias_l, 8 * h + row);
-                f4u w4;
-                w4.v[0] = old[it].v[0] + (v.x + bv); w4.v[1] = old[it].v[1] + (v.y + bv);
-                w4.v[2] = old[it].v[2] + (v.z + bv); w4.v[3] = old[it].v[3] + (v.w + bv);
-                *reinterpret_cast<f4u*>(dst[it]) = w4;
+                io_store4(dst[it], old[it].x + (v.x + bv), old[it].y + (v.y + bv), old[it].z + (v.z + bv), old[it].w + (v.w + bv));
             }
             __syncthreads();
         }
     }
 }
 
-int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, int act_in, const float* dgelu_of, hipStream_t s) {
+int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
+                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s) {
     ChannelMixParams p;
     p.accumulate = accumulate ? 1 : 0;
     p.dgelu_of = dgelu_of;
@@ -414,17 +421,19 @@ int launch_channel_mix(const float* x, const float* w, const float* bias, float*
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     {
         ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
-                       4.0 * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + (dgelu_of ? Co : 0)) + 4.0 * Ci * Co, s);
-        if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + (dgelu_of ? Co : 0)) + 4.0 * Ci * Co, s);
+        if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
-#define UNO_CM_LAUNCH(T) \
+#define UNO_CM_LAUNCH(T, BF) \
             do { \
-                if (act_in) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, true, false>), grid, dim3(256), 0, s, p); \
-                else if (dgelu_of) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, true>), grid, dim3(256), 0, s, p); \
-                else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, false>), grid, dim3(256), 0, s, p); \
+                if (act_in) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, true, false, BF>), grid, dim3(256), 0, s, p); \
+                else if (dgelu_of) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, true, BF>), grid, dim3(256), 0, s, p); \
+                else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, false, BF>), grid, dim3(256), 0, s, p); \
             } while (0)
-            if (P >= 4) UNO_CM_LAUNCH(false); else UNO_CM_LAUNCH(true);
+            if (bf16) { if (P >= 4) UNO_CM_LAUNCH(false, true); else UNO_CM_LAUNCH(true, true); }
+            else { if (P >= 4) UNO_CM_LAUNCH(false, false); else UNO_CM_LAUNCH(true, false); }
 #undef UNO_CM_LAUNCH
         }
     }
@@ -439,15 +448,17 @@ constexpr int CW_PK = 32;           // pixels per staged chunk
 constexpr int CW_S = CW_PK + 2;     // LDS row stride: 2 r16 + kk hits 32 distinct banks per half-wave
 
 struct ChannelWgradParams {
-    const float* gy;        // (B, Co, P)
-    const float* x;         // (B, Ci, P)
+    const void* gy;         // (B, Co, P) f32 | bf16
+    const void* x;          // (B, Ci, P) f32 | bf16
     float* part;            // (nsplit, Co, Ci + 1) partial sums; column Ci holds the bias gradient
     int B, Ci, Co, P, nsplit;
     int act_x;              // scalar kernel: x := gelu(x)
     long long span;         // pixels per split (informational)
 };
 
+template <bool BF>
 __global__ __launch_bounds__(256) void channel_wgrad_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    using T = typename IoElem<BF>::type;
     __shared__ float sG[2][CW_T * CW_S];
     __shared__ float sXc[2][CW_T * CW_S];
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
@@ -461,14 +472,14 @@ __global__ __launch_bounds__(256) void channel_wgrad_kernel(ChannelWgradParams p
     float rg[8], rxv[8];
     auto load_chunk = [&](int idx) {
         const int b = idx / npc, pp0 = (idx - b * npc) * CW_PK;
-        const float* gb = p.gy + (size_t)b * p.Co * p.P;
-        const float* xb = p.x + (size_t)b * p.Ci * p.P;
+        const T* gb = reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P;
+        const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
             const int row = e >> 5, px = pp0 + (e & 31);
-            rg[u] = (px < p.P && o0 + row < p.Co) ? gb[(size_t)(o0 + row) * p.P + px] : 0.f;
-            rxv[u] = (px < p.P && i0 + row < p.Ci) ? xb[(size_t)(i0 + row) * p.P + px] : 0.f;
+            rg[u] = (px < p.P && o0 + row < p.Co) ? io_widen(gb[(size_t)(o0 + row) * p.P + px]) : 0.f;
+            rxv[u] = (px < p.P && i0 + row < p.Ci) ? io_widen(xb[(size_t)(i0 + row) * p.P + px]) : 0.f;
             if (p.act_x) rxv[u] = cm_gelu(rxv[u]);
         }
     };
@@ -530,8 +541,10 @@ constexpr int CWV_PK = 64;
 constexpr int CWV_S = CWV_PK + 4;       // 272-byte rows: 16-byte aligned for ds_write_b128; fragment reads hit banks 4 r16 + kk,
                                         // distinct over all 64 lanes (gfx950 LDS: 64 banks; a stride of 66 cost one conflict cycle per read)
 
-template <bool ACTX>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
+template <bool ACTX, bool BF>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
 __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    using T = typename IoElem<BF>::type;
+    constexpr int ES = BF ? 2 : 4;          // bytes per element
     __shared__ __attribute__((aligned(16))) float sG[CW_T * CWV_S];
     __shared__ __attribute__((aligned(16))) float sXc[CW_T * CWV_S];
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
@@ -560,17 +573,25 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_chunk = [&](int idx) {
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK;
-        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gy + (size_t)b * p.Co * p.P), 0, p.Co * p.P * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.Ci * p.P), 0, p.Ci * p.P * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P), 0, p.Ci * p.P * ES, 0x00020000);
         const int px = pp + c4, pc = min(px, p.P - 4);
         sh_cur = px - pc;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
-            const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 4, 0, 0);
-            const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(i0 + row, p.Ci - 1) * p.P + pc) * 4, 0, 0);
-            rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
-            rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
+            if constexpr (BF) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 tg = __builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 2, 0, 0);
+                const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(i0 + row, p.Ci - 1) * p.P + pc) * 2, 0, 0);
+                rg[u] = make_float4(__uint_as_float(tg.x << 16), __uint_as_float(tg.x & 0xffff0000u), __uint_as_float(tg.y << 16), __uint_as_float(tg.y & 0xffff0000u));
+                rxv[u] = make_float4(__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u), __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u));
+            } else {
+                const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 4, 0, 0);
+                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(i0 + row, p.Ci - 1) * p.P + pc) * 4, 0, 0);
+                rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
+                rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
+            }
         }
     };
     auto shifted = [&](const float4& v, bool valid) {
@@ -689,8 +710,8 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
     return (long long)nsplit * Co * (long long)(Ci + 1);
 }
 
-int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
-                         int act_x, hipStream_t s) {
+int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
+                         int act_x, int bf16, hipStream_t s) {
     if ((long long)(Ci > Co ? Ci : Co) * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
         set_error("channel_wgrad: tensor too large (channels * pixels must stay below 2^29)");
         return -2;
@@ -702,13 +723,19 @@ int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, 
     p.span = (long long)cps * pk;
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
     {
-        ProfScope prof(pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel", 4.0 * B * (double)P * (Ci + Co), s);
-        if (pk == CWV_PK && act_x)
-            hipLaunchKernelGGL(channel_wgrad_vec_kernel<true>, dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
-        else if (pk == CWV_PK)
-            hipLaunchKernelGGL(channel_wgrad_vec_kernel<false>, dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
-        else
-            hipLaunchKernelGGL(channel_wgrad_kernel, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
+        ProfScope prof(pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
+        const dim3 gv(8 * tiles * ((p.nsplit + 7) / 8));
+        if (pk == CWV_PK && act_x) {
+            if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, true>), gv, dim3(256), 0, s, p, npc, cps);
+            else hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false>), gv, dim3(256), 0, s, p, npc, cps);
+        } else if (pk == CWV_PK) {
+            if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<false, true>), gv, dim3(256), 0, s, p, npc, cps);
+            else hipLaunchKernelGGL((channel_wgrad_vec_kernel<false, false>), gv, dim3(256), 0, s, p, npc, cps);
+        } else if (bf16) {
+            hipLaunchKernelGGL(channel_wgrad_kernel<true>, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
+        } else {
+            hipLaunchKernelGGL(channel_wgrad_kernel<false>, dim3(tiles, p.nsplit), dim3(256), 0, s, p, npc, cps);
+        }
     }
     const int n = Co * (Ci + 1);
     hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit);

@@ -39,20 +39,25 @@ __device__ __forceinline__ float in_block_sum(float s, float* red) {
 // Visit the row(s) in 16-byte pieces (rows are only 4-byte aligned): f(k, v0[4], v1[4], n_valid).  Pieces are taken in
 // groups of 4 per thread with the NEXT group's loads issued before the current group is consumed; left to the compiler's
 // unrolling every group was drained (s_waitcnt vmcnt(0)) before the next was issued - one memory latency per group.
-template <bool TWO, class F>
-__device__ __forceinline__ void in_sweep(const float* row0, const float* row1, int N, F f) {
+// T = float | unsigned short (bfloat16 bits: widened on load; statistics and arithmetic stay f32)
+struct in_f4 { float v[4]; };
+template <typename T>
+__device__ __forceinline__ in_f4 in_ld4(const T* p) { const float4 t = io_ld4(p); return in_f4{{t.x, t.y, t.z, t.w}}; }
+
+template <bool TWO, typename T, class F>
+__device__ __forceinline__ void in_sweep(const T* row0, const T* row1, int N, F f) {
     const int nq = N >> 2;
     if (nq > 0) {
-        f4u a0[4], a1[4], b0[4], b1[4];
-        auto load = [&](int k, f4u* d0, f4u* d1) {
+        in_f4 a0[4], a1[4], b0[4], b1[4];
+        auto load = [&](int k, in_f4* d0, in_f4* d1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int q = min((int)threadIdx.x + (k + i) * IN_T, nq - 1);       // clamped: pieces past the end are not consumed
-                d0[i] = *reinterpret_cast<const f4u*>(row0 + 4 * q);
-                if (TWO) d1[i] = *reinterpret_cast<const f4u*>(row1 + 4 * q);
+                d0[i] = in_ld4(row0 + 4 * q);
+                if (TWO) d1[i] = in_ld4(row1 + 4 * q);
             }
         };
-        auto use = [&](int k, const f4u* d0, const f4u* d1) {
+        auto use = [&](int k, const in_f4* d0, const in_f4* d1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int q = threadIdx.x + (k + i) * IN_T;
@@ -73,19 +78,19 @@ __device__ __forceinline__ void in_sweep(const float* row0, const float* row1, i
     const int tail = N & 3;
     if (tail && threadIdx.x == 0) {
         float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < tail; ++i) { v0[i] = row0[4 * nq + i]; if (TWO) v1[i] = row1[4 * nq + i]; }
+        for (int i = 0; i < tail; ++i) { v0[i] = io_widen(row0[4 * nq + i]); if (TWO) v1[i] = io_widen(row1[4 * nq + i]); }
         f(4 * nq, v0, v1, tail);
     }
 }
 
-template <bool GELU>
-__global__ __launch_bounds__(IN_T) void instnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y,
+template <bool GELU, typename T>
+__global__ __launch_bounds__(IN_T) void instnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps) {
     __shared__ float red[IN_T / 64];
     const int r = blockIdx.x, c = r % C;
-    const float* row = x + (size_t)r * N;
-    float* dst = y + (size_t)r * N;
+    const T* row = x + (size_t)r * N;
+    T* dst = y + (size_t)r * N;
     float s = 0.f;
     in_sweep<false>(row, row, N, [&](int, const float* v, const float*, int n) { for (int i = 0; i < n; ++i) s += v[i]; });
     const float mean = in_block_sum(s, red) / (float)N;
@@ -101,26 +106,23 @@ __global__ __launch_bounds__(IN_T) void instnorm_fwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float z = fmaf(a, v[i], sh); o[i] = GELU ? in_gelu(z) : z; }
         if (n == 4) {
-            f4u t;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t.v[i] = o[i];
-            *reinterpret_cast<f4u*>(dst + k) = t;
+            io_store4(dst + k, o[0], o[1], o[2], o[3]);
         } else {
-            for (int i = 0; i < n; ++i) dst[k + i] = o[i];
+            for (int i = 0; i < n; ++i) io_store1(dst + k + i, o[i]);
         }
     });
 }
 
-template <bool GELU>
-__global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+template <bool GELU, typename T>
+__global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                            float* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N) {
+                                                            T* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N) {
     __shared__ float red[IN_T / 64];
     const int r = blockIdx.x, c = r % C;
-    const float* row = x + (size_t)r * N;
-    const float* grow = gy + (size_t)r * N;
-    float* dst = gx + (size_t)r * N;
+    const T* row = x + (size_t)r * N;
+    const T* grow = gy + (size_t)r * N;
+    T* dst = gx + (size_t)r * N;
     const float mean = mean_in[r], rstd = rstd_in[r];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
@@ -139,36 +141,47 @@ __global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) { float xh; const float gz = gz_of(xv[i], gv[i], xh); o[i] = gr * (gz - m1 - xh * m2); }
         if (n == 4) {
-            f4u t;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t.v[i] = o[i];
-            *reinterpret_cast<f4u*>(dst + k) = t;
+            io_store4(dst + k, o[0], o[1], o[2], o[3]);
         } else {
-            for (int i = 0; i < n; ++i) dst[k + i] = o[i];
+            for (int i = 0; i < n; ++i) io_store1(dst + k + i, o[i]);
         }
     });
 }
 
-int launch_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
-                        long long N, float eps, int gelu, hipStream_t s) {
+int launch_instnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
+                        long long N, float eps, int gelu, int bf16, hipStream_t s) {
+    typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
     {
-        ProfScope prof("uno::instnorm_fwd_kernel", 8.0 * rows * (double)N, s);
-        if (gelu) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gamma, beta, y, mean, rstd, C, (int)N, eps);
-        else hipLaunchKernelGGL(instnorm_fwd_kernel<false>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gamma, beta, y, mean, rstd, C, (int)N, eps);
+        ProfScope prof("uno::instnorm_fwd_kernel", (bf16 ? 4.0 : 8.0) * rows * (double)N, s);
+        const dim3 grid((unsigned)rows);
+        if (bf16) {
+            if (gelu) hipLaunchKernelGGL((instnorm_fwd_kernel<true, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, gamma, beta, (bf_t*)y, mean, rstd, C, (int)N, eps);
+            else hipLaunchKernelGGL((instnorm_fwd_kernel<false, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, gamma, beta, (bf_t*)y, mean, rstd, C, (int)N, eps);
+        } else {
+            if (gelu) hipLaunchKernelGGL((instnorm_fwd_kernel<true, float>), grid, dim3(IN_T), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, C, (int)N, eps);
+            else hipLaunchKernelGGL((instnorm_fwd_kernel<false, float>), grid, dim3(IN_T), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, C, (int)N, eps);
+        }
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("instnorm launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
 }
 
-int launch_instnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                        float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, hipStream_t s) {
+int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, int bf16, hipStream_t s) {
+    typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
     {
-        ProfScope prof("uno::instnorm_bwd_kernel", 12.0 * rows * (double)N, s);
-        if (gelu) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gy, gamma, beta, mean, rstd, gx, s1, s2, C, (int)N);
-        else hipLaunchKernelGGL(instnorm_bwd_kernel<false>, dim3((unsigned)rows), dim3(IN_T), 0, s, x, gy, gamma, beta, mean, rstd, gx, s1, s2, C, (int)N);
+        ProfScope prof("uno::instnorm_bwd_kernel", (bf16 ? 6.0 : 12.0) * rows * (double)N, s);
+        const dim3 grid((unsigned)rows);
+        if (bf16) {
+            if (gelu) hipLaunchKernelGGL((instnorm_bwd_kernel<true, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, (const bf_t*)gy, gamma, beta, mean, rstd, (bf_t*)gx, s1, s2, C, (int)N);
+            else hipLaunchKernelGGL((instnorm_bwd_kernel<false, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, (const bf_t*)gy, gamma, beta, mean, rstd, (bf_t*)gx, s1, s2, C, (int)N);
+        } else {
+            if (gelu) hipLaunchKernelGGL((instnorm_bwd_kernel<true, float>), grid, dim3(IN_T), 0, s, (const float*)x, (const float*)gy, gamma, beta, mean, rstd, (float*)gx, s1, s2, C, (int)N);
+            else hipLaunchKernelGGL((instnorm_bwd_kernel<false, float>), grid, dim3(IN_T), 0, s, (const float*)x, (const float*)gy, gamma, beta, mean, rstd, (float*)gx, s1, s2, C, (int)N);
+        }
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("instnorm backward launch: %s", hipGetErrorString(e)); return -5; }

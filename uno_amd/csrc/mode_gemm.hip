@@ -28,7 +28,9 @@ constexpr int KC = 8;           // reduction chunk staged in LDS
 // modes and many channels - 2 x 64 modes x 256 x 256 channels - give only 128 workgroups of 16 modes, and a workgroup's phases
 // (stage to LDS, issue loads, multiply) do not overlap with one wave per SIMD: the time was the sum of the three)
 // PIPE: software-pipelined K loop over two LDS buffers (8-mode variant on layers with few mode chunks, see the launcher)
-template <int QC, bool PIPE>
+// BH: operand B (the weights of ops 0 / 1) is stored as half-precision (re, im) pairs - config C5's weight storage - and widened
+// as it is loaded; everything after the load is the complex64 kernel.
+template <int QC, bool PIPE, bool BH>
 __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     constexpr int TILE_ELEMS = 16 * KC * QC;        // complex elements of one operand chunk
     constexpr int EPT = TILE_ELEMS / 256;           // elements per thread per operand: 8 / 4
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     const int nmodes = min(QC, p.Mc - q0);
 
     const float2* Ab = p.A.base[corner] + q0;
-    const float2* Bb = p.B.base[corner] + q0;
+    constexpr int ESB = BH ? 4 : 8;         // bytes per complex element of operand B
+    const char* Bb = reinterpret_cast<const char*>(p.B.base[corner]) + (size_t)q0 * ESB;
     const float sgnA = p.A.conj ? -1.f : 1.f;
     const float sgnB = p.B.conj ? -1.f : 1.f;
 
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, -1, 0x00020000);
     const unsigned voA = okA ? (unsigned)(((long long)(m0 + x_t) * p.A.s0 + q_t + (long long)kb_t * p.A.s1) * 8) : 0u;
-    const unsigned voB = okB ? (unsigned)(((long long)(n0 + x_t) * p.B.s1 + q_t + (long long)kb_t * p.B.s0) * 8) : 0u;
-    const unsigned strideA = (unsigned)(p.A.s1 * 8), strideB = (unsigned)(p.B.s0 * 8);
+    const unsigned voB = okB ? (unsigned)(((long long)(n0 + x_t) * p.B.s1 + q_t + (long long)kb_t * p.B.s0) * ESB) : 0u;
+    const unsigned strideA = (unsigned)(p.A.s1 * 8), strideB = (unsigned)(p.B.s0 * ESB);
     auto load_chunk = [&](float2* da, float2* db, int k0) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
@@ -77,9 +80,16 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
             // after the MFMA block (masking here would consume the registers at once)
             const unsigned kb = (unsigned)max(min(k0 + KSTEP * u, p.K - KSTEP), 0);
             const u32x2 ta = __builtin_amdgcn_raw_buffer_load_b64(rA, voA, kb * strideA, 0);
-            const u32x2 tb = __builtin_amdgcn_raw_buffer_load_b64(rB, voB, kb * strideB, 0);
             da[u] = make_float2(__uint_as_float(ta[0]), __uint_as_float(ta[1]));
-            db[u] = make_float2(__uint_as_float(tb[0]), __uint_as_float(tb[1]));
+            if constexpr (BH) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                const unsigned tb = __builtin_amdgcn_raw_buffer_load_b32(rB, voB, kb * strideB, 0);
+                const h2_t hv = __builtin_bit_cast(h2_t, tb);
+                db[u] = make_float2((float)hv[0], (float)hv[1]);
+            } else {
+                const u32x2 tb = __builtin_amdgcn_raw_buffer_load_b64(rB, voB, kb * strideB, 0);
+                db[u] = make_float2(__uint_as_float(tb[0]), __uint_as_float(tb[1]));
+            }
         }
     };
     auto store_chunk = [&](float* buf, const float2* sa, const float2* sb, int k0) {
@@ -202,14 +212,20 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
     dim3 grid(p.ncorner * nq, (p.N + 15) / 16, (p.M + 15) / 16);
     {
         // each operand counted once: A (M x K), B (K x N), out (M x N) complex64 per mode
-        const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
+        const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.M * p.N) + (p.B.half ? 4.0 : 8.0) * (double)p.K * p.N;
         ProfScope prof("uno::mode_gemm_kernel", per_mode * p.ncorner * p.Mc, s);
         // pipelined K loop: measured better with few mode chunks per layer (2 x 36 / 2 x 64 modes: 26 -> 22, 34 -> 29 us) and
         // worse with many (2 x 196 / 2 x 324 modes: 41 -> 50, 58 -> 67 us)
         const bool pipe = narrow && p.ncorner * nq <= 32;
-        if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
-        else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
-        else hipLaunchKernelGGL((mode_gemm_kernel<16, false>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
+        if (p.B.half) {
+            if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, true>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
+            else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false, true>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
+            else hipLaunchKernelGGL((mode_gemm_kernel<16, false, true>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
+        } else {
+            if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, false>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
+            else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false, false>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
+            else hipLaunchKernelGGL((mode_gemm_kernel<16, false, false>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
+        }
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }

@@ -22,26 +22,26 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 
 // up to four consecutive floats row[px .. px+3] with zeros from `n` on (n = valid floats in the row, n >= 4)
-__device__ __forceinline__ void load4_guard(const float* row, int px, int n, float v[4]) {
+// T = float, or unsigned short = bfloat16 bits (config C5: activations bf16, weights and every accumulation f32; widened on
+// load, rounded to nearest even on store)
+template <typename T>
+__device__ __forceinline__ void load4_guard(const T* row, int px, int n, float v[4]) {
     if (px + 3 < n) {
-        const f4u t = *reinterpret_cast<const f4u*>(row + px);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = t.v[i];
+        const float4 t = io_ld4(row + px);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = px + i < n ? row[px + i] : 0.f;
+        for (int i = 0; i < 4; ++i) v[i] = px + i < n ? io_widen(row[px + i]) : 0.f;
     }
 }
-__device__ __forceinline__ void store4_guard(float* row, int px, int n, const float v[4]) {
+template <typename T>
+__device__ __forceinline__ void store4_guard(T* row, int px, int n, const float v[4]) {
     if (px + 3 < n) {
-        f4u t;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t.v[i] = v[i];
-        *reinterpret_cast<f4u*>(row + px) = t;
+        io_store4(row + px, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (px + i < n) row[px + i] = v[i];
+            if (px + i < n) io_store1(row + px + i, v[i]);
     }
 }
 
@@ -51,9 +51,9 @@ constexpr int GP_MAXC = 1024;
 // SPLIT: small tensors (a 64 x 64 grid at batch 32 gives 512 one-wave pixel tiles for 256 CUs, each walking all C channels): the
 // four waves of a workgroup share ONE 256-pixel tile and take a quarter of the channels each; partial sums meet in LDS and are
 // added in wave order (fixed -> bit-reproducible).
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
-                                                               const float* __restrict__ bias, float* __restrict__ out, int C, int P) {
+template <bool SPLIT, typename T>
+__global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const T* __restrict__ pre, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, T* __restrict__ out, int C, int P) {
     __shared__ float sw[GP_MAXC];
     __shared__ float sred[SPLIT ? 4 * 64 * 4 : 1];
     for (int c = threadIdx.x; c < C; c += blockDim.x) sw[c] = w[c];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __re
     if (!SPLIT && !live) return;
     const int Cs = SPLIT ? (C + 3) / 4 : C;
     const int c_lo = SPLIT ? min(wave * Cs, C) : 0, c_hi = SPLIT ? min(c_lo + Cs, C) : C;
-    const float* src = pre + (size_t)b * C * P;
+    const T* src = pre + (size_t)b * C * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // channels in groups of 4, the next group's loads issued before the current one is consumed (-11 % against the
     // compiler's own unrolling, which drains each group of loads before issuing the next; the same change made the
@@ -114,8 +114,9 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const float* __re
 // batch 32 gave 128 workgroups of 256 threads for 256 CUs); partial weight / bias gradients per workgroup: part[blk][C + 1].
 // Per channel every wave reduces its 256 pixels by butterfly and parks the sum in LDS; one barrier at the end, then the
 // four wave sums are added in wave order (fixed order -> bit-reproducible).
-__global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ w,
-                                                               const float* __restrict__ gout, float* __restrict__ gpre,
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restrict__ pre, const float* __restrict__ w,
+                                                               const T* __restrict__ gout, T* __restrict__ gpre,
                                                                float* __restrict__ part, int C, int P, int Cs) {
     // blockIdx.z = channel split: channels [z Cs, min(C, (z + 1) Cs)); small tensors (one-wave workgroups) are split over
     // channels as well, so that the chip sees 4x the waves (a 64 x 64 grid at batch 32 gave 512 waves walking 128 channels each)
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const float* __re
     const bool live = px < P;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) load4_guard(gout + (size_t)b * P, px, P, g);
-    const float* src = pre + (size_t)b * C * P;
-    float* dst = gpre + (size_t)b * C * P;
+    const T* src = pre + (size_t)b * C * P;
+    T* dst = gpre + (size_t)b * C * P;
     float* mine = swave + wave * (C + 1);
     auto wave_sum = [&](float s, int slot) {
 #pragma unroll
@@ -190,15 +191,21 @@ __global__ __launch_bounds__(256) void gelu_project_reduce_kernel(const float* _
 // 256-thread workgroups unless that leaves the GPU under-filled (< 4 workgroups per CU)
 static int gelu_project_threads(int B, long long P) { return (long long)B * ((P + 1023) / 1024) >= 1024 ? 256 : 64; }
 
-int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s) {
+int launch_gelu_project_fwd(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, hipStream_t s) {
+    typedef unsigned short bf_t;
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
     const int threads = gelu_project_threads(B, P);
     const bool split = threads == 64 && C >= 16;
     const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     {
-        ProfScope prof("uno::gelu_project_fwd_kernel", 4.0 * B * (double)P * (C + 1), s);
-        if (split) hipLaunchKernelGGL(gelu_project_fwd_kernel<true>, dim3(nb, B), dim3(256), 0, s, pre, w, bias, out, C, (int)P);
-        else hipLaunchKernelGGL(gelu_project_fwd_kernel<false>, dim3(nb, B), dim3(threads), 0, s, pre, w, bias, out, C, (int)P);
+        ProfScope prof("uno::gelu_project_fwd_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (C + 1), s);
+        if (bf16) {
+            if (split) hipLaunchKernelGGL((gelu_project_fwd_kernel<true, bf_t>), dim3(nb, B), dim3(256), 0, s, (const bf_t*)pre, w, bias, (bf_t*)out, C, (int)P);
+            else hipLaunchKernelGGL((gelu_project_fwd_kernel<false, bf_t>), dim3(nb, B), dim3(threads), 0, s, (const bf_t*)pre, w, bias, (bf_t*)out, C, (int)P);
+        } else {
+            if (split) hipLaunchKernelGGL((gelu_project_fwd_kernel<true, float>), dim3(nb, B), dim3(256), 0, s, (const float*)pre, w, bias, (float*)out, C, (int)P);
+            else hipLaunchKernelGGL((gelu_project_fwd_kernel<false, float>), dim3(nb, B), dim3(threads), 0, s, (const float*)pre, w, bias, (float*)out, C, (int)P);
+        }
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gelu_project launch: %s", hipGetErrorString(e)); return -5; }
@@ -213,15 +220,18 @@ long long gelu_project_ws_floats(int B, int C, long long P) {
     return (long long)gelu_project_splits(B, C, P) * B * ((P + 4 * t - 1) / (4 * t)) * (C + 1);
 }
 
-int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
-                            int C, long long P, hipStream_t s) {
+int launch_gelu_project_bwd(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, float* ws, int B,
+                            int C, long long P, int bf16, hipStream_t s) {
+    typedef unsigned short bf_t;
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
     const int threads = gelu_project_threads(B, P);
     const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     const int nsplit = gelu_project_splits(B, C, P), Cs = (C + nsplit - 1) / nsplit;
     {
-        ProfScope prof("uno::gelu_project_bwd_kernel", 4.0 * B * (double)P * (2 * C + 1), s);
-        hipLaunchKernelGGL(gelu_project_bwd_kernel, dim3(nb, B, nsplit), dim3(threads), (threads / 64) * (C + 1) * sizeof(float), s, pre, w, gout, gpre, ws, C, (int)P, Cs);
+        ProfScope prof("uno::gelu_project_bwd_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (2 * C + 1), s);
+        const size_t lds = (threads / 64) * (C + 1) * sizeof(float);
+        if (bf16) hipLaunchKernelGGL(gelu_project_bwd_kernel<bf_t>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const bf_t*)pre, w, (const bf_t*)gout, (bf_t*)gpre, ws, C, (int)P, Cs);
+        else hipLaunchKernelGGL(gelu_project_bwd_kernel<float>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const float*)pre, w, (const float*)gout, (float*)gpre, ws, C, (int)P, Cs);
     }
     hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B), Cs);
     const hipError_t e = hipGetLastError();
@@ -231,7 +241,8 @@ int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout,
 
 // ------------------------------------------------------------------------------------------------ K12
 // thread = 4 consecutive columns of one row; rows are flattened so that short rows do not leave lanes idle
-__global__ __launch_bounds__(256) void gelu_pad_fwd_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_pad_fwd_kernel(const T* __restrict__ s, T* __restrict__ out, int H, int W, int Hp, int Wp) {
     const int n = blockIdx.y;
     const int nq = (Wp + 3) >> 2;
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -247,7 +258,8 @@ __global__ __launch_bounds__(256) void gelu_pad_fwd_kernel(const float* __restri
     store4_guard(out + ((size_t)n * Hp + h) * Wp, w0, Wp, v);
 }
 
-__global__ __launch_bounds__(256) void gelu_pad_bwd_kernel(const float* __restrict__ s, const float* __restrict__ gy, float* __restrict__ gs,
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_pad_bwd_kernel(const T* __restrict__ s, const T* __restrict__ gy, T* __restrict__ gs,
                                                            int H, int W, int Hp, int Wp) {
     const int n = blockIdx.y;
     const int nq = (W + 3) >> 2;
@@ -263,16 +275,22 @@ __global__ __launch_bounds__(256) void gelu_pad_bwd_kernel(const float* __restri
     store4_guard(gs + ((size_t)n * H + h) * W, w0, W, o);
 }
 
-int launch_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, hipStream_t st) {
+int launch_gelu_pad(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward, int bf16, hipStream_t st) {
+    typedef unsigned short bf_t;
+    const double es = bf16 ? 2.0 : 4.0;
     if (n_img > 65535 || (long long)Hp * ((Wp + 3) / 4) > 0x7fffffffLL) { set_error("gelu_pad: at most 65535 images"); return -2; }
     if (!backward) {
-        ProfScope prof("uno::gelu_pad_fwd_kernel", 4.0 * n_img * ((double)H * W + (double)Hp * Wp), st);
+        ProfScope prof("uno::gelu_pad_fwd_kernel", es * n_img * ((double)H * W + (double)Hp * Wp), st);
         const long long quads = (long long)Hp * ((Wp + 3) / 4);
-        hipLaunchKernelGGL(gelu_pad_fwd_kernel, dim3((unsigned)((quads + 255) / 256), n_img), dim3(256), 0, st, s, out, H, W, Hp, Wp);
+        const dim3 grid((unsigned)((quads + 255) / 256), n_img);
+        if (bf16) hipLaunchKernelGGL(gelu_pad_fwd_kernel<bf_t>, grid, dim3(256), 0, st, (const bf_t*)s, (bf_t*)out, H, W, Hp, Wp);
+        else hipLaunchKernelGGL(gelu_pad_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)s, (float*)out, H, W, Hp, Wp);
     } else {
-        ProfScope prof("uno::gelu_pad_bwd_kernel", 4.0 * n_img * 3.0 * H * W, st);
+        ProfScope prof("uno::gelu_pad_bwd_kernel", es * n_img * 3.0 * H * W, st);
         const long long quads = (long long)H * ((W + 3) / 4);
-        hipLaunchKernelGGL(gelu_pad_bwd_kernel, dim3((unsigned)((quads + 255) / 256), n_img), dim3(256), 0, st, s, gy, out, H, W, Hp, Wp);
+        const dim3 grid((unsigned)((quads + 255) / 256), n_img);
+        if (bf16) hipLaunchKernelGGL(gelu_pad_bwd_kernel<bf_t>, grid, dim3(256), 0, st, (const bf_t*)s, (const bf_t*)gy, (bf_t*)out, H, W, Hp, Wp);
+        else hipLaunchKernelGGL(gelu_pad_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)s, (const float*)gy, (float*)out, H, W, Hp, Wp);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gelu_pad launch: %s", hipGetErrorString(e)); return -5; }

@@ -16,14 +16,17 @@
 namespace uno {
 
 // out[n][i][q] = sum_t wt[i][t] * in[n][start[i] + t][q]      (rows of length W)
-__global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+// TI / TO: element types of the source / destination (float | unsigned short = bfloat16 bits); the two-pass form keeps its
+// intermediate in f32
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void resample_rows_kernel(const TI* __restrict__ in, TO* __restrict__ out,
                                                             const int* __restrict__ start, const float* __restrict__ wt,
                                                             int K, int H, int Ho, int W, int rows_per_block, int accumulate) {
     const int n = blockIdx.z;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= W) return;
-    const float* src = in + (size_t)n * H * W + q;
-    float* dst = out + (size_t)n * Ho * W + q;
+    const TI* src = in + (size_t)n * H * W + q;
+    TO* dst = out + (size_t)n * Ho * W + q;
     const int i0 = blockIdx.y * rows_per_block;
     const int i1 = min(i0 + rows_per_block, Ho);
     for (int i = i0; i < i1; ++i) {
@@ -32,14 +35,15 @@ __global__ __launch_bounds__(256) void resample_rows_kernel(const float* __restr
         float acc = 0.f;
         for (int t = 0; t < K; ++t) {
             const int p = min(s + t, H - 1);            // taps beyond the band carry weight 0
-            acc = fmaf(w[t], src[(size_t)p * W], acc);
+            acc = fmaf(w[t], io_widen(src[(size_t)p * W]), acc);
         }
-        dst[(size_t)i * W] = accumulate ? dst[(size_t)i * W] + acc : acc;
+        io_store1(dst + (size_t)i * W, accumulate ? io_widen(dst[(size_t)i * W]) + acc : acc);
     }
 }
 
 // out[n][r][j] = sum_t wt[j][t] * in[n][r][start[j] + t]
-__global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void resample_cols_kernel(const TI* __restrict__ in, TO* __restrict__ out,
                                                             const int* __restrict__ start, const float* __restrict__ wt,
                                                             int K, int R, int W, int Wo, int rows_per_block, int accumulate) {
     const int n = blockIdx.z;
@@ -52,13 +56,13 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restr
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(r0 + rows_per_block, R);
     for (int r = r0; r < r1; ++r) {
-        const float* src = in + ((size_t)n * R + r) * W;
+        const TI* src = in + ((size_t)n * R + r) * W;
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-            if (t < K) acc = fmaf(w[t], src[min(s + t, W - 1)], acc);
-        float* o = out + ((size_t)n * R + r) * Wo + j;
-        *o = accumulate ? *o + acc : acc;
+            if (t < K) acc = fmaf(w[t], io_widen(src[min(s + t, W - 1)]), acc);
+        TO* o = out + ((size_t)n * R + r) * Wo + j;
+        io_store1(o, accumulate ? io_widen(*o) + acc : acc);
     }
 }
 
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const float* __restr
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
 
-template <bool ACCUM, int KT>      // KT: compiled tap count of the column operator (>= KW; weights past KW are zero)
-__global__ __launch_bounds__(512) void resample_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <bool ACCUM, int KT, typename T>      // KT: compiled tap count of the column operator (>= KW; weights past KW are zero)
+__global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
                                                              int H, int W, int Ho, int Wo) {
@@ -86,17 +90,17 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
     const int nthreads = blockDim.x;
     for (int e = tid; e < NP * RS_TR; e += nthreads) sWd[e] = tile_w[(size_t)tile * NP * RS_TR + e];   // [NP][16], zero outside the band
     __syncthreads();
-    const float* src = in + (size_t)n * H * W;
+    const T* src = in + (size_t)n * H * W;
     for (int q = tid; q < W; q += nthreads) {
         float acc[RS_TR];
 #pragma unroll
         for (int r = 0; r < RS_TR; ++r) acc[r] = 0.f;
         // input rows in groups of 4, the next group's loads issued before the current group is consumed (the compiler's
         // own unrolling drained every group - s_waitcnt vmcnt(0) - before issuing the next: one memory latency per 4 rows)
-        const float* col = src + q;
+        const T* col = src + q;
         auto load4 = [&](int u0, float x[4]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = col[(size_t)min(p0 + u0 + i, H - 1) * W];      // clamped: rows past the tile meet no weights
+            for (int i = 0; i < 4; ++i) x[i] = io_widen(col[(size_t)min(p0 + u0 + i, H - 1) * W]);      // clamped: rows past the tile meet no weights
         };
         auto fma4 = [&](int u0, const float x[4]) {
 #pragma unroll
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
         for (int r = 0; r < RS_TR; ++r) V[r * W + q] = acc[r];
     }
     __syncthreads();
-    float* dst = out + ((size_t)n * Ho + i0) * Wo;
+    T* dst = out + ((size_t)n * Ho + i0) * Wo;
     const int nr = min(RS_TR, Ho - i0);
     // phase 2: thread -> (row group g, column j): when the workgroup is wider than a row, groups take rows round-robin
     const int WoP = (Wo + 63) & ~63;
@@ -152,26 +156,37 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const float* __rest
                 for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
                 // ACCUM is a template parameter: a run-time flag here put a conditional load into the store loop and
                 // cost the plain path 60 % (227 -> 362 us at 1024 x 446^2 -> 223^2)
-                dst[(size_t)r * Wo + j] = ACCUM ? dst[(size_t)r * Wo + j] + acc : acc;
+                io_store1(dst + (size_t)r * Wo + j, ACCUM ? io_widen(dst[(size_t)r * Wo + j]) + acc : acc);
             }
         }
     }
 }
 
-int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
-                      const float* tile_w, int NP, int accumulate, hipStream_t s) {
+                      const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s) {
+    typedef unsigned short bf_t;
+    const float* in = static_cast<const float*>(in_);
+    float* out = static_cast<float*>(out_);
+    const bf_t* inb = static_cast<const bf_t*>(in_);
+    bf_t* outb = static_cast<bf_t*>(out_);
+    const double es = bf16 ? 2.0 : 4.0;
     if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
     if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
         const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)NP * RS_TR * sizeof(float);
-        ProfScope prof("uno::resample_fused_kernel", 4.0 * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
+        ProfScope prof("uno::resample_fused_kernel", es * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
         // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
         const int sweeps = (W + 511) / 512;
         const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
         const dim3 grid((Ho + RS_TR - 1) / RS_TR, n_img);
-#define UNO_RS_LAUNCH(A, K) hipLaunchKernelGGL((resample_fused_kernel<A, K>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
-                                               startW, wtW, KW, H, W, Ho, Wo)
+#define UNO_RS_LAUNCH(A, K)                                                                                                    \
+        do {                                                                                                                   \
+            if (bf16) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \
+                                         startW, wtW, KW, H, W, Ho, Wo);                                                       \
+            else hipLaunchKernelGGL((resample_fused_kernel<A, K, float>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
+                                    startW, wtW, KW, H, W, Ho, Wo);                                                            \
+        } while (0)
         // tap counts seen in the U-NO models: 4-5 (up-sampling by ~2 and its adjoint's rows), 9-10 (down-sampling by ~2)
 #define UNO_RS_PICK(A)                                                                                                         \
         do {                                                                                                                   \
@@ -189,26 +204,33 @@ int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H,
     const int RPB = 16;
     // rows first when that shrinks the intermediate (Ho*W <= H*Wo), columns first otherwise
     const bool rows_first = (long long)Ho * W <= (long long)H * Wo;
-    const double img_bytes = 4.0 * n_img;
+    const double img_bytes = 4.0 * n_img;       // the intermediate is f32 in both element types
     if (rows_first) {
+        const dim3 g1((W + 255) / 256, (Ho + RPB - 1) / RPB, n_img), g2((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img);
         {
-            ProfScope prof("uno::resample_rows_kernel", img_bytes * ((double)H * W + (double)Ho * W), s);
-            hipLaunchKernelGGL(resample_rows_kernel, dim3((W + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startH, wtH, KH, H, Ho, W, RPB, 0);
+            ProfScope prof("uno::resample_rows_kernel", n_img * (es * H * W + 4.0 * Ho * W), s);
+            if (bf16) hipLaunchKernelGGL((resample_rows_kernel<bf_t, float>), g1, dim3(256), 0, s, inb, tmp, startH, wtH, KH, H, Ho, W, RPB, 0);
+            else hipLaunchKernelGGL((resample_rows_kernel<float, float>), g1, dim3(256), 0, s, in, tmp, startH, wtH, KH, H, Ho, W, RPB, 0);
         }
         {
-            ProfScope prof("uno::resample_cols_kernel", img_bytes * ((double)Ho * W + (double)Ho * Wo), s);
-            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
+            ProfScope prof("uno::resample_cols_kernel", n_img * (4.0 * Ho * W + es * Ho * Wo), s);
+            if (bf16) hipLaunchKernelGGL((resample_cols_kernel<float, bf_t>), g2, dim3(256), 0, s, (const float*)tmp, outb, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
+            else hipLaunchKernelGGL((resample_cols_kernel<float, float>), g2, dim3(256), 0, s, (const float*)tmp, out, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
         }
     } else {
+        const dim3 g1((Wo + 255) / 256, (H + RPB - 1) / RPB, n_img), g2((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img);
         {
-            ProfScope prof("uno::resample_cols_kernel", img_bytes * ((double)H * W + (double)H * Wo), s);
-            hipLaunchKernelGGL(resample_cols_kernel, dim3((Wo + 255) / 256, (H + RPB - 1) / RPB, n_img), dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
+            ProfScope prof("uno::resample_cols_kernel", n_img * (es * H * W + 4.0 * H * Wo), s);
+            if (bf16) hipLaunchKernelGGL((resample_cols_kernel<bf_t, float>), g1, dim3(256), 0, s, inb, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
+            else hipLaunchKernelGGL((resample_cols_kernel<float, float>), g1, dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
         }
         {
-            ProfScope prof("uno::resample_rows_kernel", img_bytes * ((double)H * Wo + (double)Ho * Wo), s);
-            hipLaunchKernelGGL(resample_rows_kernel, dim3((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img), dim3(256), 0, s, tmp, out, startH, wtH, KH, H, Ho, Wo, RPB, accumulate);
+            ProfScope prof("uno::resample_rows_kernel", n_img * (4.0 * H * Wo + es * Ho * Wo), s);
+            if (bf16) hipLaunchKernelGGL((resample_rows_kernel<float, bf_t>), g2, dim3(256), 0, s, (const float*)tmp, outb, startH, wtH, KH, H, Ho, Wo, RPB, accumulate);
+            else hipLaunchKernelGGL((resample_rows_kernel<float, float>), g2, dim3(256), 0, s, (const float*)tmp, out, startH, wtH, KH, H, Ho, Wo, RPB, accumulate);
         }
     }
+    (void)img_bytes;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

@@ -51,6 +51,15 @@ __device__ __forceinline__ void io_store4(unsigned short* dst, float a, float b,
 __device__ __forceinline__ void io_store8(unsigned short* dst, const f32x4& a, const f32x4& b) {
     *reinterpret_cast<h8u*>(dst) = h8u{{bf16_pack2(a[0], a[1]), bf16_pack2(a[2], a[3]), bf16_pack2(b[0], b[1]), bf16_pack2(b[2], b[3])}};
 }
+// four consecutive elements at ELEMENT alignment (rows of odd length), widened to f32
+__device__ __forceinline__ float4 io_ld4(const float* p) {
+    const f4u v = *reinterpret_cast<const f4u*>(p);
+    return make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+}
+__device__ __forceinline__ float4 io_ld4(const unsigned short* p) {
+    const h4u v = *reinterpret_cast<const h4u*>(p);
+    return make_float4(io_widen(v.v[0]), io_widen(v.v[1]), io_widen(v.v[2]), io_widen(v.v[3]));
+}
 __device__ __forceinline__ void io_store1(float* dst, float a) { *dst = a; }
 __device__ __forceinline__ void io_store1(unsigned short* dst, float a) { *dst = bf16_rne(a); }
 
@@ -112,6 +121,7 @@ struct ModeOperand {
     const float2* base[4];
     long long s0, s1;       // A: (m, k); B: (k, n); out: (m, n)
     int conj;
+    int half;               // operand B only: elements are half-precision (re, im) pairs instead of complex64
 };
 struct ModeGemmParams {
     ModeOperand A, B;
@@ -152,24 +162,24 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_dft2d_generic(const Dft2dParams& p, bool inverse, hipStream_t s);      // dft_generic.hip: any mode count
 int launch_cdft_generic(const CdftParams& p, bool inverse, hipStream_t s);
-int launch_resample2d(const float* in, float* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
+int launch_resample2d(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
-                      const float* tile_w, int NP, int accumulate, hipStream_t s);
-int launch_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, int act_in, const float* dgelu_of, hipStream_t s);
+                      const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s);
+int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
+                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s);
-int launch_gelu_project_fwd(const float* pre, const float* w, const float* bias, float* out, int B, int C, long long P, hipStream_t s);
+int launch_gelu_project_fwd(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, hipStream_t s);
 long long gelu_project_ws_floats(int B, int C, long long P);
-int launch_gelu_project_bwd(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, float* ws, int B,
-                            int C, long long P, hipStream_t s);
-int launch_gelu_pad(const float* s, const float* gy, float* out, int n_img, int H, int W, int Hp, int Wp, int backward, hipStream_t st);
-int launch_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long rows, int C,
-                        long long N, float eps, int gelu, hipStream_t s);
-int launch_instnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                        float* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, hipStream_t s);
+int launch_gelu_project_bwd(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, float* ws, int B,
+                            int C, long long P, int bf16, hipStream_t s);
+int launch_gelu_pad(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward, int bf16, hipStream_t st);
+int launch_instnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
+                        long long N, float eps, int gelu, int bf16, hipStream_t s);
+int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, int bf16, hipStream_t s);
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
-int launch_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
-                         int act_x, hipStream_t s);
+int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
+                         int act_x, int bf16, hipStream_t s);
 
 }  // namespace uno

@@ -6,4 +6,5 @@ from .models import UNO, UNO_9, Uno3D_T20  # noqa: F401
 from .reference_style import UNO_9_ReferenceStyle  # noqa: F401
 from .optim import ComplexAdam  # noqa: F401
 from .losses import lp_loss_rel_sum  # noqa: F401
+from .mixed import MixedDarcyTrainer  # noqa: F401
 from .train import DarcyTrainer, GraphedStep, ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch  # noqa: F401

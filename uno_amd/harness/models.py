@@ -54,7 +54,7 @@ class UNO_9(nn.Module):
 
     def forward(self, x):
         S1, S2 = x.shape[1], x.shape[2]
-        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()   # (B, 3, S, S): tiny
+        x = torch.cat((x, self.get_grid(x.shape, x.device).to(x.dtype)), dim=-1).permute(0, 3, 1, 2).contiguous()   # (B, 3, S, S): tiny
         # lift: fc0(gelu(fc_n1(x))) with the intermediate kept pre-activation (GELU applied as fc0's kernels read it)
         lifted = gelu_channel_mix(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias), self.fc0.weight, self.fc0.bias)
         scale = math.ceil(S2 / 85)

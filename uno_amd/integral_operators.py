@@ -31,10 +31,37 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 __all__ = [
+    "enable_mixed_precision",
     "SpectralConv1d_Uno", "pointwise_op_1D", "OperatorBlock_1D",
     "SpectralConv2d_Uno", "pointwise_op_2D", "OperatorBlock_2D",
     "SpectralConv3d_Uno", "pointwise_op_3D", "OperatorBlock_3D",
 ]
+
+
+# activation dtypes the device kernels take: float32 (the reference's contract) and bfloat16 (mixed precision, BASELINE.json
+# configs[4]: opt-in per spectral layer via enable_mixed_precision - weights, statistics and accumulations stay float32)
+_ACT = (torch.float32, torch.bfloat16)
+
+
+def _dev_act(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype in _ACT
+
+
+def enable_mixed_precision(module: nn.Module, enabled: bool = True) -> nn.Module:
+    """Let the 2-D spectral layers under `module` take bfloat16 activations (the reference raises on them, integral_operators.py:187,
+    and so do these layers unless enabled here).  In that mode a layer reads its complex weights through a half-precision
+    (re, im) copy made per call (the parameters themselves - and their gradients - stay complex64: the master copy the
+    optimiser updates), transforms bf16 images directly and accumulates in f32 / c64; outputs and input gradients are bf16."""
+    for m in module.modules():
+        if isinstance(m, SpectralConv2d_Uno):
+            m.mixed_precision = bool(enabled)
+    return module
+
+
+def _half_weights(w1, w2):
+    """(Ci, Co, m1, m2, 2) float16 copies of two complex64 weight tensors (storage format of the mixed-precision kernels)."""
+    with torch.no_grad():
+        return torch.view_as_real(w1.detach()).half().contiguous(), torch.view_as_real(w2.detach()).half().contiguous()
 
 
 def _plain(t: torch.Tensor) -> torch.Tensor:
@@ -62,8 +89,10 @@ class _SpectralConv2dFn(torch.autograd.Function):
     """y = irfft2(corner-mix(rfft2(x)));  saves only the truncated input spectrum."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, Ho, Wo):
+    def forward(ctx, x, w1, w2, Ho, Wo, half_weights=False):
         x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
+        if half_weights:                    # complex64 master weights, read through float16 (re, im) copies
+            w1, w2 = _half_weights(w1, w2)
         y, xt = _native.spectral_conv2d_forward(x, w1, w2, int(Ho), int(Wo))
         ctx.save_for_backward(xt, w1, w2)
         ctx.in_hw = (x.shape[-2], x.shape[-1])
@@ -77,7 +106,7 @@ class _SpectralConv2dFn(torch.autograd.Function):
         need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         gx, gw1, gw2 = _native.spectral_conv2d_backward(_plain(gy), xt, w1, w2, ctx.in_hw[0], ctx.in_hw[1],
                                                         need_gx=need_gx, need_gw=need_gw)
-        return gx, gw1, gw2, None, None
+        return gx, gw1, gw2, None, None, None
 
 
 class _ChannelMixFn(torch.autograd.Function):
@@ -111,7 +140,7 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     B, Ci = x.shape[0], x.shape[1]
     w = weight.reshape(weight.shape[0], Ci)
     xv = x.reshape(B, Ci, -1)
-    if x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
+    if _dev_act(x) and w.dtype == torch.float32:
         y = _ChannelMixFn.apply(xv, w, bias)
     elif bias is not None:
         y = torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xv)
@@ -161,7 +190,7 @@ def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_fi
     darcy_flow_uno2d.py:122-127: `torch.cat([x_c5, x_fc0], dim=1)` then `fc1`) - without materialising the
     concatenation when there are two float32 device tensors.  gelu_first: xs[0] is a PRE-activation tensor and stands
     for gelu(xs[0]) (the block in front deferred its GELU to this consumer)."""
-    if len(xs) == 2 and all(x.is_cuda and x.dtype == torch.float32 for x in xs) and weight.dtype == torch.float32:
+    if len(xs) == 2 and all(_dev_act(x) for x in xs) and xs[0].dtype == xs[1].dtype and weight.dtype == torch.float32:
         x1, x2 = xs
         B = x1.shape[0]
         w = weight.reshape(weight.shape[0], -1)
@@ -201,7 +230,7 @@ def gelu_channel_mix(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
     """channel_mix(F.gelu(pre), weight, bias) without the activation tensor (float32 device tensors)."""
     B, Ci = pre.shape[0], pre.shape[1]
     w = weight.reshape(weight.shape[0], Ci)
-    if pre.is_cuda and pre.dtype == torch.float32 and w.dtype == torch.float32:
+    if _dev_act(pre) and w.dtype == torch.float32:
         y = _GeluChannelMixFn.apply(pre.reshape(B, Ci, -1), w, bias)
         return y.view(B, w.shape[0], *pre.shape[2:])
     return channel_mix(F.gelu(pre), weight, bias)
@@ -230,7 +259,7 @@ def gelu_project(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | N
     """channel_mix(F.gelu(pre), weight, bias) for the models' final projection (reference darcy_flow_uno2d.py:128-131:
     `F.gelu(self.fc1(x))` then `self.fc2`, fc2 = Linear(C, 1)): with ONE output channel on a HIP device the GELU and
     the projection are a single streaming pass (no GELU output tensor, no one-row GEMM)."""
-    if weight.shape[0] == 1 and pre.is_cuda and pre.dtype == torch.float32 and weight.dtype == torch.float32 and pre.shape[1] <= 1024:
+    if weight.shape[0] == 1 and _dev_act(pre) and weight.dtype == torch.float32 and pre.shape[1] <= 1024:
         B, C = pre.shape[0], pre.shape[1]
         out = _GeluProjectFn.apply(pre.reshape(B, C, -1), weight.reshape(C), bias)
         return out.view(B, 1, *pre.shape[2:])
@@ -256,7 +285,7 @@ class _GeluPadFn(torch.autograd.Function):
 def gelu_pad2d(s: torch.Tensor, pad_h: int, pad_w: int) -> torch.Tensor:
     """F.pad(F.gelu(s), [0, pad_w, 0, pad_h]) - the lift's last activation and the domain padding (reference
     darcy_flow_uno2d.py:103-107) in one pass over the tensor on a HIP device."""
-    if s.is_cuda and s.dtype == torch.float32 and s.dim() >= 2 and pad_h >= 0 and pad_w >= 0:
+    if _dev_act(s) and s.dim() >= 2 and pad_h >= 0 and pad_w >= 0:
         return _GeluPadFn.apply(s, s.shape[-2] + int(pad_h), s.shape[-1] + int(pad_w))
     return F.pad(F.gelu(s), [0, pad_w, 0, pad_h])
 
@@ -287,7 +316,7 @@ class _InstanceNormGeluFn(torch.autograd.Function):
 def instance_norm_gelu(x: torch.Tensor, norm: nn.Module, gelu: bool) -> torch.Tensor:
     """`norm(x)` followed, if `gelu`, by F.gelu - for an nn.InstanceNorm{2,3}d without running statistics on a float32
     HIP tensor both run as one kernel; anything else takes the stock modules."""
-    if (x.is_cuda and x.dtype == torch.float32 and isinstance(norm, (nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d))
+    if (_dev_act(x) and isinstance(norm, (nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d))
             and not norm.track_running_stats and x.dim() >= 3 and x.shape[1] == norm.num_features):
         if x.numel() // max(x.shape[0] * x.shape[1], 1) <= 1:           # torch.nn.functional.instance_norm refuses this too
             raise ValueError(f"Expected more than 1 spatial element when training, got input size {x.size()}")
@@ -306,9 +335,11 @@ class _OperatorBlock2dFn(torch.autograd.Function):
     separate element-wise pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo):
+    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo, half_weights=False):
         from .resample import resample_forward
         x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
+        if half_weights:
+            w1, w2 = _half_weights(w1, w2)
         B, Ci, H, W = x.shape
         Co = cw.shape[0]
         cwm = _plain(cw).reshape(Co, Ci)
@@ -360,7 +391,7 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                 gcw, gcb = _native.channel_wgrad(g_t, act.view(B, Ci, -1), need_bias=has_bias)
         if gcw is not None:
             gcw = gcw.view(cw_shape)
-        return gx, gw1, gw2, gcw, gcb, None, None
+        return gx, gw1, gw2, gcw, gcb, None, None, None
 
 
 class _OperatorBlock2dCatFn(torch.autograd.Function):
@@ -371,12 +402,14 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
     of a joint gradient to copy or accumulate)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo):
+    def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo, half_weights=False):
         from .resample import resample_forward
         x1, x2, w1, w2 = _plain(x1), _plain(x2), _plain(w1), _plain(w2)
         B, C1, H, W = x1.shape
         C2 = x2.shape[1]
         Ci, Co, m1, m2 = w1.shape
+        if half_weights:
+            w1, w2 = _half_weights(w1, w2)
         cwm = _plain(cw).reshape(Co, Ci)
         cwa, cwb = cwm[:, :C1].contiguous(), cwm[:, C1:].contiguous()
         cb = None if cb is None else _plain(cb)
@@ -385,7 +418,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         _native.dft2d_forward(x1, m1, m2, 1.0 / (H * W), out=xt, channel_offset=0)
         _native.dft2d_forward(x2, m1, m2, 1.0 / (H * W), out=xt, channel_offset=C1)
         O = _native.mode_mix(xt.view(B, Ci, 2, m1 * m2), [w1, w2], 0)
-        s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True)
+        s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True, dtype=x1.dtype)
         # point-wise branch accumulates into s
         same = (H, W) == (Ho, Wo)
         mix_last = same or Ho * Wo < H * W
@@ -412,7 +445,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         H, W, same, mix_last, has_bias, cw_shape = ctx.geom
         gs = _plain(gs)
         B, Co, Ho, Wo = gs.shape
-        Ci, _, m1, m2 = w1.shape
+        Ci, _, m1, m2 = w1.shape[:4]
         C1, C2 = a1.shape[1], a2.shape[1]
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_gw = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
@@ -420,14 +453,14 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)                       # c (.) keep (.) DFT_trunc(gs)
         gw1 = gw2 = None
         if need_gw:
-            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape), 2)
+            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2)
         gx1 = gx2 = None
         if need1 or need2:
             gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
             if need1:
-                gx1 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C1, channel_offset=0)
+                gx1 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C1, channel_offset=0, dtype=gs.dtype)
             if need2:
-                gx2 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C2, channel_offset=C1)
+                gx2 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C2, channel_offset=C1, dtype=gs.dtype)
         gcw = gcb = None
         if mix_last:
             g_src = gs.view(B, Co, -1)
@@ -449,7 +482,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
             gwa, gcb = _native.channel_wgrad(g_src, a1.view(B, C1, -1), need_bias=has_bias)
             gwb, _ = _native.channel_wgrad(g_src, a2.view(B, C2, -1), need_bias=False)
             gcw = torch.cat([gwa, gwb], dim=1).view(cw_shape)
-        return gx1, gx2, gw1, gw2, gcw, gcb, None, None
+        return gx1, gx2, gw1, gw2, gcw, gcb, None, None, None
 
 
 def spectral_conv2d(x, weights1, weights2, dim1, dim2):
@@ -463,19 +496,43 @@ def spectral_conv2d_mixed(x, weights1, weights2, dim1, dim2):
     (integral_operators.py:187).
 
     x (B, Ci, H, W) bfloat16 -> (B, Co, dim1, dim2) bfloat16; gradients: gx bfloat16, weights in their own dtype.
-    weights1/2: complex64 (Ci, Co, m1, m2), or their half-precision storage (Ci, Co, m1, m2, 2) float16 (re, im), which is
-    widened on the fly (33 MB at the C5 size against 1 GB of activations).  The pruned DFT kernels read / write the bf16
+    weights1/2: complex64 (Ci, Co, m1, m2), or their half-precision storage (Ci, Co, m1, m2, 2) float16 (re, im), which the
+    per-mode GEMM reads as it is (widened in registers; 33 MB at the C5 size).  The pruned DFT kernels read / write the bf16
     tensors directly; the truncated spectrum, the per-mode GEMM and every accumulation are f32 / c64, so the result equals the
     f32 operator applied to the widened inputs, rounded once (to nearest even) on the way out - tests/test_hip_mixed.py."""
     if x.dtype != torch.bfloat16:
         raise RuntimeError(f"spectral_conv2d_mixed: input must be bfloat16 (got {x.dtype})")
-    def widen(w):
-        if w.dtype == torch.float16:
-            if w.shape[-1] != 2:
-                raise RuntimeError("spectral_conv2d_mixed: half-precision weights are stored as (..., 2) = (re, im)")
-            return torch.view_as_complex(w.float())
-        return w
-    return _SpectralConv2dFn.apply(x, widen(weights1), widen(weights2), dim1, dim2)
+    for w in (weights1, weights2):
+        if w.dtype == torch.float16 and w.shape[-1] != 2:
+            raise RuntimeError("spectral_conv2d_mixed: half-precision weights are stored as (..., 2) = (re, im)")
+    if weights1.dtype == torch.float16:
+        return _SpectralConv2dHalfFn.apply(x, weights1, weights2, dim1, dim2)
+    return _SpectralConv2dFn.apply(x, weights1, weights2, dim1, dim2)
+
+
+class _SpectralConv2dHalfFn(torch.autograd.Function):
+    """spectral_conv2d_mixed with the weights GIVEN in half-precision (re, im) storage: K2 reads them as they are (no widened
+    copy); their gradients are accumulated in complex64 and returned rounded once to the storage format."""
+
+    @staticmethod
+    def forward(ctx, x, w1h, w2h, Ho, Wo):
+        x, w1h, w2h = _plain(x), _plain(w1h), _plain(w2h)
+        y, xt = _native.spectral_conv2d_forward(x, w1h, w2h, int(Ho), int(Wo))
+        ctx.save_for_backward(xt, w1h, w2h)
+        ctx.in_hw = (x.shape[-2], x.shape[-1])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xt, w1h, w2h = ctx.saved_tensors
+        need_gx = ctx.needs_input_grad[0]
+        need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gx, gw1, gw2 = _native.spectral_conv2d_backward(_plain(gy), xt, w1h, w2h, ctx.in_hw[0], ctx.in_hw[1],
+                                                        need_gx=need_gx, need_gw=need_gw)
+        if need_gw:
+            gw1, gw2 = torch.view_as_real(gw1).half(), torch.view_as_real(gw2).half()
+        return gx, gw1, gw2, None, None
 
 
 # --------------------------------------------------------------------------------------------- 2-D
@@ -503,11 +560,14 @@ class SpectralConv2d_Uno(nn.Module):
         shape = (in_codim, out_codim, self.modes1, self.modes2)
         self.weights1 = nn.Parameter(self.scale * torch.randn(*shape, dtype=torch.cfloat))
         self.weights2 = nn.Parameter(self.scale * torch.randn(*shape, dtype=torch.cfloat))
+        self.mixed_precision = False        # enable_mixed_precision(): accept bfloat16 activations (the reference raises)
 
     def forward(self, x, dim1=None, dim2=None):
         if dim1 is not None:        # persistent override, as in the reference (:182-184)
             self.dim1 = dim1
             self.dim2 = dim2
+        if self.mixed_precision and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == self.in_channels:
+            return _SpectralConv2dFn.apply(x, self.weights1, self.weights2, self.dim1, self.dim2, True)
         _check_input(x, 4, self.in_channels, "SpectralConv2d_Uno")
         return spectral_conv2d(x, self.weights1, self.weights2, self.dim1, self.dim2)
 
@@ -525,7 +585,7 @@ class pointwise_op_2D(nn.Module):
     def forward(self, x, dim1=None, dim2=None):
         if dim1 is None:
             dim1, dim2 = self.dim1, self.dim2
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        if not (_dev_act(x) and x.dim() == 4):
             return F.interpolate(self.conv(x), size=(dim1, dim2), mode="bicubic", align_corners=True, antialias=True)
         # HIP path: the resampling is a separable banded operator with the reference's weights (uno_amd/resample.py).
         # It commutes with the 1x1 convolution (both linear, resampling rows sum to 1 so the bias passes through),
@@ -566,7 +626,7 @@ class OperatorBlock_2D(nn.Module):
         conv, w = self.conv, self.w
         d1, d2 = (dim1, dim2) if dim1 is not None else (w.dim1, w.dim2)
         cdims = (dim1, dim2) if dim1 is not None else (conv.dim1, conv.dim2)
-        fused = (len(xs) == 2 and all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 for x in xs)
+        fused = (len(xs) == 2 and all(self._takes(x) for x in xs) and xs[0].dtype == xs[1].dtype
                  and xs[0].shape[0] == xs[1].shape[0] and xs[0].shape[2:] == xs[1].shape[2:]
                  and xs[0].shape[1] + xs[1].shape[1] == conv.in_channels and cdims == (d1, d2)
                  and w.conv.weight.dtype == torch.float32)
@@ -576,7 +636,8 @@ class OperatorBlock_2D(nn.Module):
             return self.forward(torch.cat(xs, dim=1), dim1, dim2)
         if dim1 is not None:
             conv.dim1, conv.dim2 = dim1, dim2
-        out = _OperatorBlock2dCatFn.apply(xs[0], xs[1], conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2))
+        out = _OperatorBlock2dCatFn.apply(xs[0], xs[1], conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2),
+                                          xs[0].dtype == torch.bfloat16)
         if defer_gelu:
             return out
         if self.normalize:
@@ -590,11 +651,17 @@ class OperatorBlock_2D(nn.Module):
             d1, d2 = dim1, dim2
         else:
             d1, d2 = w.dim1, w.dim2
-        fused = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (conv.dim1, conv.dim2) == (d1, d2)
+        fused = (self._takes(x) and (conv.dim1, conv.dim2) == (d1, d2)
                  and x.shape[1] == conv.in_channels and w.conv.weight.dtype == torch.float32)
         if not fused:               # CPU tensors raise inside the spectral layer; mismatched grids raise at the sum
             return conv(x) + w(x, d1, d2)
-        return _OperatorBlock2dFn.apply(x, conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2))
+        return _OperatorBlock2dFn.apply(x, conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2),
+                                        x.dtype == torch.bfloat16)
+
+    def _takes(self, x):
+        """4-D device tensor the fused block kernels take: float32, or bfloat16 once the spectral layer is in mixed-precision mode."""
+        return (x.is_cuda and x.dim() == 4 and
+                (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and getattr(self.conv, "mixed_precision", False))))
 
 
 # --------------------------------------------------------------------------------------------- 3-D
