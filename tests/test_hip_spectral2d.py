@@ -268,16 +268,6 @@ def test_empty_batch():
     assert tuple(spectral_conv2d(x, w, w, 8, 8).shape) == (0, 4, 8, 8)
 
 
-def test_mode_counts_beyond_the_compiled_range_raise():
-    """modes1 <= 40 and modes2 <= 48 are compiled; larger requests fail loudly (no silent fallback)."""
-    from uno_amd.integral_operators import spectral_conv2d
-    x = torch.randn(1, 1, 128, 128, device=dev())
-    for m1, m2 in ((41, 8), (8, 49)):
-        w = torch.randn(1, 1, m1, m2, dtype=torch.cfloat, device=dev())
-        with pytest.raises(RuntimeError, match="compiled range"):
-            spectral_conv2d(x, w, w, 128, 128)
-
-
 @pytest.mark.parametrize("cfg", [(3, 4, 5, 37, 50, 9), (2, 6, 3, 64, 32, 17), (1, 1, 2, 9, 9, 5), (4, 8, 8, 421, 211, 20)])
 def test_spectral_conv1d_runs_on_the_2d_kernels(cfg):
     """SpectralConv1d_Uno (reference integral_operators.py:7-72) on the GPU = the 2-D layer on a one-row grid; compared with

@@ -349,15 +349,13 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
     const int wfast_hi = W - Wh - 1;                        // largest w whose mirror column W - w lies in the right half
     const bool chain = NW == 1;                             // consecutive tiles by one wave: carry the partial line
 
-    for (int rt = wsub; rt < nrt; rt += NW) {
-        float* tile = img + (size_t)rt * 16 * W;
-        const int rows = min(16, H - 16 * rt);
-        const int phase = (int)((reinterpret_cast<uintptr_t>(tile) >> 2) & 31);       // LDS index == memory offset (mod 128 B)
-        // ---- stage B'
+    // stage B' of row tile rt -> (Ur, Ui); `between(ks)` runs after the MFMAs of k-step ks (the store phase of the PREVIOUS tile is
+    // threaded through here: its LDS reads and global stores issue in the shadow of the column stage's MFMAs)
+    f32x4 Ur[NT], Ui[NT];
+    auto stage_b = [&](int rt, auto&& between) {
         const unsigned hB = (unsigned)min(16 * rt + r16, H - 1);
         const unsigned a4 = 8u * ((4u * hB) % (unsigned)H);
         unsigned aj = 8u * (((unsigned)kk * hB) % (unsigned)H);
-        f32x4 Ur[NT], Ui[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Ur[t] = f32x4{0, 0, 0, 0}; Ui[t] = f32x4{0, 0, 0, 0}; }
         float2 twb = lds_tw(sTwH, aj);
@@ -376,7 +374,15 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
                 }
             }
             twb = twn;
+            between(ks);
         }
+    };
+    if (wsub < nrt) stage_b(wsub, [](int) {});
+
+    for (int rt = wsub; rt < nrt; rt += NW) {
+        float* tile = img + (size_t)rt * 16 * W;
+        const int rows = min(16, H - 16 * rt);
+        const int phase = (int)((reinterpret_cast<uintptr_t>(tile) >> 2) & 31);       // LDS index == memory offset (mod 128 B)
 
         // ---- stage A' into the LDS tile: lane (h = r16, g = kk) owns columns 16 wt + 4 g + e and their mirrors W - (...).
         // One wave per SIMD: the MFMA pipe only stays busy if nothing in the instruction stream waits for the MFMAs just
@@ -461,18 +467,24 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
         const int nfull = hi >> 8;                          // instructions [1, nfull) cover whole 1 KB runs inside [lo, hi)
         store_guarded(4 * lane);
         int it = 1;
-        for (; it + 4 <= nfull; it += 4) {
-            const float* src = buf + 256 * it + 4 * lane;
-            float* dst = gbase + 256 * it + 4 * lane;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 256);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 512);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + 768);
-            *reinterpret_cast<f32x4*>(dst) = v0;
-            *reinterpret_cast<f32x4*>(dst + 256) = v1;
-            *reinterpret_cast<f32x4*>(dst + 512) = v2;
-            *reinterpret_cast<f32x4*>(dst + 768) = v3;
-        }
+        auto store_batch = [&]() {                          // four whole 1 KB runs: reads first, then the stores
+            if (it + 4 <= nfull) {
+                const float* src = buf + 256 * it + 4 * lane;
+                float* dst = gbase + 256 * it + 4 * lane;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 256);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 512);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + 768);
+                *reinterpret_cast<f32x4*>(dst) = v0;
+                *reinterpret_cast<f32x4*>(dst + 256) = v1;
+                *reinterpret_cast<f32x4*>(dst + 512) = v2;
+                *reinterpret_cast<f32x4*>(dst + 768) = v3;
+                it += 4;
+            }
+        };
+        // the next tile's column stage does not touch the LDS tile: its MFMAs cover this tile's store phase
+        if (rt + NW < nrt) stage_b(rt + NW, [&](int) { store_batch(); });
+        while (it + 4 <= nfull) store_batch();
         for (; it < nfull; ++it)
             *reinterpret_cast<f32x4*>(gbase + 256 * it + 4 * lane) = *reinterpret_cast<const f32x4*>(buf + 256 * it + 4 * lane);
         if (nfull >= 1) store_guarded(256 * nfull + 4 * lane);
