@@ -23,6 +23,9 @@ namespace uno {
 
 constexpr int FT_TAILMAX = 5;           // tail <= 15 pairs + w = 0 + Nyquist column = 17 elements = 5 k-steps
 constexpr size_t FT_LDS_BUDGET = 160 * 1024 - 2048;
+#ifndef UNO_FT_AUX
+#define UNO_FT_AUX 2                    // cache policy of the tile loads: 2 = non-temporal
+#endif
 #ifndef UNO_FT_MAXW
 #define UNO_FT_MAXW 160                // widest image the full-tile form takes (see fwd_ft_geometry)
 #endif
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
         const unsigned v0 = (unsigned)(((toff & ~31) + 4 * lane) * 4);
         for (int i = 0; i < npiece; ++i)
             if (256 * i + 4 * lane < total)         // the last piece stops at the end of the tile (lanes beyond it are masked off)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(buf + 256 * i), 16, v0 + 1024u * (unsigned)i, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(buf + 256 * i), 16, v0 + 1024u * (unsigned)i, 0, 0, UNO_FT_AUX);
     };
     if (active && wsub < nrt) request_tile(wsub);
 
@@ -425,12 +428,8 @@ static bool fwd_ft_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtG
 template <int NT, int MT, int R4>
 static int launch_fwd_ft(Dft2dParams p, const FwdFtGeometry& g, hipStream_t s) {
     auto k = dft2d_fwd_ft_kernel<NT, MT, R4>;
-    if (g.lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) {
-            set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", g.lds);
-            return -4;
-        }
-    }
+    static int lds_slot[64];
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_fwd_ft_kernel<%d, %d, %d>", NT, MT, R4);

@@ -382,12 +382,8 @@ static int launch_fwd_b(const Dft2dParams& p, hipStream_t s) {
     const size_t lds = (size_t)(p.W + p.H) * sizeof(float2) + (size_t)TAILMAX * (2 + NS) * 64 * 4 + red;
     if (lds > 160 * 1024) { set_error("dft2d_fwd: grid %dx%d needs %zu B of LDS", p.H, p.W, lds); return -3; }
     auto k = dft2d_fwd_kernel<NT, MT, VEC, R4, BF16>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", lds);
-            return -4;
-        }
-    }
+    static int lds_slot[64];
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_slot)) { set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", lds); return -4; }
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_fwd_kernel<%d, %d, %s, %d, %s>", NT, MT, VEC ? "true" : "false", R4, BF16 ? "true" : "false");
     {

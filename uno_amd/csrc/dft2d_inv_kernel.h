@@ -31,6 +31,9 @@
 
 namespace uno {
 
+#ifndef UNO_K3_NT
+#define UNO_K3_NT 0                     // 1: non-temporal stores of the full-tile form (experiment switch)
+#endif
 constexpr int STG_COLS = 64;            // columns per staged chunk (4 MFMA column tiles)
 constexpr int STG_RS = STG_COLS + 4;    // LDS row stride in floats: 16-byte aligned, 4-bank skew per row
 constexpr int INV_MAX_WAVES = 12;       // waves per workgroup (3 per SIMD: the register budget of the large instantiations)
@@ -475,10 +478,17 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 256);
                 const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 512);
                 const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + 768);
-                *reinterpret_cast<f32x4*>(dst) = v0;
-                *reinterpret_cast<f32x4*>(dst + 256) = v1;
-                *reinterpret_cast<f32x4*>(dst + 512) = v2;
-                *reinterpret_cast<f32x4*>(dst + 768) = v3;
+                if (UNO_K3_NT) {
+                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(dst));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(dst + 256));
+                    __builtin_nontemporal_store(v2, reinterpret_cast<f32x4*>(dst + 512));
+                    __builtin_nontemporal_store(v3, reinterpret_cast<f32x4*>(dst + 768));
+                } else {
+                    *reinterpret_cast<f32x4*>(dst) = v0;
+                    *reinterpret_cast<f32x4*>(dst + 256) = v1;
+                    *reinterpret_cast<f32x4*>(dst + 512) = v2;
+                    *reinterpret_cast<f32x4*>(dst + 768) = v3;
+                }
                 it += 4;
             }
         };
@@ -544,12 +554,8 @@ static InvGeometry inv_geometry(const Dft2dParams& p, int KS, bool allow_tab) {
 template <int KS, int JT, bool BF16, bool TAB>
 static int launch_inv_k(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     auto k = dft2d_inv_kernel<KS, JT, BF16, TAB>;
-    if (g.lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) {
-            set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds);
-            return -4;
-        }
-    }
+    static int lds_slot[64];
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d, %s, %s>", KS, JT, BF16 ? "true" : "false", TAB ? "true" : "false");
@@ -593,12 +599,8 @@ static bool inv_ft_geometry(const Dft2dParams& p, int KS, InvGeometry* out) {
 template <int KS, int JT>
 static int launch_inv_ft(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     auto k = dft2d_inv_ft_kernel<KS, JT>;
-    if (g.lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds) != hipSuccess) {
-            set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds);
-            return -4;
-        }
-    }
+    static int lds_slot[64];
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_inv_ft_kernel<%d, %d>", KS, JT);

@@ -142,6 +142,20 @@ struct CdftParams {
 };
 
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
+
+// Raise a kernel's dynamic-LDS limit to the largest size any launch of it (on this device) has asked for so far.  The driver call is
+// made only when the request grows: it costs tens of microseconds, and the transforms are launched thousands of times per step.
+// `slot` is a per-kernel-instantiation static array (one entry per device, zero-initialised).
+inline bool ensure_dynamic_lds(const void* kernel, size_t bytes, int* slot) {
+    if (bytes <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if ((size_t)__atomic_load_n(&slot[dev], __ATOMIC_RELAXED) >= bytes) return true;
+    const int want = 160 * 1024;            // the hardware limit: one call covers every later size
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess) return false;
+    __atomic_store_n(&slot[dev], want, __ATOMIC_RELAXED);
+    return true;
+}
 void set_error(const char* fmt, ...);
 
 // RAII timing scope around one kernel launch (no-op unless uno_profile_begin() is active).
