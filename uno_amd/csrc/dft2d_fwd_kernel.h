@@ -23,10 +23,6 @@
 #include "dft2d_fwd_ht_kernel.h"
 #include <cstdio>
 
-#ifndef UNO_ABLATE
-#define UNO_ABLATE 0        // developer ablation builds only (tools/ablate.sh); 0 = product
-#endif
-
 namespace uno {
 
 constexpr int TAILMAX = 5;      // tail <= 15 pairs + w=0 + Nyquist column = 17 elements = 5 k-steps
@@ -139,14 +135,8 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
 #define UNO_LOAD_CHUNK(buf, xr, c)                                                        \
     do {                                                                                  \
         const int a_ = 16 * min((c), clast) + 4 * kk;                                     \
-        if (UNO_ABLATE & 8) { /* same bytes, fully contiguous per instruction (wrong data) */ \
-        const in_t* t_ = img + min(__builtin_amdgcn_readfirstlane((int)((xr) - img)), (H - 16) * W) + 128 * min((c), clast) + 4 * lane; \
-        bl[buf] = *reinterpret_cast<const vec_t*>(t_);                                    \
-        br[buf] = *reinterpret_cast<const vec_t*>(t_ + 256);                              \
-        } else if (!(UNO_ABLATE & 2)) {                                                   \
         bl[buf] = *reinterpret_cast<const vec_t*>((xr) + 1 + a_);                         \
         br[buf] = *reinterpret_cast<const vec_t*>((xr) + W - 4 - a_);                     \
-        }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);  /* keep the prefetch where it is issued */    \
     } while (0)
 
@@ -206,11 +196,8 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
             const float D = io_widen(bl[buf].v[s]) - io_widen(br[buf].v[3 - s]);          \
             float2 twn[NS];                                                               \
             _Pragma("unroll") for (int t = 0; t < NS; ++t) {                              \
-                if (UNO_ABLATE & 1) { twn[t] = tw[t]; }                                   \
-                else {                                                                    \
                 twn[t] = lds_tw(sTwW, idx[t]);                                            \
                 idx[t] = wrap_add(idx[t], s == 2 ? jump[t] : stepL[t], W8);               \
-                }                                                                         \
             }                                                                             \
             UNO_STAGE_A_MFMA(E, D, tw);                                                   \
             _Pragma("unroll") for (int t = 0; t < NS; ++t) tw[t] = twn[t];                \
@@ -290,7 +277,7 @@ __global__ __launch_bounds__(256, (fwd_waves_per_simd<NT, MT>())) void dft2d_fwd
             idxB[mt] = wrap_add(i0, 8u * (unsigned)Kj[mt], H8);
         }
 #pragma unroll
-        for (int s = 0; s < ((UNO_ABLATE & 4) ? 1 : 4); ++s) {
+        for (int s = 0; s < 4; ++s) {
             const bool hvalid = (16 * rt + 4 * kk + s) < H;
             float2 twBn[MT];
 #pragma unroll
