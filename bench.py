@@ -158,12 +158,13 @@ def _kernel_table(fn, n=5):
                 "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in agg.items()}
 
 
-def _traffic(names):
-    """HBM bytes per launch (PMC passes, profiles/hbm_traffic.json) summed over the kernels of one call, or None."""
+def _traffic(names, launches=None):
+    """HBM bytes per call (PMC passes of the standalone blocks, profiles/block_traffic.json): sum over the call's kernels of
+    bytes per launch x launches per call, or None."""
     tfile = os.path.join(ROOT, "profiles", "block_traffic.json")     # standalone C2 / C4 block runs (tools/profile_round.sh)
     try:
         table = json.load(open(tfile))
-        vals = [table[n]["bytes_per_launch"] for n in names]
+        vals = [table[n]["bytes_per_launch"] * (launches[n] if launches else 1.0) for n in names]
         return float(sum(vals))
     except Exception:
         return None
@@ -461,11 +462,12 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": "spectral block forward = " + " + ".join(sorted(kf)),
             "achieved": block["fwd_bytes"] / (block["fwd_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": block["fwd_frac_of_8TBs"], "traffic": _traffic(list(kf)),
+            "frac": block["fwd_frac_of_8TBs"], "traffic": _traffic(list(kf), {k: v["launches_per_call"] for k, v in kf.items()}),
             "avg_launch_us": block["fwd_us"], "algorithmic_bytes_per_launch": block["fwd_bytes"],
             "backward": {"achieved": block["bwd_bytes"] / (block["bwd_us"] * 1e-6) / 1e9, "frac": block["bwd_frac_of_8TBs"],
                          "avg_launch_us": block["bwd_us"], "algorithmic_bytes_per_launch": block["bwd_bytes"],
-                         "traffic": _traffic(list(block["bwd_kernels"])), "kernels": block["bwd_kernels"]},
+                         "traffic": _traffic(list(block["bwd_kernels"]), {k: v["launches_per_call"] for k, v in block["bwd_kernels"].items()}),
+                         "kernels": block["bwd_kernels"]},
             "kernels": kf,
             "dominant_kernel": {"name": dom, "avg_launch_us": kf[dom]["avg_us"], "achieved": kf[dom]["GBps"],
                                 "frac": kf[dom]["GBps"] / HBM_PEAK_GBS, "traffic": _traffic([dom])},
