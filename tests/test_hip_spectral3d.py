@@ -67,8 +67,20 @@ SEEDED3 = [
 ]
 
 
+# >= 192 (sample, channel) volumes on both sides: the one-workgroup-per-volume kernels K1v / K3v (csrc/dft3d_volume.hip)
+VOLUME3 = [
+    (4, 48, 48, (16, 16, 10), (16, 16, 10), (6, 6, 4)),       # 16-byte pieces only
+    (6, 32, 32, (12, 20, 20), (12, 20, 20), (4, 7, 8)),       # + the 4-column block of T = 20; all 16 interleaved columns
+    (4, 48, 64, (9, 15, 7), (11, 13, 12), (4, 6, 4)),         # odd axis lengths (no N/2 plane / row), resampling
+    (2, 96, 96, (8, 40, 6), (8, 40, 6), (3, 18, 3)),          # two kappa tiles and two slot tiles along dim2
+    (2, 96, 96, (40, 8, 6), (40, 8, 6), (18, 3, 3)),          # ... along dim1
+    (2, 96, 96, (8, 8, 26), (8, 8, 26), (3, 3, 8)),           # two 16-column blocks along T
+    (1, 192, 192, (16, 12, 21), (12, 16, 19), (6, 6, 8)),     # two T blocks, the second one narrow on the way in
+]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", SEEDED3)
+@pytest.mark.parametrize("cfg", SEEDED3 + VOLUME3)
 def test_seeded_3d_vs_dense_oracle(cfg):
     from uno_amd import _native
     from uno_amd.spectral3d import spectral_conv3d

@@ -596,6 +596,38 @@ static int check_modes3d(const char* who, int H, int W, int T, int Ho, int Wo, i
     return 0;
 }
 
+// volumes (n_vol, D1, D2, D3) -> corner-major truncated spectra (n_vol, 4, m1, m2, m3); `adjoint` = the Hermitian-weighted, masked form
+// the backward pass applies to the output gradient.  One workgroup per volume where that fits (K1v), else plane by plane (K1p) into
+// the workspace Z (n_vol * D1, 2 m2, m3) c64 and the leading axis from there (K5).
+static int fwd_transform3d(const float* x, float* spec, float* Z, int n_vol, int D1, int D2, int D3, int m1, int m2, int m3, float scale,
+                           int adjoint, hipStream_t s) {
+    if (vol3d_fwd_applies(n_vol, D1, D2, D3, m1, m2, m3)) {
+        Vol3dParams v;
+        v.in = x; v.out = spec; v.n_vol = n_vol; v.D1 = D1; v.D2 = D2; v.D3 = D3; v.m1 = m1; v.m2 = m2; v.m3 = m3;
+        v.scale = scale; v.herm = adjoint;
+        v.tw1 = twiddle_table(2 * D1); v.tw2 = twiddle_table(2 * D2); v.tw3 = twiddle_table(D3);
+        if (!v.tw1 || !v.tw2 || !v.tw3) return -6;
+        return launch_dft3d_fwd_volume(v, s);
+    }
+    if (int rc = dft2d(false, x, Z, n_vol * D1, D2, D3, m2, m3, scale, adjoint, adjoint, s)) return rc;
+    return uno_cdft_axis(Z, spec, 0, n_vol, D1, m1, m2, m3, 1.0f, adjoint, (void*)s);
+}
+
+// the inverse: corner-major spectra -> volumes; `weighted` = Hermitian weights + later-wins masks (the forward pass's irfftn)
+static int inv_transform3d(const float* spec, float* y, float* Z, int n_vol, int D1, int D2, int D3, int m1, int m2, int m3, float scale,
+                           int weighted, hipStream_t s) {
+    if (vol3d_inv_applies(n_vol, D1, D2, D3, m1, m2, m3)) {
+        Vol3dParams v;
+        v.in = spec; v.out = y; v.n_vol = n_vol; v.D1 = D1; v.D2 = D2; v.D3 = D3; v.m1 = m1; v.m2 = m2; v.m3 = m3;
+        v.scale = scale; v.herm = weighted;
+        v.tw1 = twiddle_table(2 * D1); v.tw2 = twiddle_table(2 * D2); v.tw3 = twiddle_table(D3);
+        if (!v.tw1 || !v.tw2 || !v.tw3) return -6;
+        return launch_dft3d_inv_volume(v, s);
+    }
+    if (int rc = uno_cdft_axis(spec, Z, 1, n_vol, D1, m1, m2, m3, 1.0f, weighted, (void*)s)) return rc;
+    return dft2d(true, Z, y, n_vol * D1, D2, D3, m2, m3, scale, weighted, weighted, s);
+}
+
 long long uno_spectral_conv3d_fwd_ws_bytes(int B, int Ci, int Co, int H, int Ho, int m1, int m2, int m3) {
     const long long C = 2LL * m2 * m3;
     return 8LL * B * ((long long)Ci * H * C + (long long)Co * Ho * C + 4LL * Co * m1 * m2 * m3);
@@ -620,13 +652,11 @@ int uno_spectral_conv3d_forward(const float* x, const float* const* w, float* y,
     float* O5 = Z2 + 2LL * B * Co * Ho * C;                       // (B, Co, 4, m1, m2, m3) c64
     const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
     // rfftn over (W, T) plane by plane, then the H axis                       (reference :398)
-    if (int rc = dft2d(false, x, Z1, B * Ci * H, W, T, m2, m3, inv_n, 0, 0, s)) return rc;
-    if (int rc = uno_cdft_axis(Z1, xtrunc, 0, B * Ci, H, m1, m2, m3, 1.0f, 0, stream)) return rc;
+    if (int rc = fwd_transform3d(x, xtrunc, Z1, B * Ci, H, W, T, m1, m2, m3, inv_n, 0, s)) return rc;
     // four corner einsums "bixyz,ioxyz->boxyz"                                  (reference :410-421)
     if (int rc = uno_mode_mix(xtrunc, w, O5, 0, B, Ci, Co, 4, (int)Mc, stream)) return rc;
     // irfftn(out_ft, s=(Ho, Wo, To), norm="forward"); later-wins masks are separable per axis (reference :400-426)
-    if (int rc = uno_cdft_axis(O5, Z2, 1, B * Co, Ho, m1, m2, m3, 1.0f, 1, stream)) return rc;
-    return dft2d(true, Z2, y, B * Co * Ho, Wo, To, m2, m3, 1.0f, 1, 1, s);
+    return inv_transform3d(O5, y, Z2, B * Co, Ho, Wo, To, m1, m2, m3, 1.0f, 1, s);
 }
 
 int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const float* const* w, float* gx, float* const* gw,
@@ -648,15 +678,13 @@ int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const flo
     float* Z2 = Z1 + 2LL * B * Ci * H * C;
     float* gO = Z2 + 2LL * B * Co * Ho * C;
     float* gX = gO + 2LL * B * Co * 4 * Mc;
-    if (int rc = dft2d(false, gy, Z2, B * Co * Ho, Wo, To, m2, m3, 1.0f, 1, 1, s)) return rc;
-    if (int rc = uno_cdft_axis(Z2, gO, 0, B * Co, Ho, m1, m2, m3, 1.0f, 1, stream)) return rc;
+    if (int rc = fwd_transform3d(gy, gO, Z2, B * Co, Ho, Wo, To, m1, m2, m3, 1.0f, 1, s)) return rc;
     if (gw)
         if (int rc = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, stream)) return rc;
     if (gx) {
         if (int rc = uno_mode_mix(gO, w, gX, 1, B, Ci, Co, 4, (int)Mc, stream)) return rc;
-        if (int rc = uno_cdft_axis(gX, Z1, 1, B * Ci, H, m1, m2, m3, 1.0f, 0, stream)) return rc;
         const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
-        if (int rc = dft2d(true, Z1, gx, B * Ci * H, W, T, m2, m3, inv_n, 0, 0, s)) return rc;
+        if (int rc = inv_transform3d(gX, gx, Z1, B * Ci, H, W, T, m1, m2, m3, inv_n, 0, s)) return rc;
     }
     return 0;
 }

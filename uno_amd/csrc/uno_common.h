@@ -141,6 +141,18 @@ struct CdftParams {
     const int* rowfreq;     // optional: frequency of spectrum row j, j < 2*m1, instead of the corner rule
 };
 
+// One workgroup per (sample, channel) volume: all three pruned transforms of the 3-D layer (dft3d_volume.hip).
+struct Vol3dParams {
+    const float* in;        // forward: volumes (n_vol, D1, D2, D3) f32; inverse: corner-major spectra (n_vol, 4, m1, m2, m3) c64
+    float* out;
+    const float2* tw1;      // (cos, sin)(2 pi n / (2 D1)), n in [0, 2 D1): half-shifted frequencies and the e^{i pi h / D1} twist
+    const float2* tw2;      // ... of 2 D2
+    const float2* tw3;      // (cos, sin)(2 pi n / D3)
+    int n_vol, D1, D2, D3, m1, m2, m3;
+    float scale;
+    int herm;               // 1: multiply T-mode l by the Hermitian weight c_l of D3
+};
+
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
 
 // Raise a kernel's dynamic-LDS limit to the largest size any launch of it (on this device) has asked for so far.  The driver call is
@@ -172,6 +184,10 @@ bool dft2d_fwd_plane_applies(const Dft2dParams& p);      // dft2d_plane.hip: man
 bool dft2d_inv_plane_applies(const Dft2dParams& p);
 int launch_dft2d_fwd_plane(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv_plane(const Dft2dParams& p, hipStream_t s);
+bool vol3d_fwd_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3);      // dft3d_volume.hip
+bool vol3d_inv_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3);
+int launch_dft3d_fwd_volume(const Vol3dParams& p, hipStream_t s);
+int launch_dft3d_inv_volume(const Vol3dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_dft2d_generic(const Dft2dParams& p, bool inverse, hipStream_t s);      // dft_generic.hip: any mode count
