@@ -28,6 +28,9 @@ namespace uno {
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int VOL_WAVES = 16;
+#ifndef UNO_VOL_EXP
+#define UNO_VOL_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = no planes, 2 = planes only, 3 = tables only
+#endif
 constexpr size_t VOL_LDS_LIMIT = 160 * 1024;
 
 __device__ __forceinline__ float vol_xor1(float v) {       // the value held by lane ^ 1 (DPP quad_perm [1,0,3,2])
@@ -41,8 +44,8 @@ struct VolShape {
     int NBW, NARROW;         // dim3 in 16-column blocks: NBW with a 16-byte piece per lane (4 k-steps), + one 4-byte block (1 k-step)
     int KA;                  // k-steps of the T-axis stage
     int C2;                  // floats of a per-plane truncated spectrum: 2 m2 rows x m3 complex
-    int RP;                  // its row pitch in LDS (floats), = 16 mod 32: the four k-slots of a B-operand read fall on distinct banks
-    int NT;                  // 16-column tiles of C2
+    int RP;                  // its row pitch in LDS (floats), = 32 mod 64: the two k-slots of a half-wave's 8-byte B-operand reads fall on distinct banks
+    int NT;                  // 32-column (16 complex) blocks of C2
     int nks1;                // k-steps of the leading-axis stage
     size_t lds;
 };
@@ -59,9 +62,9 @@ static VolShape vol_shape(int D1, int D2, int D3, int m1, int m2, int m3) {
     g.NBW = nblk - g.NARROW;
     g.KA = 4 * g.NBW + g.NARROW;
     g.C2 = 2 * m2 * 2 * m3;
-    g.RP = g.C2;
-    while ((g.RP & 31) != 16) ++g.RP;
-    g.NT = (g.C2 + 15) / 16;
+    g.NT = (g.C2 + 31) / 32;
+    g.RP = 32 * g.NT;
+    while ((g.RP & 63) != 32) g.RP += 32;
     g.nks1 = (g.nslot1 + 3) / 4;
     g.lds = (size_t)2 * g.nslot1 * g.RP * 4                      // sD, sE
             + (size_t)g.KA * 64 * 4                              // T-axis twiddles (B operand)
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_fwd_volume_kernel(Vol3dP
 
     // this wave's slots: wave, wave + 16, ...; per slot two planes (a = slot, b = partner), per plane U tile pairs
     const int my_slots = (g.nslot1 - wave + VOL_WAVES - 1) / VOL_WAVES;      // may be <= 0
-    const int n_units = max(my_slots, 0) * 2 * U;
+    const int n_units = (UNO_VOL_EXP == 1 || UNO_VOL_EXP == 3) ? 0 : max(my_slots, 0) * 2 * U;
     auto unit_plane = [&](int q) -> int {
         const int slot = wave + VOL_WAVES * (q / (2 * U));
         const int second = (q / U) & 1;
@@ -267,32 +270,36 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_fwd_volume_kernel(Vol3dP
     }
     __syncthreads();
 
-    // ---- phase 2: leading axis out of LDS, 16-column tiles dealt to the waves
-    float* out = p.out + (size_t)vol * (size_t)(8 * m1 * m2 * m3);            // 4 corners x m1 m2 m3 complex
-    for (int tt = wave; tt < g.NT; tt += VOL_WAVES) {
-        const int col = 16 * tt + n16;
-        const bool cvalid = col < g.C2;
-        const int j2 = col / (2 * m3), nn = col - j2 * 2 * m3, l = nn >> 1, part = nn & 1;
+    if (UNO_VOL_EXP == 2 || UNO_VOL_EXP == 3) return;
+    // ---- phase 2: leading axis out of LDS, blocks of 16 complex columns dealt to the waves.  A lane owns one complex column
+    // (re and im are two MFMA column tiles), so i S needs no lane exchange and a row of the result leaves as 128 contiguous bytes.
+    float2* out = reinterpret_cast<float2*>(p.out) + (size_t)vol * (size_t)(4 * m1 * m2 * m3);            // 4 corners x m1 m2 m3 complex
+    for (int blk = wave; blk < g.NT; blk += VOL_WAVES) {
+        const int c = 16 * blk + n16;                                          // complex column j2 * m3 + l
+        const bool cvalid = 2 * c < g.C2;
+        const int j2 = c / m3, l = c - j2 * m3;
         const int cc = j2 >= m2, jj2 = j2 - cc * m2;
         for (int mt = 0; mt < g.MT1; ++mt) {
-            f32x4 C1 = f32x4{0, 0, 0, 0}, S1 = f32x4{0, 0, 0, 0};
+            f32x4 Cr = f32x4{0, 0, 0, 0}, Ci = f32x4{0, 0, 0, 0}, Sr = f32x4{0, 0, 0, 0}, Si = f32x4{0, 0, 0, 0};
             for (int ks = 0; ks < g.nks1; ++ks) {
                 const int row = min(4 * ks + gq, g.nslot1 - 1);
-                const float bD = sD[row * g.RP + col], bE = sE[row * g.RP + col];
+                const float2 bD = *reinterpret_cast<const float2*>(sD + row * g.RP + 32 * blk + 2 * n16);
+                const float2 bE = *reinterpret_cast<const float2*>(sE + row * g.RP + 32 * blk + 2 * n16);
                 const float2 tw = sTw1[(ks * g.MT1 + mt) * 64 + lane];
-                C1 = mfma16(tw.x, bD, C1);
-                S1 = mfma16(tw.y, bE, S1);
+                Cr = mfma16(tw.x, bD.x, Cr);
+                Ci = mfma16(tw.x, bD.y, Ci);
+                Sr = mfma16(tw.y, bE.x, Sr);
+                Si = mfma16(tw.y, bE.y, Si);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float js = sg * vol_xor1(S1[r]);
                 const int mk = 16 * mt + 4 * gq + r;
                 if (cvalid && mk < m1) {
-                    // corner-major (4, m1, m2, m3): corner = (j1 >= m1) + 2 (j2 >= m2)
-                    const size_t lo = ((((size_t)(0 + 2 * cc) * m1 + mk) * m2 + jj2) * m3 + l) * 2 + part;
-                    const size_t hi = ((((size_t)(1 + 2 * cc) * m1 + (m1 - 1 - mk)) * m2 + jj2) * m3 + l) * 2 + part;
-                    out[lo] = C1[r] - js;
-                    out[hi] = C1[r] + js;
+                    // corner-major (4, m1, m2, m3): corner = (j1 >= m1) + 2 (j2 >= m2);  +kappa = C - i S,  -kappa = C + i S
+                    const size_t lo = (((size_t)(0 + 2 * cc) * m1 + mk) * m2 + jj2) * m3 + l;
+                    const size_t hi = (((size_t)(1 + 2 * cc) * m1 + (m1 - 1 - mk)) * m2 + jj2) * m3 + l;
+                    out[lo] = make_float2(Cr[r] + Si[r], Ci[r] - Sr[r]);
+                    out[hi] = make_float2(Cr[r] - Si[r], Ci[r] + Sr[r]);
                 }
             }
         }
@@ -320,8 +327,8 @@ static VolInvShape vol_inv_shape(int D1, int D2, int D3, int m1, int m2, int m3)
     g.nk1 = (m1 + 3) / 4;
     g.nk2 = (m2 + 3) / 4;
     g.C2 = 2 * m2 * 2 * m3;
-    g.NT = (g.C2 + 15) / 16;
-    g.RP = 16 * g.NT + 4;                   // = 4 mod 16: the four 4-row groups of a phase-1 accumulator write fall on distinct banks
+    g.NT = (g.C2 + 31) / 32;               // blocks of 16 complex columns
+    g.RP = 32 * g.NT + 8;                   // = 8 mod 16: the two 4-row groups of a half-wave's 8-byte phase-1 writes fall on distinct banks
     g.lds = (size_t)D1 * g.RP * 4 + (size_t)g.nk1 * g.MTS * 64 * 8 + (size_t)g.MTS * 16 * 8 + (size_t)g.nk2 * g.U * 64 * 8;
     return g;
 }
@@ -392,58 +399,65 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_inv_volume_kernel(Vol3dP
     }
     __syncthreads();
 
-    // ---- phase 1: leading axis
+    // ---- phase 1: leading axis.  A lane owns one complex column of the volume's spectrum (16 of them per block): 8-byte loads,
+    // i Dk and the untwist without lane exchange, 8-byte LDS writes.
     const int vol = blockIdx.x;
-    const float* O = p.in + (size_t)vol * (size_t)(8 * m1 * m2 * m3);
-    const size_t cstride = (size_t)2 * m1 * m2 * m3;                             // floats per corner
-    for (int tt = wave; tt < g.NT; tt += VOL_WAVES) {
-        const int col = 16 * tt + n16, colc = min(col, g.C2 - 1);
-        const int j2 = colc / (2 * m3), nn = colc - j2 * 2 * m3;
+    const float2* O = reinterpret_cast<const float2*>(p.in) + (size_t)vol * (size_t)(4 * m1 * m2 * m3);
+    const size_t cstride = (size_t)m1 * m2 * m3;                                 // complex elements per corner
+    for (int blk = wave; blk < ((UNO_VOL_EXP == 2 || UNO_VOL_EXP == 3) ? 0 : g.NT); blk += VOL_WAVES) {
+        const int c = min(16 * blk + n16, g.C2 / 2 - 1);
+        const int j2 = c / m3, l = c - j2 * m3;
         const int cc = j2 >= m2, jj2 = j2 - cc * m2;
-        const float* Olo = O + (size_t)(2 * cc) * cstride + (size_t)jj2 * m3 * 2 + nn;          // + row * m2 * m3 * 2
-        const float* Ohi = Olo + cstride;
-        const int rstride = 2 * m2 * m3;
-        f32x4 Pc[MTS], Qs[MTS];
+        const float2* Olo = O + (size_t)(2 * cc) * cstride + (size_t)jj2 * m3 + l;          // + row * m2 * m3
+        const float2* Ohi = Olo + cstride;
+        const int rstride = m2 * m3;
+        f32x4 Pr[MTS], Pi[MTS], Qr[MTS], Qi[MTS];
 #pragma unroll
-        for (int mt = 0; mt < MTS; ++mt) { Pc[mt] = f32x4{0, 0, 0, 0}; Qs[mt] = f32x4{0, 0, 0, 0}; }
-        auto fetch = [&](int ks, float& lo, float& hi) {
+        for (int mt = 0; mt < MTS; ++mt) { Pr[mt] = f32x4{0, 0, 0, 0}; Pi[mt] = f32x4{0, 0, 0, 0}; Qr[mt] = f32x4{0, 0, 0, 0}; Qi[mt] = f32x4{0, 0, 0, 0}; }
+        auto fetch = [&](int ks, float2& lo, float2& hi) {
             const int mk = min(4 * ks + gq, m1 - 1);
             lo = Olo[(size_t)mk * rstride];
             hi = Ohi[(size_t)(m1 - 1 - mk) * rstride];
         };
-        float lo, hi, nlo, nhi;
+        float2 lo, hi, nlo, nhi;
         fetch(0, nlo, nhi);
         for (int ks = 0; ks < g.nk1; ++ks) {
             lo = nlo; hi = nhi;
             if (ks + 1 < g.nk1) fetch(ks + 1, nlo, nhi);
-            const float ek = lo + hi, jd = sg * vol_xor1(lo - hi);
+            const float er = lo.x + hi.x, ei = lo.y + hi.y;                      // Ek
+            const float jr = -(lo.y - hi.y), ji = lo.x - hi.x;                   // i Dk
 #pragma unroll
             for (int mt = 0; mt < MTS; ++mt) {
                 const float2 tw = sTw1[(ks * MTS + mt) * 64 + lane];
-                Pc[mt] = mfma16(tw.x, ek, Pc[mt]);
-                Qs[mt] = mfma16(tw.y, jd, Qs[mt]);
+                Pr[mt] = mfma16(tw.x, er, Pr[mt]);
+                Pi[mt] = mfma16(tw.x, ei, Pi[mt]);
+                Qr[mt] = mfma16(tw.y, jr, Qr[mt]);
+                Qi[mt] = mfma16(tw.y, ji, Qi[mt]);
             }
         }
+        const int colf = 32 * blk + 2 * n16;
 #pragma unroll
         for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * mt + 4 * gq + r;
                 const float2 t = sTwist1[i];
-                const float a = Pc[mt][r] + Qs[mt][r], b = Pc[mt][r] - Qs[mt][r];
-                float zi = t.x * a - t.y * (sg * vol_xor1(a));
-                float zn = t.x * b + t.y * (sg * vol_xor1(b));
-                const float jq = sg * vol_xor1(Qs[mt][r]);
-                if (i == 0) { zi = Pc[mt][r]; zn = -jq; }
+                const float ar = Pr[mt][r] + Qr[mt][r], ai = Pi[mt][r] + Qi[mt][r];
+                const float br = Pr[mt][r] - Qr[mt][r], bi = Pi[mt][r] - Qi[mt][r];
+                // plane i = conj(t) (Pc + Qs),  plane N - i = -t (Qs - Pc) = t (Pc - Qs)
+                float2 zi = make_float2(t.x * ar + t.y * ai, t.x * ai - t.y * ar);
+                float2 zn = make_float2(t.x * br - t.y * bi, t.x * bi + t.y * br);
+                if (i == 0) { zi = make_float2(Pr[mt][r], Pi[mt][r]); zn = make_float2(Qi[mt][r], -Qr[mt][r]); }      // planes 0 and N/2: Pc, -i Qs
                 if (i < g.nslot1) {
-                    sZ[i * g.RP + col] = zi;
-                    if (i > 0) sZ[(D1 - i) * g.RP + col] = zn;
-                    else if (even1) sZ[(D1 / 2) * g.RP + col] = zn;
+                    *reinterpret_cast<float2*>(sZ + i * g.RP + colf) = zi;
+                    if (i > 0) *reinterpret_cast<float2*>(sZ + (D1 - i) * g.RP + colf) = zn;
+                    else if (even1) *reinterpret_cast<float2*>(sZ + (D1 / 2) * g.RP + colf) = zn;
                 }
             }
     }
     __syncthreads();
 
+    if (UNO_VOL_EXP == 1 || UNO_VOL_EXP == 3) return;
     // ---- phase 2: planes
     float* ybase = p.out + (size_t)vol * D1 * D2 * D3;
     for (int d1 = wave; d1 < D1; d1 += VOL_WAVES) {
