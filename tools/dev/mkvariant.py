@@ -10,7 +10,7 @@ B.build()
 vdir = os.path.join(B.LIBDIR, "variants")
 os.makedirs(vdir, exist_ok=True)
 obj = os.path.join(vdir, f"{os.path.splitext(src)[0]}_{tag}.o")
-subprocess.run([B._hipcc(), *B.FLAGS, *defs, "-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
+subprocess.run([B._hipcc(), *B.FLAGS, *B.EXTRA_FLAGS.get(src, []), *defs, "-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
 objs = [obj if s == src else os.path.join(B.LIBDIR, "obj", os.path.splitext(s)[0] + ".o") for s in B.SOURCES]
 out = os.path.join(vdir, f"libuno_{tag}.so")
 subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-fno-gpu-rdc", *objs, "-o", out], check=True)

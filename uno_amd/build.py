@@ -24,6 +24,9 @@ SOURCES = ["capi.hip", "dft2d_fwd.hip", "dft2d_fwd_r4.hip", "dft2d_inv.hip", "df
 HEADERS = ["uno_common.h", "dft2d_fwd_kernel.h", "dft2d_fwd_ft_kernel.h", "dft2d_fwd_ht_kernel.h", "dft2d_inv_kernel.h", os.path.join("..", "..", "include", "uno_spectral.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# per-source flags.  mode_gemm.hip: its 4x4x1 kernel keeps 16 accumulator tiles live across a 4-step unrolled loop; with the
+# default AGPR form the register allocator permutes the tiles at every back edge (268 v_accvgpr moves per iteration)
+EXTRA_FLAGS = {"mode_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -39,6 +42,7 @@ def _digest() -> str:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -53,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -32,6 +32,9 @@ constexpr int VOL_WAVES = 16;
 #define UNO_VOL_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = no planes, 2 = planes only, 3 = tables only
 #endif
 constexpr size_t VOL_LDS_LIMIT = 160 * 1024;
+#ifndef UNO_VOL_MIN_VOLUMES
+#define UNO_VOL_MIN_VOLUMES 192  // one workgroup per volume: fewer volumes than CUs leave the chip idle
+#endif
 
 __device__ __forceinline__ float vol_xor1(float v) {       // the value held by lane ^ 1 (DPP quad_perm [1,0,3,2])
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -75,7 +78,7 @@ static VolShape vol_shape(int D1, int D2, int D3, int m1, int m2, int m3) {
 }
 
 bool vol3d_fwd_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3) {
-    if (n_vol < 192) return false;                               // one workgroup per volume: fewer volumes than CUs leave the chip idle
+    if (n_vol < UNO_VOL_MIN_VOLUMES) return false;
     if (D1 < 4 || D2 < 4 || D3 < 2 || D1 > 128 || D2 > 64 || D3 > 32) return false;
     if (2 * m1 > D1 || 2 * m2 > D2 || m1 > 32 || m2 > 32 || 2 * m3 > 16 || m3 > D3 / 2 + 1) return false;      // no corner overlap
     const VolShape g = vol_shape(D1, D2, D3, m1, m2, m3);
@@ -334,7 +337,7 @@ static VolInvShape vol_inv_shape(int D1, int D2, int D3, int m1, int m2, int m3)
 }
 
 bool vol3d_inv_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3) {
-    if (n_vol < 192) return false;
+    if (n_vol < UNO_VOL_MIN_VOLUMES) return false;
     if (D1 < 4 || D2 < 4 || D3 < 2 || D1 > 64 || D2 > 64 || D3 > 32) return false;
     if (2 * m1 > D1 || 2 * m2 > D2 || m1 > 32 || m2 > 32 || 2 * m3 > 16 || m3 > D3 / 2 + 1) return false;
     if ((long long)D1 * D2 * D3 * 4 >= (1LL << 31)) return false;

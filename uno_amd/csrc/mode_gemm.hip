@@ -188,6 +188,198 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- K2b
+// The same contraction on v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products per instruction, one per MODE.
+// Lane 4 q + x supplies A[m = 4 mt + x][k] and B[k][n = 4 nt + x] of mode q0 + q, and the mode axis is the contiguous axis of all
+// three operands - so an 8-byte load per lane (4 rows x 128 contiguous bytes per instruction) IS the MFMA operand and the
+// accumulator register i of lane 4 q + j IS out[m = 4 mt + i][n = 4 nt + j][q0 + q]: no LDS staging, no transposes, no barriers
+// in the K loop, and modes / rows past the end never mix with valid ones (their blocks / rows are simply not stored).
+// A wave owns MTW x NTW tiles of 4 x 4 outputs for 16 modes and walks K with its loads PF steps ahead; layers with few
+// (mode, tile) tasks split K over the waves of a workgroup and reduce through LDS.
+__device__ __forceinline__ f32x4 mfma4b(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);      // A[i] = lane 4 blk + i, B[j] = lane 4 blk + j, D[i][j] = lane 4 blk + j, reg i
+}
+
+
+// The MFMA wants the four rows of a block in four CONSECUTIVE lanes, memory wants consecutive lanes on consecutive addresses (with
+// lane 4 q + x on row x the address unit sees four different 128-byte lines in every group of four lanes: measured 27 us at the
+// Darcy block against 17 us for the LDS-staged kernel).  So lane 16 x + q loads / stores row x, mode q - 16 consecutive lanes on
+// 128 contiguous bytes - and a 64-lane transpose (ds_bpermute_b32: the LDS crossbar, no LDS memory) moves the value to lane 4 q + x.
+__device__ __forceinline__ float lane_pull(int src_lane_x4, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_x4, __float_as_int(v)));
+}
+
+template <int MTW, int NTW, int K2B_PF, bool BH>
+__global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p, int KS, int ngw, int per_group) {
+    extern __shared__ __attribute__((aligned(16))) float smb[];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = lane >> 2, x = lane & 3;                          // MFMA layout: block (mode) q, row / column x
+    const int mq = lane & 15, mx = lane >> 4;                       // memory layout: mode mq, row / column mx
+    const int to_mfma = 4 * (16 * x + q), to_mem = 4 * (4 * mq + mx);      // ds_bpermute source lanes (x 4 bytes)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroups go to the 8 XCDs round-robin by linear index, and every workgroup of a mode group reads the same A rows (all
+    // column groups) or the same B rows (all row groups): keep a mode group on ONE XCD, so that its operands come out of that
+    // XCD's L2 instead of being fetched over the fabric once per workgroup.
+    const int nq = (p.Mc + 15) >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = (slot / per_group) * 8 + xcd, within = slot % per_group;      // mode group, (column-group workgroup, row group) inside it
+    if (grp >= p.ncorner * nq) return;
+    const int corner = grp / nq, q0 = (grp % nq) * 16;
+    const int kidx = wave % KS, ng = (within % ngw) * (4 / KS) + wave / KS;
+    const int n0 = ng * 4 * NTW, m0 = (within / ngw) * 4 * MTW;
+    const bool active = n0 < p.N;
+    constexpr int ESB = BH ? 4 : 8;
+    const int pq = min(q0 + mq, p.Mc - 1);                         // modes past the end: a clamped (valid) address, never stored
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A.base[corner], 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B.base[corner], 0, -1, 0x00020000);
+    unsigned voA[MTW], voB[NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) voA[mt] = (unsigned)(((long long)min(m0 + 4 * mt + mx, p.M - 1) * p.A.s0 + pq) * 8);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) voB[nt] = (unsigned)(((long long)min(n0 + 4 * nt + mx, p.N - 1) * p.B.s1 + pq) * ESB);
+    const unsigned strideA = (unsigned)(p.A.s1 * 8), strideB = (unsigned)(p.B.s0 * ESB);
+    const float sgnA = p.A.conj ? -1.f : 1.f, sgnB = p.B.conj ? -1.f : 1.f;
+    const int kper = (p.K + KS - 1) / KS, kb = kidx * kper, ke = min(p.K, kb + kper);
+
+    f32x4 Dr[MTW][NTW], Di[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) { Dr[mt][nt] = f32x4{0, 0, 0, 0}; Di[mt][nt] = f32x4{0, 0, 0, 0}; }
+
+    float2 ra[K2B_PF][MTW], rb[K2B_PF][NTW];          // as loaded (memory layout)
+    float2 pa[2][MTW], pb[2][NTW];                    // transposed to the MFMA layout, one step ahead of the multiply
+    auto load_step = [&](int s, int k) {
+        const unsigned kk = (unsigned)min(k, p.K - 1);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rA, voA[mt], kk * strideA, 0);
+            ra[s][mt] = make_float2(__uint_as_float(t[0]), __uint_as_float(t[1]));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            if constexpr (BH) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(rB, voB[nt], kk * strideB, 0);
+                const h2_t hv = __builtin_bit_cast(h2_t, t);
+                rb[s][nt] = make_float2((float)hv[0], (float)hv[1]);
+            } else {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rB, voB[nt], kk * strideB, 0);
+                rb[s][nt] = make_float2(__uint_as_float(t[0]), __uint_as_float(t[1]));
+            }
+        }
+    };
+    auto transpose_step = [&](int s, int d) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) pa[d][mt] = make_float2(lane_pull(to_mfma, ra[s][mt].x), lane_pull(to_mfma, ra[s][mt].y));
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) pb[d][nt] = make_float2(lane_pull(to_mfma, rb[s][nt].x), lane_pull(to_mfma, rb[s][nt].y));
+    };
+    // Register stage s holds step k + s.  Per step: multiply the transposed operands of this step, refill the stage they came from
+    // (unconditionally, clamped row), transpose the next step's stage - whose loads were issued PF - 1 steps ago, so the waits in
+    // the loop are s_waitcnt vmcnt((PF - 1) steps' loads), never 0.  Steps past the end of this wave's K range multiply the (valid,
+    // clamped) row by zero: one straight-line loop body, no tail code.
+    if (active && kb < ke) {
+#pragma unroll
+        for (int s = 0; s < K2B_PF; ++s) {
+            load_step(s, kb + s);
+            __builtin_amdgcn_sched_barrier(0);           // issue order = stage order, in the prologue as in the loop
+        }
+        transpose_step(0, 0);
+#pragma unroll 1
+        for (int k = kb; k < ke; k += K2B_PF) {
+#pragma unroll
+            for (int s = 0; s < K2B_PF; ++s) {
+                const int d = s & 1;
+                const float live = (k + s < ke) ? 1.f : 0.f, la = live * sgnA;
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const float ar = live * pa[d][mt].x, ai = la * pa[d][mt].y, nai = -ai;
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const float br = pb[d][nt].x, bi = sgnB * pb[d][nt].y;
+                        Dr[mt][nt] = mfma4b(ar, br, Dr[mt][nt]);
+                        Di[mt][nt] = mfma4b(ar, bi, Di[mt][nt]);
+                        Dr[mt][nt] = mfma4b(nai, bi, Dr[mt][nt]);
+                        Di[mt][nt] = mfma4b(ai, br, Di[mt][nt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_step(s, k + s + K2B_PF);
+                __builtin_amdgcn_sched_barrier(0);
+                transpose_step((s + 1) % K2B_PF, d ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    float2* Ob = p.out[corner];
+    const bool qv = q0 + mq < p.Mc;
+    // accumulator register i of MFMA lane 4 q + j is out[m = 4 mt + i][n = 4 nt + j][q0 + q]; lane 16 j + q stores it
+    auto store_tile = [&](int mt, int nt, const f32x4& vr, const f32x4& vi) {
+        const int n = n0 + 4 * nt + mx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 v = make_float2(lane_pull(to_mem, vr[i]), lane_pull(to_mem, vi[i]));
+            const int m = m0 + 4 * mt + i;
+            if (qv && n < p.N && m < p.M) Ob[(long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq] = v;
+        }
+    };
+    if (KS == 1) {
+        if (!active) return;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) store_tile(mt, nt, Dr[mt][nt], Di[mt][nt]);
+        return;
+    }
+    // K split over KS waves: every wave leaves its partial tiles in LDS as [wave][tile][re | im][reg][lane]; wave r of a split group
+    // then sums and stores the tiles t = r (mod KS)
+    constexpr int TILES = MTW * NTW;
+    float* mine = smb + (size_t)wave * TILES * 8 * 64;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                mine[((mt * NTW + nt) * 8 + i) * 64 + lane] = Dr[mt][nt][i];
+                mine[((mt * NTW + nt) * 8 + 4 + i) * 64 + lane] = Di[mt][nt][i];
+            }
+    __syncthreads();
+    if (!active) return;
+    const float* grpb = smb + (size_t)(wave - kidx) * TILES * 8 * 64;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        if (t % KS != kidx) continue;
+        f32x4 vr = f32x4{0, 0, 0, 0}, vi = f32x4{0, 0, 0, 0};
+        for (int w = 0; w < KS; ++w)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vr[i] += grpb[((size_t)w * TILES * 8 + t * 8 + i) * 64 + lane];
+                vi[i] += grpb[((size_t)w * TILES * 8 + t * 8 + 4 + i) * 64 + lane];
+            }
+        store_tile(t / NTW, t % NTW, vr, vi);
+    }
+}
+
+template <int MTW, int NTW, int PF>
+static void launch_blocks_t(const ModeGemmParams& p, int KS, hipStream_t s) {
+    const int nq = (p.Mc + 15) / 16;
+    const int ngroups = (p.N + 4 * NTW - 1) / (4 * NTW), mgroups = (p.M + 4 * MTW - 1) / (4 * MTW);
+    const int per_wg = 4 / KS;
+    const int ngw = (ngroups + per_wg - 1) / per_wg, per_group = ngw * mgroups;
+    dim3 grid(((p.ncorner * nq + 7) / 8) * 8 * per_group);
+    const size_t lds = KS > 1 ? (size_t)4 * MTW * NTW * 8 * 64 * sizeof(float) : 0;
+    if (p.B.half) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
+    else hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
+}
+
+#ifndef UNO_K2_BLOCKS
+#define UNO_K2_BLOCKS 1
+#endif
+
 // 16 modes: one staging buffer (33.8 KB, also holds the 34.8 KB output tile); 8 modes: two (34.8 KB)
 static size_t mode_gemm_lds(int qc, bool pipe) {
     const size_t sb = (size_t)2 * 2 * qc * (KC * 16 + 64 / qc), out = (size_t)16 * 16 * (qc + 1) * 2;
@@ -214,6 +406,29 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         // each operand counted once: A (M x K), B (K x N), out (M x N) complex64 per mode
         const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.M * p.N) + (p.B.half ? 4.0 : 8.0) * (double)p.K * p.N;
         ProfScope prof("uno::mode_gemm_kernel", per_mode * p.ncorner * p.Mc, s);
+        // The 4x4x1 form works on whole groups of 16 modes: layers whose last group is mostly padding (2 x 36 modes = 3 groups per
+        // corner, a quarter of the third one used) stay on the LDS-staged form with its 8-mode variant; so do weight gradients
+        // with very large outputs (measured, tools/k2bench.py: 256 -> 512 channels x 4 x 216 modes, 906 MB: 263 against 332 us).
+        const int groups = (p.Mc + 15) / 16;
+        const bool padded = 16 * groups * 5 > p.Mc * 6;                         // > 20 % idle blocks
+        const bool short_k = p.K <= 32 && p.M >= 16 && p.N >= 16;               // the weight gradient: K = batch
+        const bool huge_out = short_k && 8.0 * p.M * p.N * p.Mc * p.ncorner > 200e6;
+        if (UNO_K2_BLOCKS && !padded && !huge_out) {
+            // short K and many rows / columns: 16 x 16 outputs per wave, so that each operand row is re-read by N / 16 (M / 16)
+            // waves like in the LDS-staged form; few rows (the batch, in the forward /
+            // input-gradient forms): all of them in one wave, more columns
+            const bool square = short_k;
+            const bool wide_m = p.M > 8;
+            const int tm = wide_m ? 16 : 8, tn = wide_m ? 8 : 16;
+            const long long tasks = (long long)p.ncorner * groups * ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn);
+            const int KS = square ? 1 : (tasks < 1024 && p.K >= 32) ? 4 : (tasks < 2048 && p.K >= 16) ? 2 : 1;
+            if (square) launch_blocks_t<4, 4, 2>(p, KS, s);
+            else if (wide_m) launch_blocks_t<4, 2, 4>(p, KS, s);
+            else launch_blocks_t<2, 4, 4>(p, KS, s);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }
+            return 0;
+        }
         // pipelined K loop: measured better with few mode chunks per layer (2 x 36 / 2 x 64 modes: 26 -> 22, 34 -> 29 us) and
         // worse with many (2 x 196 / 2 x 324 modes: 41 -> 50, 58 -> 67 us)
         const bool pipe = narrow && p.ncorner * nq <= 32;
