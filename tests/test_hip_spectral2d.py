@@ -106,6 +106,10 @@ MIX_SHAPES = [
     (17, 20, 33, 2, (2, 9)), (1, 1, 1, 2, (1, 1)), (4, 6, 5, 4, (3, 3, 2)), (3, 48, 24, 2, (18, 18)),
     # long channel loop on a small grid: the 8-mode workgroup variant (forward K = Ci, input gradient K = Co)
     (4, 96, 40, 2, (3, 3)), (3, 20, 128, 2, (5, 4)), (2, 130, 100, 4, (3, 2, 2)), (16, 256, 256, 2, (8, 8)), (5, 192, 48, 2, (3, 7)),
+    # mode counts with little padding to a multiple of 16: the 4x4x1 form (16 modes = the 16 blocks of an instruction) with ragged
+    # rows / columns / reduction lengths, its K split (few tasks, long K), the 16 x 16-per-wave weight-gradient form (K = B <= 32)
+    (5, 7, 9, 2, (9, 11)), (17, 20, 33, 2, (7, 9)), (3, 130, 100, 4, (6, 5, 3)), (8, 32, 64, 4, (6, 6, 5)), (32, 48, 96, 2, (14, 14)),
+    (9, 70, 18, 2, (10, 11)), (2, 64, 8, 2, (16, 16)),
 ]
 
 
