@@ -6,39 +6,43 @@
 
 namespace uno {
 
-struct AdamParams {
+
+struct AdamScalars {
+    float beta1, beta2, omb1, omb2, eps, wd, step_size, inv_sqrt_bc2;      // omb = 1 - beta, rounded from double
+};
+struct AdamTensor {
     float* p;
     const float* g;
     float* m;
     float* v;
     long long n;            // entries (complex entries for complex tensors)
-    float beta1, beta2, omb1, omb2, eps, wd, step_size, inv_sqrt_bc2;      // omb = 1 - beta, rounded from double
 };
 
+// the update of the 256 x EPT entries starting at entry 256 * EPT * blk of one tensor
 template <bool CPLX>
-__global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
+__device__ __forceinline__ void adam_block(const AdamTensor& t, const AdamScalars& a, long long blk) {
     // a thread owns 4 floats of p/g/m = 4 real entries or 2 complex ones
     constexpr int EPT = CPLX ? 2 : 4;
-    const long long e0 = ((long long)blockIdx.x * 256 + threadIdx.x) * EPT;
-    if (e0 >= a.n) return;
+    const long long e0 = (blk * 256 + threadIdx.x) * EPT;
+    if (e0 >= t.n) return;
     const long long f0 = CPLX ? 2 * e0 : e0;
     float p[4], g[4], m[4], v[EPT];
-    const bool full = e0 + EPT <= a.n;
-    const int nf = full ? 4 : (int)((a.n - e0) * (CPLX ? 2 : 1));
+    const bool full = e0 + EPT <= t.n;
+    const int nf = full ? 4 : (int)((t.n - e0) * (CPLX ? 2 : 1));
     if (full) {
         // 16-byte accesses at 4-byte alignment (gradients may be views at any offset of a flat buffer)
-        const f4u p4 = *reinterpret_cast<const f4u*>(a.p + f0), g4 = *reinterpret_cast<const f4u*>(a.g + f0),
-                  m4 = *reinterpret_cast<const f4u*>(a.m + f0);
+        const f4u p4 = *reinterpret_cast<const f4u*>(t.p + f0), g4 = *reinterpret_cast<const f4u*>(t.g + f0),
+                  m4 = *reinterpret_cast<const f4u*>(t.m + f0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { p[i] = p4.v[i]; g[i] = g4.v[i]; m[i] = m4.v[i]; }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            p[i] = i < nf ? a.p[f0 + i] : 0.f; g[i] = i < nf ? a.g[f0 + i] : 0.f; m[i] = i < nf ? a.m[f0 + i] : 0.f;
+            p[i] = i < nf ? t.p[f0 + i] : 0.f; g[i] = i < nf ? t.g[f0 + i] : 0.f; m[i] = i < nf ? t.m[f0 + i] : 0.f;
         }
     }
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) v[i] = e0 + i < a.n ? a.v[e0 + i] : 0.f;
+    for (int i = 0; i < EPT; ++i) v[i] = e0 + i < t.n ? t.v[e0 + i] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         g[i] = fmaf(a.wd, p[i], g[i]);
@@ -60,38 +64,91 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
         f4u po, mo;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { po.v[i] = p[i]; mo.v[i] = m[i]; }
-        *reinterpret_cast<f4u*>(a.p + f0) = po;
-        *reinterpret_cast<f4u*>(a.m + f0) = mo;
+        *reinterpret_cast<f4u*>(t.p + f0) = po;
+        *reinterpret_cast<f4u*>(t.m + f0) = mo;
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < nf) { a.p[f0 + i] = p[i]; a.m[f0 + i] = m[i]; }
+            if (i < nf) { t.p[f0 + i] = p[i]; t.m[f0 + i] = m[i]; }
     }
 #pragma unroll
     for (int i = 0; i < EPT; ++i)
-        if (e0 + i < a.n) a.v[e0 + i] = v[i];
+        if (e0 + i < t.n) t.v[e0 + i] = v[i];
 }
 
-int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
-                double eps, double wd, int step, hipStream_t s) {
-    AdamParams a;
-    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+// Multi-tensor form: up to ADAM_MAX_TENSORS parameter tensors per launch, described in the kernel arguments (no device-side
+// table to upload).  Workgroup b belongs to the tensor whose range of workgroup indices [first[t], first[t + 1]) holds b: a model's
+// dozens of small tensors (biases, 64 x 64 weights) share launches with the large ones instead of one under-filled launch each.
+constexpr int ADAM_MAX_TENSORS = 24;
+struct AdamMultiParams {
+    AdamTensor t[ADAM_MAX_TENSORS];
+    unsigned first[ADAM_MAX_TENSORS + 1];
+    unsigned cplx_mask;
+    int n_tensors;
+    AdamScalars a;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiParams q) {
+    int t = 0;
+#pragma unroll 1
+    for (int i = 1; i < q.n_tensors; ++i)
+        if (blockIdx.x >= q.first[i]) t = i;
+    const long long blk = blockIdx.x - q.first[t];
+    if ((q.cplx_mask >> t) & 1u) adam_block<true>(q.t[t], q.a, blk);
+    else adam_block<false>(q.t[t], q.a, blk);
+}
+
+static AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, double wd, int step) {
+    AdamScalars a;
     a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps; a.wd = (float)wd;
     a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     a.step_size = (float)(lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    const int ept = is_complex ? 2 : 4;
-    const long long threads = (n + ept - 1) / ept;
-    const unsigned grid = (unsigned)((threads + 255) / 256);
-    {
-        ProfScope prof("uno::adam_kernel", (is_complex ? 8.0 * 5 + 4.0 * 2 : 4.0 * 7) * (double)n, s);
-        if (is_complex) hipLaunchKernelGGL(adam_kernel<true>, dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(adam_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    return a;
+}
+
+int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
+                      const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s) {
+    const AdamScalars a = adam_scalars(lr, beta1, beta2, eps, wd, step);
+    int t0 = 0;
+    while (t0 < n_tensors) {
+        AdamMultiParams q;
+        q.a = a; q.cplx_mask = 0; q.n_tensors = 0;
+        unsigned long long blocks = 0;
+        double bytes = 0;
+        while (t0 < n_tensors && q.n_tensors < ADAM_MAX_TENSORS) {
+            const long long nt = n[t0];
+            const long long b = (nt + (is_complex[t0] ? 511 : 1023)) / (is_complex[t0] ? 512 : 1024);
+            if (blocks + (unsigned long long)b > 0x7fffffffULL) break;
+            if (nt > 0) {
+                const int k = q.n_tensors++;
+                q.t[k] = AdamTensor{p[t0], g[t0], m[t0], v[t0], nt};
+                q.first[k] = (unsigned)blocks;
+                if (is_complex[t0]) q.cplx_mask |= 1u << k;
+                blocks += (unsigned long long)b;
+                bytes += (is_complex[t0] ? 8.0 * 5 + 4.0 * 2 : 4.0 * 7) * (double)nt;
+            }
+            ++t0;
+        }
+        if (q.n_tensors == 0) {
+            if (t0 < n_tensors && blocks == 0) { set_error("adam: tensor %d is too large for one launch", t0); return -2; }
+            continue;
+        }
+        q.first[q.n_tensors] = (unsigned)blocks;
+        {
+            ProfScope prof("uno::adam_kernel", bytes, s);
+            hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("adam launch: %s", hipGetErrorString(e)); return -5; }
     }
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("adam launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
+                double eps, double wd, int step, hipStream_t s) {
+    return launch_adam_multi(1, &p, &g, &m, &v, &n, &is_complex, lr, beta1, beta2, eps, wd, step, s);
 }
 
 }  // namespace uno

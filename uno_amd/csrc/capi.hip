@@ -416,11 +416,16 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
         set_error("uno_adam_step_multi: bad arguments");
         return -1;
     }
-    for (int t = 0; t < n_tensors; ++t) {
-        const int rc = uno_adam_step(p[t], g[t], m[t], v[t], n[t], is_complex[t], lr, beta1, beta2, eps, weight_decay, step, stream);
-        if (rc) return rc;
+    if (step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) {
+        set_error("uno_adam_step_multi: bad arguments step=%d betas=(%g, %g)", step, beta1, beta2);
+        return -1;
     }
-    return 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        if (n[t] < 0) { set_error("uno_adam_step_multi: tensor %d has n=%lld", t, n[t]); return -1; }
+        if (n[t] > 0 && (!p[t] || !g[t] || !m[t] || !v[t])) { set_error("uno_adam_step_multi: null pointer (tensor %d)", t); return -1; }
+    }
+    // one launch per 24 tensors (csrc/adam.hip): the tensors' descriptors travel in the kernel arguments
+    return launch_adam_multi(n_tensors, p, g, m, v, n, is_complex, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
 static int gelu_project_forward_impl(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, void* stream) {

@@ -197,6 +197,8 @@ int launch_resample2d(const void* in, void* out, float* tmp, int n_img, int H, i
                       const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s);
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s);
+int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
+                      const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s);
 int launch_gelu_project_fwd(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, hipStream_t s);
