@@ -126,7 +126,10 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
     // mode counts beyond the compiled MFMA range (the reference's default modes, integral_operators.py:153-158): any-mode form
-    if (m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, s);
+#ifndef UNO_FORCE_VALU_DFT
+#define UNO_FORCE_VALU_DFT 0     // ablation build (tools/dev/mkvariant.py): every 2-D transform on the plain-FMA (VALU) kernels of dft_generic.hip
+#endif
+    if (UNO_FORCE_VALU_DFT || m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, s);
     // many small images (3-D planes, coarse 2-D levels): plane-batched kernels (dft2d_plane.hip)
     if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
         return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);
@@ -380,8 +383,8 @@ static int channel_wgrad_impl(const void* gy, const void* x, float* gw, float* g
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (!gw) { set_error("uno_channel_wgrad: null pointer"); return -1; }
     if (B == 0 || P == 0) {
-        hipMemsetAsync(gw, 0, sizeof(float) * Co * Ci, (hipStream_t)stream);
-        if (gb) hipMemsetAsync(gb, 0, sizeof(float) * Co, (hipStream_t)stream);
+        if (hipMemsetAsync(gw, 0, sizeof(float) * Co * Ci, (hipStream_t)stream) != hipSuccess ||
+            (gb && hipMemsetAsync(gb, 0, sizeof(float) * Co, (hipStream_t)stream) != hipSuccess)) { set_error("uno_channel_wgrad: memset failed"); return -5; }
         return 0;
     }
     if (!gy || !x || !ws) { set_error("uno_channel_wgrad: null pointer"); return -1; }
@@ -453,8 +456,8 @@ static int gelu_project_backward_impl(const void* pre, const float* w, const voi
     if (B < 0 || C < 1 || P < 0) { set_error("uno_gelu_project_backward: bad sizes B=%d C=%d P=%lld", B, C, P); return -1; }
     if (!gw) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
     if (B == 0 || P == 0) {
-        hipMemsetAsync(gw, 0, sizeof(float) * C, (hipStream_t)stream);
-        if (gb) hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream);
+        if (hipMemsetAsync(gw, 0, sizeof(float) * C, (hipStream_t)stream) != hipSuccess ||
+            (gb && hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream) != hipSuccess)) { set_error("uno_gelu_project_backward: memset failed"); return -5; }
         return 0;
     }
     if (!pre || !w || !gout || !gpre || !ws) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
