@@ -158,12 +158,12 @@ def _kernel_table(fn, n=5):
                 "GBps": v[2] / (v[1] * 1e-3) / 1e9} for k, v in agg.items()}
 
 
-def _traffic(names, launches=None):
-    """HBM bytes per call (PMC passes of the standalone blocks, profiles/block_traffic.json): sum over the call's kernels of
-    bytes per launch x launches per call, or None."""
+def _traffic(names, launches=None, block="c2"):
+    """HBM bytes per call (PMC passes of the standalone blocks, profiles/block_traffic.json, one table per block): sum over the
+    call's kernels of bytes per launch x launches per call, or None."""
     tfile = os.path.join(ROOT, "profiles", "block_traffic.json")     # standalone C2 / C4 block runs (tools/profile_round.sh)
     try:
-        table = json.load(open(tfile))
+        table = json.load(open(tfile))[block]
         vals = [table[n]["bytes_per_launch"] * (launches[n] if launches else 1.0) for n in names]
         return float(sum(vals))
     except Exception:
@@ -219,7 +219,9 @@ def spectral_block3d_roofline(dev):
     return {"config": f"SpectralConv3d({C},{C},{H},{W},{T},{m1},{m2},{m3}) batch {B} f32",
             "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_bytes": fwd_b, "bwd_bytes": bwd_b,
             "fwd_frac_of_8TBs": fwd_b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBs": bwd_b / tb / 1e9 / HBM_PEAK_GBS,
-            "fwd_kernels": _kernel_table(fwd), "bwd_kernels": _kernel_table(bwd)}
+            "fwd_kernels": (kf := _kernel_table(fwd)), "bwd_kernels": (kb := _kernel_table(bwd)),
+            "fwd_traffic": _traffic(list(kf), {k: v["launches_per_call"] for k, v in kf.items()}, block="c4"),
+            "bwd_traffic": _traffic(list(kb), {k: v["launches_per_call"] for k, v in kb.items()}, block="c4")}
 
 
 # ----------------------------------------------------------------------------------------------- secondary workloads

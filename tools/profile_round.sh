@@ -21,8 +21,7 @@ for w in c2 c4; do
   done
   python tools/pmc_summary.py $out/pmc_$w > profiles/${tag}_block${n}_pmc.txt
 done
-mkdir -p $out/pmc_blocks; cp -r $out/pmc_c2/p4 $out/pmc_blocks/c2p4; cp -r $out/pmc_c2/p5 $out/pmc_blocks/c2p5; cp -r $out/pmc_c4/p4 $out/pmc_blocks/c4p4; cp -r $out/pmc_c4/p5 $out/pmc_blocks/c4p5
-python tools/traffic_json.py $out/pmc_blocks profiles/block_traffic.json profiles/${tag}_block_traffic.txt > /dev/null
+bash tools/block_traffic.sh $out $tag
 # the training step
 bash tools/pmc_traffic.sh $out/pmc_bench
 python tools/traffic_json.py $out/pmc_bench profiles/hbm_traffic.json profiles/${tag}_bench_pmc_traffic.txt > /dev/null

@@ -529,7 +529,7 @@ static int launch_fwd_volume_t(const Vol3dParams& p, const VolShape& g, hipStrea
     if (!ensure_dynamic_lds(k, g.lds, lds_slot)) { set_error("dft3d_fwd_volume: cannot raise the dynamic LDS limit to %zu", g.lds); return -5; }
     {
         char name[64];
-        snprintf(name, sizeof(name), "uno::dft3d_fwd_volume_kernel<%d, %d, %d>", MT2, NBW, (int)NARROW);
+        snprintf(name, sizeof(name), "uno::dft3d_fwd_volume_kernel<%d, %d, %s>", MT2, NBW, NARROW ? "true" : "false");
         ProfScope prof(name, (double)p.n_vol * ((double)p.D1 * p.D2 * p.D3 * 4.0 + 8.0 * p.m1 * p.m2 * p.m3 * 4.0), s);
         hipLaunchKernelGGL((dft3d_fwd_volume_kernel<MT2, NBW, NARROW>), dim3(p.n_vol), dim3(64 * VOL_WAVES), g.lds, s, p, g);
     }

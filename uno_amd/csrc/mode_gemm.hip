@@ -19,6 +19,7 @@
 // while the current one is multiplied.
 #include "uno_common.h"
 #include <algorithm>
+#include <cstdio>
 
 namespace uno {
 
@@ -405,7 +406,7 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
     {
         // each operand counted once: A (M x K), B (K x N), out (M x N) complex64 per mode
         const double per_mode = 8.0 * ((double)p.M * p.K + (double)p.M * p.N) + (p.B.half ? 4.0 : 8.0) * (double)p.K * p.N;
-        ProfScope prof("uno::mode_gemm_kernel", per_mode * p.ncorner * p.Mc, s);
+        const double k2_bytes = per_mode * p.ncorner * p.Mc;
         // The 4x4x1 form works on whole groups of 16 modes: layers whose last group is mostly padding (2 x 36 modes = 3 groups per
         // corner, a quarter of the third one used) stay on the LDS-staged form with its 8-mode variant; so do weight gradients
         // with very large outputs (measured, tools/k2bench.py: 256 -> 512 channels x 4 x 216 modes, 906 MB: 263 against 332 us).
@@ -422,6 +423,9 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
             const int tm = wide_m ? 16 : 8, tn = wide_m ? 8 : 16;
             const long long tasks = (long long)p.ncorner * groups * ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn);
             const int KS = square ? 1 : (tasks < 1024 && p.K >= 32) ? 4 : (tasks < 2048 && p.K >= 16) ? 2 : 1;
+            char name[64];
+            snprintf(name, sizeof(name), "uno::mode_gemm_blocks_kernel<%s, %s>", square ? "4, 4, 2" : wide_m ? "4, 2, 4" : "2, 4, 4", p.B.half ? "true" : "false");
+            ProfScope prof(name, k2_bytes, s);
             if (square) launch_blocks_t<4, 4, 2>(p, KS, s);
             else if (wide_m) launch_blocks_t<4, 2, 4>(p, KS, s);
             else launch_blocks_t<2, 4, 4>(p, KS, s);
@@ -432,6 +436,9 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         // pipelined K loop: measured better with few mode chunks per layer (2 x 36 / 2 x 64 modes: 26 -> 22, 34 -> 29 us) and
         // worse with many (2 x 196 / 2 x 324 modes: 41 -> 50, 58 -> 67 us)
         const bool pipe = narrow && p.ncorner * nq <= 32;
+        char name[64];
+        snprintf(name, sizeof(name), "uno::mode_gemm_kernel<%d, %s, %s>", qc, pipe ? "true" : "false", p.B.half ? "true" : "false");
+        ProfScope prof(name, k2_bytes, s);
         if (p.B.half) {
             if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, true>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
             else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false, true>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
