@@ -106,6 +106,58 @@ def test_seeded_3d_vs_dense_oracle(cfg):
     assert rel_err(xt.cpu().numpy(), corner_major(X, modes[0], modes[1])) < TOL
 
 
+def _random_volume_cases(n, seed):
+    """Seeded random geometries inside the range of the per-volume kernels (>= 192 volumes on both sides, no corner overlap,
+    2 m3 <= 16, axis lengths <= 40 / 40 / 32): odd and even lengths, all tile-count combinations, resampling in every axis."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        din = (int(rng.integers(4, 41)), int(rng.integers(4, 41)), int(rng.integers(5, 33)))       # T >= 5: one 16-byte piece per row
+        dout = tuple(int(max(lo, min(hi, d + rng.integers(-6, 7)))) for d, lo, hi in zip(din, (4, 4, 5), (40, 40, 32)))
+        m1 = int(rng.integers(1, min(din[0], dout[0]) // 2 + 1))
+        m2 = int(rng.integers(1, min(din[1], dout[1]) // 2 + 1))
+        m3 = int(rng.integers(1, min(8, min(din[2], dout[2]) // 2 + 1) + 1))
+        C = int(rng.choice([192, 200, 256]))
+        out.append((1, C, C, din, dout, (m1, m2, m3)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _random_volume_cases(10, 2026), ids=lambda c: "x".join(map(str, c[3])) + "-" + "x".join(map(str, c[4])) + "-m" + "x".join(map(str, c[5])))
+def test_volume_kernels_random_geometry(cfg):
+    """K1v / K3v (one workgroup per volume) on random geometries against the dense float64 oracle: forward, the saved truncated
+    spectrum, the input gradient (weights of few channels would make the einsum the expensive part: Ci = Co >= 192 only to reach
+    the kernels' volume count, so the weights are block-diagonal copies of a 4-channel layer)."""
+    from uno_amd import _native
+    B, Ci, Co, din, dout, modes = cfg
+    rng = np.random.default_rng(sum(din) * 131 + sum(dout) * 17 + sum(modes))
+    x = rng.standard_normal((B, Ci, *din)).astype(np.float32)
+    gy = rng.standard_normal((B, Co, *dout)).astype(np.float32)
+    g = 4
+    small = [((1 / (2 * g)) ** 0.5 * (rng.standard_normal((g, g, *modes)) + 1j * rng.standard_normal((g, g, *modes)))).astype(np.complex64)
+             for _ in range(4)]
+    ws = []
+    for w in small:                                            # block-diagonal (Ci, Co) weights
+        full = np.zeros((Ci, Co, *modes), np.complex64)
+        for k in range(Ci // g):
+            full[k * g:(k + 1) * g, k * g:(k + 1) * g] = w
+        ws.append(full)
+    _native.profile_begin(64)
+    y, xt = _native.spectral_conv3d_forward(cu(x), [cu(w) for w in ws], *dout)
+    gx, gws = _native.spectral_conv3d_backward(cu(gy), xt, [cu(w) for w in ws], *din)
+    torch.cuda.synchronize()
+    ran = [name for name, _, _ in _native.profile_end()]
+    assert sum("dft3d_fwd_volume_kernel" in n for n in ran) == 2 and sum("dft3d_inv_volume_kernel" in n for n in ran) == 2, ran
+    y, gx, xt = y.cpu().numpy(), gx.cpu().numpy(), xt.cpu().numpy()
+    for k in range(0, Ci // g, max(1, Ci // g // 3)):          # a few channel groups through the dense oracle
+        sl = slice(k * g, (k + 1) * g)
+        y_ref, X = so.spectral_conv3d_dense(x[:, sl], small, *dout)
+        gx_ref, _, _, _ = so.spectral_conv3d_dense_bwd(gy[:, sl], X, small, *din)
+        assert rel_err(y[:, sl], y_ref) < TOL, (k, "y")
+        assert rel_err(gx[:, sl], gx_ref) < TOL, (k, "gx")
+        assert rel_err(xt[:, sl], corner_major(X, modes[0], modes[1])) < TOL, (k, "xt")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", [n for n in NAMESB if n.startswith("b3d_")])
 def test_operator_block_3d_golden(name):
