@@ -104,40 +104,6 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_fwd_volume_kernel(Vol3dP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = 64 * VOL_WAVES;
 
-    // ---- tables
-    for (int e = tid; e < g.KA * 64; e += nthreads) {
-        const int ln = e & 63, ks = e >> 6, gg = ln >> 4, n = ln & 15, l = n >> 1;
-        const int w = ks < 4 * NBW ? 16 * (ks >> 2) + 4 * gg + (ks & 3) : 16 * NBW + gg;
-        float v = 0.f;
-        if (l < m3 && w < D3) {
-            const float2 t = p.tw3[(unsigned)(l * w) % (unsigned)D3];
-            v = ((n & 1) ? -t.y : t.x) * p.scale * (p.herm ? herm_weight(l, D3) : 1.0f);
-        }
-        sTwA[e] = v;
-    }
-    for (int e = tid; e < g.U * 4 * MT2 * 64; e += nthreads) {
-        const int ln = e & 63, mt = (e >> 6) % MT2, ur = (e >> 6) / MT2;
-        const int mk = 16 * mt + 4 * (ln & 3) + ((ln & 15) >> 2);         // kappa index of A-operand row ln & 15: accumulator row 4 g + r <-> 4 r + g
-        const int i = 16 * (ur >> 2) + 4 * (ln >> 4) + (ur & 3);            // slot of k-index g in k-step (u, r)
-        float2 v = make_float2(0.f, 0.f);
-        if (mk < m2 && i < g.nslot2) {
-            v = p.tw2[(unsigned)((2 * mk + 1) * i) % (unsigned)(2 * D2)];
-            if (i == 0) v.y = (D2 & 1) ? 0.f : ((mk & 1) ? -1.f : 1.f);
-        }
-        sTwB[e] = v;
-    }
-    for (int e = tid; e < g.U * 16; e += nthreads) sTwist2[e] = p.tw2[min(e, 2 * D2 - 1)];
-    for (int e = tid; e < g.nks1 * g.MT1 * 64; e += nthreads) {
-        const int ln = e & 63, mt = (e >> 6) % g.MT1, ks = (e >> 6) / g.MT1;
-        const int mk = 16 * mt + (ln & 15), i = 4 * ks + (ln >> 4);
-        float2 v = make_float2(0.f, 0.f);
-        if (mk < m1 && i < g.nslot1) {
-            v = p.tw1[(unsigned)((2 * mk + 1) * i) % (unsigned)(2 * D1)];
-            if (i == 0) v.y = (D1 & 1) ? 0.f : ((mk & 1) ? -1.f : 1.f);
-        }
-        sTw1[e] = v;
-    }
-
     // ---- phase 1: planes -> paired, twisted per-plane spectra in LDS
     const int vol = blockIdx.x;
     const size_t vol_elems = (size_t)D1 * D2 * D3;
@@ -185,8 +151,43 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_fwd_volume_kernel(Vol3dP
         if (!second) return slot;
         return slot == 0 ? D1 / 2 : D1 - slot;                              // (odd D1, slot 0: plane D1 / 2 is loaded and ignored)
     };
-    if (n_units > 0) issue(unit_plane(0), 0);
-    __syncthreads();                                                          // tables
+    if (n_units > 0) issue(unit_plane(0), 0);            // the first rows are on their way while the tables are built
+
+    // ---- tables
+    for (int e = tid; e < g.KA * 64; e += nthreads) {
+        const int ln = e & 63, ks = e >> 6, gg = ln >> 4, n = ln & 15, l = n >> 1;
+        const int w = ks < 4 * NBW ? 16 * (ks >> 2) + 4 * gg + (ks & 3) : 16 * NBW + gg;
+        float v = 0.f;
+        if (l < m3 && w < D3) {
+            const float2 t = p.tw3[(unsigned)(l * w) % (unsigned)D3];
+            v = ((n & 1) ? -t.y : t.x) * p.scale * (p.herm ? herm_weight(l, D3) : 1.0f);
+        }
+        sTwA[e] = v;
+    }
+    for (int e = tid; e < g.U * 4 * MT2 * 64; e += nthreads) {
+        const int ln = e & 63, mt = (e >> 6) % MT2, ur = (e >> 6) / MT2;
+        const int mk = 16 * mt + 4 * (ln & 3) + ((ln & 15) >> 2);         // kappa index of A-operand row ln & 15: accumulator row 4 g + r <-> 4 r + g
+        const int i = 16 * (ur >> 2) + 4 * (ln >> 4) + (ur & 3);            // slot of k-index g in k-step (u, r)
+        float2 v = make_float2(0.f, 0.f);
+        if (mk < m2 && i < g.nslot2) {
+            v = p.tw2[(unsigned)((2 * mk + 1) * i) % (unsigned)(2 * D2)];
+            if (i == 0) v.y = (D2 & 1) ? 0.f : ((mk & 1) ? -1.f : 1.f);
+        }
+        sTwB[e] = v;
+    }
+    for (int e = tid; e < g.U * 16; e += nthreads) sTwist2[e] = p.tw2[min(e, 2 * D2 - 1)];
+    for (int e = tid; e < g.nks1 * g.MT1 * 64; e += nthreads) {
+        const int ln = e & 63, mt = (e >> 6) % g.MT1, ks = (e >> 6) / g.MT1;
+        const int mk = 16 * mt + (ln & 15), i = 4 * ks + (ln >> 4);
+        float2 v = make_float2(0.f, 0.f);
+        if (mk < m1 && i < g.nslot1) {
+            v = p.tw1[(unsigned)((2 * mk + 1) * i) % (unsigned)(2 * D1)];
+            if (i == 0) v.y = (D1 & 1) ? 0.f : ((mk & 1) ? -1.f : 1.f);
+        }
+        sTw1[e] = v;
+    }
+
+    __syncthreads();
 
     f32x4 Xa_p[MT2], Xa_m[MT2];                                               // spectrum of the slot's first plane
     f32x4 C[MT2], S[MT2];
