@@ -74,23 +74,89 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const TI* __restrict
 //   phase 2 (columns): banded column operator from LDS, TR x Wo outputs written unit-stride.
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
+#ifndef UNO_K7_EXP
+#define UNO_K7_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = phase 1 only, 2 = phase 2 only
+#endif
 
-template <bool ACCUM, int KT, typename T>      // KT: compiled tap count of the column operator (>= KW; weights past KW are zero)
+// MF: phase 1 on v_mfma_f32_16x16x4_f32.  The dense 16 x NP row operator of the tile is the A operand (one LDS read per k-step
+// from a table in operand layout), a lane's 16-byte piece of an input row is the B operand of FOUR column tiles (tile e = columns 4 n + e of the
+// wave's 64 columns): one load instruction (4 rows x 256 contiguous bytes) feeds four MFMAs.  The VALU form spent 16 v_fmac and
+// four LDS broadcast reads of the weights per loaded element - rocprofv3 on 446^2 -> 334^2: LDS 61 % busy, most of it those reads.
+template <bool ACCUM, int KT, typename T, bool MF>      // KT: compiled tap count of the column operator (>= KW; weights past KW are zero)
 __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
-                                                             int H, int W, int Ho, int Wo) {
-    extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][W] then the tile's dense weights [NP][16]
-    const int n = blockIdx.y;
-    const int tile = blockIdx.x;
+                                                             int H, int W, int Ho, int Wo, int n_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][WP] then (VALU form) the tile's dense weights [NP][16]
+    // Workgroups go to the 8 XCDs round-robin by linear index: all row tiles of an image on ONE XCD, next to each other in time, so
+    // that the band of input rows two neighbouring tiles share (NP - 16 H / Ho rows: 27 against 21.3 at 446 -> 334) comes out of
+    // that XCD's L2 instead of over the fabric twice (FETCH_SIZE was 1.66x the image)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int n = (slot / ntiles) * 8 + xcd;
+    const int tile = slot % ntiles;
+    if (n >= n_img) return;
     const int i0 = tile * RS_TR;
     const int tid = threadIdx.x;
     const int p0 = tile_p0[tile];
-    float* sWd = V + RS_TR * ((W + 3) & ~3);
+    const int WP = (W + 3) & ~3;                                       // row pitch of V: 16-byte aligned rows
+    float* sWd = V + RS_TR * WP;
     const int nthreads = blockDim.x;
+    const T* src = in + (size_t)n * H * W;
+    if constexpr (MF) {
+        const int lane = tid & 63, n16 = lane & 15, kk = lane >> 4;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
+        const int nks = (NP + 3) >> 2;
+        // the row operator in A-operand layout: [k-step][lane (out row n16, k-slot kk)]
+        for (int e = tid; e < nks * 64; e += nthreads) {
+            const int u = 4 * (e >> 6) + ((e & 63) >> 4);
+            sWd[e] = u < NP ? tile_w[((size_t)tile * NP + u) * RS_TR + (e & 15)] : 0.f;
+        }
+        __syncthreads();
+        for (int c0 = 64 * wave; c0 < (UNO_K7_EXP == 2 ? 0 : W); c0 += 64 * nwaves) {
+            // this lane's four columns; pieces past the row end are pulled back inside the row (their results are not stored)
+            const int col = min(c0 + 4 * n16, max(W - 4, 0));
+            const T* colp = src + col;
+            f32x4 acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = f32x4{0, 0, 0, 0};
+            auto fetch = [&](int ks) { return io_ld4(colp + (size_t)min(p0 + 4 * ks + kk, H - 1) * W); };     // rows past the tile meet zero weights
+            float4 x0 = fetch(0), x1 = fetch(min(1, nks - 1)), x2 = fetch(min(2, nks - 1));
+            for (int ks = 0; ks < nks; ++ks) {
+                const float a = sWd[ks * 64 + lane];
+                const float4 x = x0;
+                x0 = x1; x1 = x2;
+                x2 = fetch(min(ks + 3, nks - 1));                                  // unconditional: the waits stay partial
+                acc[0] = mfma16(a, x.x, acc[0]);
+                acc[1] = mfma16(a, x.y, acc[1]);
+                acc[2] = mfma16(a, x.z, acc[2]);
+                acc[3] = mfma16(a, x.w, acc[3]);
+            }
+            // accumulator register r of lane (g = kk, n16) of tile e: output row 4 g + r, column col + e
+            if (c0 + 4 * n16 == col) {
+                if (W >= 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<f32x4*>(V + (4 * kk + r) * WP + col) = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < W) V[(4 * kk + r) * WP + col + e] = acc[e][r];
+                }
+            } else if (c0 + 4 * n16 < W) {
+                // the row's last, shifted piece: columns c0 + 4 n16 .. W - 1 are its elements (c0 + 4 n16 - col) ..
+                const int sh = c0 + 4 * n16 - col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e >= sh) V[(4 * kk + r) * WP + col + e] = acc[e][r];
+            }
+        }
+    } else {
     for (int e = tid; e < NP * RS_TR; e += nthreads) sWd[e] = tile_w[(size_t)tile * NP * RS_TR + e];   // [NP][16], zero outside the band
     __syncthreads();
-    const T* src = in + (size_t)n * H * W;
     for (int q = tid; q < W; q += nthreads) {
         float acc[RS_TR];
 #pragma unroll
@@ -127,9 +193,11 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
             fma4(u + 4, xb);
         }
 #pragma unroll
-        for (int r = 0; r < RS_TR; ++r) V[r * W + q] = acc[r];
+        for (int r = 0; r < RS_TR; ++r) V[r * WP + q] = acc[r];
+    }
     }
     __syncthreads();
+    if (UNO_K7_EXP == 1) return;
     T* dst = out + ((size_t)n * Ho + i0) * Wo;
     const int nr = min(RS_TR, Ho - i0);
     // phase 2: thread -> (row group g, column j): when the workgroup is wider than a row, groups take rows round-robin
@@ -150,7 +218,7 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
                 w[t] = t < KW ? wv : 0.f;
             }
             for (int r = g; r < nr; r += G) {
-                const float* v = V + r * W;
+                const float* v = V + r * WP;
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
@@ -174,18 +242,27 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
     if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
     if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
-        const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)NP * RS_TR * sizeof(float);
+        const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float);
         ProfScope prof("uno::resample_fused_kernel", es * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
         // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
         const int sweeps = (W + 511) / 512;
         const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
-        const dim3 grid((Ho + RS_TR - 1) / RS_TR, n_img);
+        const int ntiles = (Ho + RS_TR - 1) / RS_TR;
+        const dim3 grid((unsigned)(((n_img + 7) / 8) * 8) * ntiles);
+#ifndef UNO_K7_MFMA
+#define UNO_K7_MFMA 1
+#endif
+        const bool mf = UNO_K7_MFMA && W >= 4;
 #define UNO_RS_LAUNCH(A, K)                                                                                                    \
         do {                                                                                                                   \
-            if (bf16) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \
-                                         startW, wtW, KW, H, W, Ho, Wo);                                                       \
-            else hipLaunchKernelGGL((resample_fused_kernel<A, K, float>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
-                                    startW, wtW, KW, H, W, Ho, Wo);                                                            \
+            if (bf16 && mf) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t, true>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \
+                                         startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                        \
+            else if (bf16) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t, false>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \
+                                         startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                        \
+            else if (mf) hipLaunchKernelGGL((resample_fused_kernel<A, K, float, true>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
+                                    startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                             \
+            else hipLaunchKernelGGL((resample_fused_kernel<A, K, float, false>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
+                                    startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                             \
         } while (0)
         // tap counts seen in the U-NO models: 4-5 (up-sampling by ~2 and its adjoint's rows), 9-10 (down-sampling by ~2)
 #define UNO_RS_PICK(A)                                                                                                         \
