@@ -11,6 +11,7 @@
 // Memory-bound stencil, two passes (rows then columns, or columns then rows - whichever makes the
 // intermediate smaller); every load and store is unit-stride along the image row.
 #include "uno_common.h"
+#include <algorithm>
 #include <cstdio>
 
 namespace uno {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const TI* __restrict
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
 #ifndef UNO_K7_EXP
-#define UNO_K7_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = phase 1 only, 2 = phase 2 only
+#define UNO_K7_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = phase 1 only, 2 = phase 2 only, 3 = phase 2 without stores, 4 = phase 2 without LDS reads
 #endif
 
 // MF: phase 1 on v_mfma_f32_16x16x4_f32.  The dense 16 x NP row operator of the tile is the A operand (one LDS read per k-step
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
             sWd[e] = u < NP ? tile_w[((size_t)tile * NP + u) * RS_TR + (e & 15)] : 0.f;
         }
         __syncthreads();
-        for (int c0 = 64 * wave; c0 < (UNO_K7_EXP == 2 ? 0 : W); c0 += 64 * nwaves) {
+        for (int c0 = 64 * wave; c0 < ((UNO_K7_EXP >= 2) ? 0 : W); c0 += 64 * nwaves) {
             // this lane's four columns; pieces past the row end are pulled back inside the row (their results are not stored)
             const int col = min(c0 + 4 * n16, max(W - 4, 0));
             const T* colp = src + col;
@@ -221,10 +222,11 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
                 const float* v = V + r * WP;
                 float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
+                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], (UNO_K7_EXP == 4) ? (float)t : v[min(s + t, W - 1)], acc);
                 // ACCUM is a template parameter: a run-time flag here put a conditional load into the store loop and
                 // cost the plain path 60 % (227 -> 362 us at 1024 x 446^2 -> 223^2)
-                io_store1(dst + (size_t)r * Wo + j, ACCUM ? io_widen(dst[(size_t)r * Wo + j]) + acc : acc);
+                if (UNO_K7_EXP == 3) { if (acc == 123.456f) io_store1(dst + (size_t)r * Wo + j, acc); }
+                else io_store1(dst + (size_t)r * Wo + j, ACCUM ? io_widen(dst[(size_t)r * Wo + j]) + acc : acc);
             }
         }
     }
