@@ -107,7 +107,7 @@ def test_seeded_3d_vs_dense_oracle(cfg):
 
 
 def _random_volume_cases(n, seed):
-    """Seeded random geometries inside the range of the per-volume kernels (>= 192 volumes on both sides, no corner overlap,
+    """Seeded random geometries inside the range of the per-volume kernels (>= 48 volumes on both sides (these cases have >= 192), no corner overlap,
     2 m3 <= 16, axis lengths <= 40 / 40 / 32): odd and even lengths, all tile-count combinations, resampling in every axis."""
     rng = np.random.default_rng(seed)
     out = []

@@ -33,7 +33,7 @@ constexpr int VOL_WAVES = 16;
 #endif
 constexpr size_t VOL_LDS_LIMIT = 160 * 1024;
 #ifndef UNO_VOL_MIN_VOLUMES
-#define UNO_VOL_MIN_VOLUMES 192  // one workgroup per volume: fewer volumes than CUs leave the chip idle
+#define UNO_VOL_MIN_VOLUMES 48   // one workgroup per volume; measured (tools/dev/vol3dtime.py, widths 8 and 16): still ahead of the plane path at 64 volumes
 #endif
 
 __device__ __forceinline__ float vol_xor1(float v) {       // the value held by lane ^ 1 (DPP quad_perm [1,0,3,2])
