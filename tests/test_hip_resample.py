@@ -8,7 +8,7 @@ from conftest import rel_err
 
 SIZES = [((20, 18), (12, 10)), ((12, 10), (21, 19)), ((90, 90), (45, 45)), ((45, 45), (22, 22)), ((22, 22), (45, 45)),
          ((45, 45), (90, 90)), ((37, 50), (29, 31)), ((223, 223), (111, 111)), ((111, 111), (223, 223)), ((16, 16), (16, 16)),
-         ((9, 300), (4, 301)), ((446, 446), (223, 223))]
+         ((9, 300), (4, 301)), ((446, 446), (223, 223)), ((7, 3), (5, 2)), ((5, 2), (9, 3)), ((33, 5), (20, 7))]
 
 
 def test_band_tables_reconstruct_the_operator():
