@@ -19,6 +19,7 @@ SHAPES = [
     (4, 100, 36, 4097),
     (1, 128, 1, 777),             # final projection
     (5, 20, 70, 33),
+    (3, 1, 5, 1030), (2, 2, 16, 2048), (2, 4, 33, 4099), (2, 3, 17, 1025),     # few input channels: the streaming forms of K8 / K9
 ]
 
 

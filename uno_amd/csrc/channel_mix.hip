@@ -401,6 +401,51 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     }
 }
 
+// Few input channels (the lift's first layer: 3 -> 32 at full resolution).  The tiled kernel stages 16-channel chunks - 13 of 16
+// rows of every chunk would be zero fill: 148 us against 79 us for the layer's bytes.  Here a thread owns four pixels, keeps its CI
+// input values in registers and walks over the output channels with wave-uniform (scalar) weights: pure streaming, 1 KB of every
+// output row per wave instruction.
+template <int CI, bool BF>
+__global__ __launch_bounds__(256) void channel_mix_few_in_kernel(ChannelMixParams p) {
+    using T = typename IoElem<BF>::type;
+    const int b = blockIdx.y;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int px = (int)(4 * q);
+    if (px >= p.P) return;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * CI * p.P;
+    T* yb = reinterpret_cast<T*>(p.y) + (size_t)b * p.Co * p.P;
+    const bool full = px + 3 < p.P;
+    float xv[CI][4];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+        if (full) {
+            const float4 v = io_ld4(xb + (size_t)i * p.P + px);
+            xv[i][0] = v.x; xv[i][1] = v.y; xv[i][2] = v.z; xv[i][3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[i][e] = px + e < p.P ? io_widen(xb[(size_t)i * p.P + px + e]) : 0.f;
+        }
+    }
+    for (int o = 0; o < p.Co; ++o) {
+        const float bv = p.bias ? p.bias[o] : 0.f;
+        float r[4] = {bv, bv, bv, bv};
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const float wv = p.w[o * p.w_so + i * p.w_si];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaf(wv, xv[i][e], r[e]);
+        }
+        T* yrow = yb + (size_t)o * p.P + px;
+        if (full) {
+            io_store4(yrow, r[0], r[1], r[2], r[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (px + e < p.P) io_store1(yrow + e, r[e]);
+        }
+    }
+}
+
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s) {
     ChannelMixParams p;
@@ -419,6 +464,17 @@ int launch_channel_mix(const void* x, const float* w, const float* bias, void* y
         return -2;
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
+    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024) {
+        ProfScope prof("uno::channel_mix_few_in_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
+        const dim3 grid((unsigned)((P + 1023) / 1024), B);
+#define UNO_CMF(C) do { if (bf16) hipLaunchKernelGGL((channel_mix_few_in_kernel<C, true>), grid, dim3(256), 0, s, p); \
+                        else hipLaunchKernelGGL((channel_mix_few_in_kernel<C, false>), grid, dim3(256), 0, s, p); } while (0)
+        if (Ci == 1) UNO_CMF(1); else if (Ci == 2) UNO_CMF(2); else if (Ci == 3) UNO_CMF(3); else UNO_CMF(4);
+#undef UNO_CMF
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("channel_mix launch: %s", hipGetErrorString(e)); return -5; }
+        return 0;
+    }
     {
         ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + (dgelu_of ? Co : 0)) + 4.0 * Ci * Co, s);
@@ -657,6 +713,67 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     }
 }
 
+// Weight gradient with few input channels (CI <= 4): a thread owns four pixels at a time and accumulates its 16 output channels x
+// (CI + 1) sums in registers over the pixels of its split (the + 1: the bias gradient); fixed-order reduction inside the workgroup
+// (butterfly within a wave, the four waves through LDS in order), then the usual partials (split, Co, Ci + 1) for the reduce kernel.
+template <int CI, bool BF>
+__global__ __launch_bounds__(256) void channel_wgrad_few_in_kernel(ChannelWgradParams p, long long quads_per_split) {
+    using T = typename IoElem<BF>::type;
+    __shared__ float sred[4][16 * (CI + 1)];
+    const int split = blockIdx.x, o0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long qrow = ((long long)p.P + 3) >> 2;                   // pixel quads per (batch entry, channel) row
+    const long long qa = (long long)split * quads_per_split, qb = min(qa + quads_per_split, (long long)p.B * qrow);
+    float acc[16][CI + 1];
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int i = 0; i <= CI; ++i) acc[o][i] = 0.f;
+    for (long long q = qa + tid; q < qb; q += 256) {
+        const int b = (int)(q / qrow), px = (int)(4 * (q - (long long)b * qrow));
+        const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * CI * p.P + px;
+        const T* gb = reinterpret_cast<const T*>(p.gy) + ((size_t)b * p.Co + o0) * p.P + px;
+        const bool full = px + 3 < p.P;
+        float xv[CI][4];
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            if (full) { const float4 v = io_ld4(xb + (size_t)i * p.P); xv[i][0] = v.x; xv[i][1] = v.y; xv[i][2] = v.z; xv[i][3] = v.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[i][e] = px + e < p.P ? io_widen(xb[(size_t)i * p.P + e]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (o0 + o < p.Co) {
+                if (full) { const float4 v = io_ld4(gb + (size_t)o * p.P); gv[0] = v.x; gv[1] = v.y; gv[2] = v.z; gv[3] = v.w; }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gv[e] = px + e < p.P ? io_widen(gb[(size_t)o * p.P + e]) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CI; ++i) acc[o][i] += (gv[0] * xv[i][0] + gv[1] * xv[i][1]) + (gv[2] * xv[i][2] + gv[3] * xv[i][3]);
+            acc[o][CI] += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int i = 0; i <= CI; ++i) {
+            float v = acc[o][i];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (lane == 0) sred[wave][o * (CI + 1) + i] = v;
+        }
+    __syncthreads();
+    if (tid < 16 * (CI + 1)) {
+        const int o = tid / (CI + 1), i = tid % (CI + 1);
+        const float v = ((sred[0][tid] + sred[1][tid]) + sred[2][tid]) + sred[3][tid];
+        if (o0 + o < p.Co) p.part[((size_t)split * p.Co + o0 + o) * (CI + 1) + i] = v;
+    }
+}
+
 // fixed-order sum of the split-K partials (deterministic): gw (Co, Ci), gb (Co).  32 consecutive elements x 8
 // interleaved groups of splits per workgroup, the 8 group sums combined in order through LDS.
 __global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* part, float* gw, float* gb, int Co, int Ci, int nsplit) {
@@ -722,6 +839,22 @@ int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, fl
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     p.span = (long long)cps * pk;
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
+    if (Ci <= 4 && !act_x && P >= 1024) {
+        const long long quads = (long long)B * ((P + 3) / 4), qps = (quads + p.nsplit - 1) / p.nsplit;
+        {
+            ProfScope prof("uno::channel_wgrad_few_in_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
+            const dim3 grid((unsigned)p.nsplit, (unsigned)((Co + 15) / 16));
+#define UNO_CWF(C) do { if (bf16) hipLaunchKernelGGL((channel_wgrad_few_in_kernel<C, true>), grid, dim3(256), 0, s, p, qps); \
+                        else hipLaunchKernelGGL((channel_wgrad_few_in_kernel<C, false>), grid, dim3(256), 0, s, p, qps); } while (0)
+            if (Ci == 1) UNO_CWF(1); else if (Ci == 2) UNO_CWF(2); else if (Ci == 3) UNO_CWF(3); else UNO_CWF(4);
+#undef UNO_CWF
+        }
+        const int nf = Co * (Ci + 1);
+        hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((nf + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
+        return 0;
+    }
     {
         ProfScope prof(pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
         const dim3 gv(8 * tiles * ((p.nsplit + 7) / 8));
