@@ -110,6 +110,8 @@ MIX_SHAPES = [
     # rows / columns / reduction lengths, its K split (few tasks, long K), the 16 x 16-per-wave weight-gradient form (K = B <= 32)
     (5, 7, 9, 2, (9, 11)), (17, 20, 33, 2, (7, 9)), (3, 130, 100, 4, (6, 5, 3)), (8, 32, 64, 4, (6, 6, 5)), (32, 48, 96, 2, (14, 14)),
     (9, 70, 18, 2, (10, 11)), (2, 64, 8, 2, (16, 16)),
+    # odd channel counts >= 96 on few modes (found by the random-shape test: the 8-mode variant's tail load assumed even K)
+    (17, 115, 45, 2, (3, 4)), (4, 97, 40, 2, (3, 6)), (3, 40, 101, 2, (2, 5)),
 ]
 
 
@@ -132,6 +134,23 @@ def test_mode_gemms(shape):
         assert rel_err(O[:, :, c], np.einsum("bi...,io...->bo...", X64[:, :, c], w64)) < TOL
         assert rel_err(gX[:, :, c], np.einsum("bo...,io...->bi...", gO64[:, :, c], np.conj(w64))) < TOL
         assert rel_err(gW[c], np.einsum("bi...,bo...->io...", np.conj(X64[:, :, c]), gO64[:, :, c])) < TOL
+
+
+def _random_mix_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nc = int(rng.choice([2, 4]))
+        mshape = tuple(int(v) for v in rng.integers(1, 13, size=2 if nc == 2 else 3))
+        out.append((int(rng.integers(1, 34)), int(rng.integers(1, 140)), int(rng.integers(1, 140)), nc, mshape))
+    return out
+
+
+@pytest.mark.parametrize("shape", _random_mix_shapes(24, 777), ids=lambda s: f"B{s[0]}-{s[1]}x{s[2]}-c{s[3]}-m" + "x".join(map(str, s[4])))
+def test_mode_gemms_random_shapes(shape):
+    """K2 in all three roles on seeded random (batch, channels, mode-count) combinations: both kernel families (4x4x1 blocks and
+    the LDS-staged form for badly padded mode counts), every tile configuration and K split."""
+    test_mode_gemms(shape)
 
 
 # ------------------------------------------------------------------ full operator vs golden vectors

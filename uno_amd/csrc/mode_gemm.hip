@@ -399,7 +399,9 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
     const int tiles = ((p.N + 15) / 16) * ((p.M + 15) / 16);
     // under two workgroups per CU and a long K loop: halve the mode chunk (measured, tools/k2bench.py: 256 -> 256 channels x 2 x 64
     // modes 53 -> 36 us, 192 -> 192 x 2 x 36 modes 42 -> 28 us; with K <= 64 the 64-byte runs cost more than the extra workgroups give)
-    const bool narrow = (long long)p.ncorner * ((p.Mc + 15) / 16) * tiles < 512 && p.K >= 96;
+    // (the 8-mode variant walks K two rows per pass: its clamped tail load is only right for even K - odd channel counts take the
+    // 16-mode variant)
+    const bool narrow = (long long)p.ncorner * ((p.Mc + 15) / 16) * tiles < 512 && p.K >= 96 && (p.K & 1) == 0;
     const int qc = narrow ? 8 : 16;
     const int nq = (p.Mc + qc - 1) / qc;
     dim3 grid(p.ncorner * nq, (p.N + 15) / 16, (p.M + 15) / 16);
