@@ -67,6 +67,28 @@ __global__ __launch_bounds__(256) void resample_cols_kernel(const TI* __restrict
     }
 }
 
+// any band width: the taps in a run-time loop, weights read per tap (strong down-sampling - 90 -> 8 columns has 43 taps - and the
+// adjoints of strong up-sampling; the U-NO models stay below 11 taps and never come here)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void resample_cols_generic_kernel(const TI* __restrict__ in, TO* __restrict__ out,
+                                                                    const int* __restrict__ start, const float* __restrict__ wt,
+                                                                    int K, int R, int W, int Wo, int rows_per_block, int accumulate) {
+    const int n = blockIdx.z;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Wo) return;
+    const int s = start[j];
+    const float* w = wt + (size_t)j * K;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, R);
+    for (int r = r0; r < r1; ++r) {
+        const TI* src = in + ((size_t)n * R + r) * W;
+        float acc = 0.f;
+        for (int t = 0; t < K; ++t) acc = fmaf(w[t], io_widen(src[min(s + t, W - 1)]), acc);
+        TO* o = out + ((size_t)n * R + r) * Wo + j;
+        io_store1(o, accumulate ? io_widen(*o) + acc : acc);
+    }
+}
+
 // Fused form: one workgroup = (image, tile of TR = 16 output rows).
 //   phase 1 (rows): every thread owns one image column.  It streams the NP input rows the tile depends on - each
 //     element loaded exactly once, unit-stride across the wave, all loads independent - and accumulates the 16
@@ -241,8 +263,9 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
     const bf_t* inb = static_cast<const bf_t*>(in_);
     bf_t* outb = static_cast<bf_t*>(out_);
     const double es = bf16 ? 2.0 : 4.0;
-    if (KH < 1 || KW < 1 || KH > 16 || KW > 16) { set_error("resample2d: band width (%d, %d) outside 1..16", KH, KW); return -2; }
-    if (tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
+    if (KH < 1 || KW < 1) { set_error("resample2d: empty band (%d, %d)", KH, KW); return -2; }
+    const bool wide_band = KW > 16;         // the column operator's taps live in registers up to 16; beyond that: the generic two-pass form
+    if (!wide_band && tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
         const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float);
         ProfScope prof("uno::resample_fused_kernel", es * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
@@ -293,14 +316,18 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
         }
         {
             ProfScope prof("uno::resample_cols_kernel", n_img * (4.0 * Ho * W + es * Ho * Wo), s);
-            if (bf16) hipLaunchKernelGGL((resample_cols_kernel<float, bf_t>), g2, dim3(256), 0, s, (const float*)tmp, outb, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
+            if (wide_band && bf16) hipLaunchKernelGGL((resample_cols_generic_kernel<float, bf_t>), g2, dim3(256), 0, s, (const float*)tmp, outb, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
+            else if (wide_band) hipLaunchKernelGGL((resample_cols_generic_kernel<float, float>), g2, dim3(256), 0, s, (const float*)tmp, out, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
+            else if (bf16) hipLaunchKernelGGL((resample_cols_kernel<float, bf_t>), g2, dim3(256), 0, s, (const float*)tmp, outb, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
             else hipLaunchKernelGGL((resample_cols_kernel<float, float>), g2, dim3(256), 0, s, (const float*)tmp, out, startW, wtW, KW, Ho, W, Wo, RPB, accumulate);
         }
     } else {
         const dim3 g1((Wo + 255) / 256, (H + RPB - 1) / RPB, n_img), g2((Wo + 255) / 256, (Ho + RPB - 1) / RPB, n_img);
         {
             ProfScope prof("uno::resample_cols_kernel", n_img * (es * H * W + 4.0 * H * Wo), s);
-            if (bf16) hipLaunchKernelGGL((resample_cols_kernel<bf_t, float>), g1, dim3(256), 0, s, inb, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
+            if (wide_band && bf16) hipLaunchKernelGGL((resample_cols_generic_kernel<bf_t, float>), g1, dim3(256), 0, s, inb, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
+            else if (wide_band) hipLaunchKernelGGL((resample_cols_generic_kernel<float, float>), g1, dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
+            else if (bf16) hipLaunchKernelGGL((resample_cols_kernel<bf_t, float>), g1, dim3(256), 0, s, inb, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
             else hipLaunchKernelGGL((resample_cols_kernel<float, float>), g1, dim3(256), 0, s, in, tmp, startW, wtW, KW, H, W, Wo, RPB, 0);
         }
         {
