@@ -108,3 +108,111 @@ def test_resample_random_sizes(cfg):
     acc = gy.cuda().clone()
     resample_forward(x.cuda(), Ho, Wo, out=acc)
     assert rel_err(acc.cpu().numpy(), (gy + yc.detach()).numpy()) < 5e-6
+
+
+def _rel64(a, b):
+    d = (a.double().cpu() - b.cpu()).norm().item()
+    n = b.norm().item()
+    return d / n if n > 0 else d
+
+
+def _fused_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nd = int(rng.choice([1, 2, 2, 3]))
+        sp = tuple(int(v) for v in rng.integers(2, [4000, 120, 24][nd - 1] + 1, size=nd))
+        out.append((int(rng.integers(1, 4)), int(rng.integers(1, 70)), sp))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _fused_cases(16, 5), ids=lambda c: f"B{c[0]}-C{c[1]}-" + "x".join(map(str, c[2])))
+def test_fused_pointwise_kernels_random_shapes(cfg):
+    """K13 InstanceNorm(affine) + GELU, K11 GELU + projection, K12 GELU + padding (2-D shapes) on random shapes, forward and every
+    gradient against the stock op sequences in float64."""
+    import torch.nn as nn
+    from uno_amd.integral_operators import gelu_pad2d, gelu_project, instance_norm_gelu
+    B, C, sp = cfg
+    g = torch.Generator().manual_seed(B + 3 * C + sum(sp))
+    x = 2.0 * torch.randn(B, C, *sp, generator=g) + 0.5
+    gy = torch.randn(B, C, *sp, generator=g)
+    # K13
+    cls = {1: nn.InstanceNorm1d, 2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}[len(sp)]
+    norm = cls(C, affine=True)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g)); norm.bias.copy_(torch.randn(C, generator=g))
+    ref_norm = cls(C, affine=True).double()
+    ref_norm.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    x2 = x.double().requires_grad_(True)
+    y2 = F.gelu(ref_norm(x2))
+    ref = torch.autograd.grad(y2, [x2] + list(ref_norm.parameters()), gy.double())
+    norm = norm.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = instance_norm_gelu(xd, norm, True)
+    got = torch.autograd.grad(y, [xd] + list(norm.parameters()), gy.cuda())
+    assert _rel64(y, y2.detach()) < 5e-6
+    for a, r in zip(got, ref):
+        assert a.shape == r.shape and _rel64(a, r) < 3e-5
+    # K11
+    w = torch.randn(1, C, generator=g); b = torch.randn(1, generator=g)
+    pre = x.cuda().requires_grad_(True); wd = w.cuda().requires_grad_(True); bd = b.cuda().requires_grad_(True)
+    yp = gelu_project(pre, wd, bd)
+    gyp = torch.randn(B, 1, *sp, generator=g)
+    gotp = torch.autograd.grad(yp, (pre, wd, bd), gyp.cuda())
+    pre2, w2, b2 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yp2 = torch.einsum("oc,bc...->bo...", w2, F.gelu(pre2)) + b2.view(1, 1, *([1] * len(sp)))
+    refp = torch.autograd.grad(yp2, (pre2, w2, b2), gyp.double())
+    assert _rel64(yp, yp2.detach()) < 5e-6
+    for a, r in zip(gotp, refp):
+        assert a.shape == r.shape and _rel64(a, r) < 3e-5
+    # K12
+    if len(sp) == 2:
+        pad = (int(sp[0] % 7), int(sp[1] % 5))
+        s = x.cuda().requires_grad_(True)
+        yq = gelu_pad2d(s, pad[0], pad[1])
+        gyq = torch.randn(B, C, sp[0] + pad[0], sp[1] + pad[1], generator=g)
+        (gs,) = torch.autograd.grad(yq, s, gyq.cuda())
+        s2 = x.double().requires_grad_(True)
+        yq2 = F.pad(F.gelu(s2), [0, pad[1], 0, pad[0]])
+        (gs2,) = torch.autograd.grad(yq2, s2, gyq.double())
+        assert _rel64(yq, yq2.detach()) < 5e-6 and _rel64(gs, gs2) < 5e-6
+
+
+def _plane3d_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        din = (int(rng.integers(2, 30)), int(rng.integers(2, 30)), int(rng.integers(2, 24)))
+        dout = (int(rng.integers(2, 30)), int(rng.integers(2, 30)), int(rng.integers(2, 24)))
+        m1 = int(rng.integers(1, min(din[0], dout[0]) + 1))
+        m2 = int(rng.integers(1, min(din[1], dout[1]) + 1))
+        m3 = int(rng.integers(1, min(din[2], dout[2]) // 2 + 2))
+        try:
+            so.check_modes_3d(*din, *dout, m1, m2, m3)
+        except Exception:
+            continue
+        out.append((int(rng.integers(1, 3)), int(rng.integers(1, 5)), int(rng.integers(1, 5)), din, dout, (m1, m2, m3)))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _plane3d_cases(14, 808), ids=lambda c: f"B{c[0]}-{c[1]}x{c[2]}-" + "x".join(map(str, c[3])) + "-" + "x".join(map(str, c[4])) + "-m" + "x".join(map(str, c[5])))
+def test_spectral_conv3d_random_geometry_small_batches(cfg):
+    """SpectralConv3d with few volumes (the plane-batched K1p / K3p + K5 / K6 path, the any-mode forms, overlapping corners):
+    forward and all gradients against the dense float64 oracle."""
+    from uno_amd.spectral3d import spectral_conv3d
+    B, Ci, Co, din, dout, modes = cfg
+    rng = np.random.default_rng(sum(din) * 7 + sum(dout) + sum(modes))
+    x = rng.standard_normal((B, Ci, *din)).astype(np.float32)
+    sc = (1 / (2 * Ci)) ** 0.5
+    ws = [(sc * (rng.standard_normal((Ci, Co, *modes)) + 1j * rng.standard_normal((Ci, Co, *modes)))).astype(np.complex64) for _ in range(4)]
+    gy = rng.standard_normal((B, Co, *dout)).astype(np.float32)
+    y_ref, X = so.spectral_conv3d_dense(x, ws, *dout)
+    gx_ref, gws_ref, _, _ = so.spectral_conv3d_dense_bwd(gy, X, ws, *din)
+    xd = cu(x).requires_grad_(True)
+    wd = [cu(w).requires_grad_(True) for w in ws]
+    y = spectral_conv3d(xd, wd, *dout)
+    y.backward(cu(gy))
+    assert rel_err(y.detach().cpu().numpy(), y_ref) < TOL
+    assert rel_err(xd.grad.cpu().numpy(), gx_ref) < TOL
+    for k in range(4):
+        assert rel_err(wd[k].grad.cpu().numpy(), gws_ref[k]) < TOL, k
