@@ -51,3 +51,28 @@ def test_adam_kernel_matches_cpu_path(shape, cplx):
     assert rel_err(a.numpy(), b.numpy()) < 1e-6
     sa, sb = od.state[pd], oc.state[pc]
     assert rel_err(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].numpy()) < 1e-6
+
+
+def test_adam_multi_tensor_launches_many_mixed_tensors():
+    """60 parameter tensors - real and complex, 1 to 70000 entries - through the multi-tensor kernel (24 tensors per launch: three
+    launches with the type mask and the workgroup -> tensor map changing between them) against the CPU path, 3 steps."""
+    rng = np.random.default_rng(12)
+    g = torch.Generator().manual_seed(5)
+    shapes = [tuple(int(v) for v in rng.integers(1, [70000, 300, 40][nd - 1] + 1, size=nd)) for nd in rng.integers(1, 4, size=60)]
+    cplx = [bool(v) for v in rng.integers(0, 2, size=60)]
+    p0 = [torch.randn(*s, dtype=torch.complex64 if c else torch.float32, generator=g) for s, c in zip(shapes, cplx)]
+    pc = [torch.nn.Parameter(t.clone()) for t in p0]
+    pd = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    oc = ComplexAdam(pc, lr=2e-3, weight_decay=1e-3)
+    od = ComplexAdam(pd, lr=2e-3, weight_decay=1e-3)
+    for _ in range(3):
+        for a, b in zip(pc, pd):
+            gr = torch.randn(*a.shape, dtype=a.dtype, generator=g)
+            a.grad = gr.clone()
+            b.grad = gr.cuda()
+        oc.step()
+        od.step()
+    for a, b in zip(pc, pd):
+        x = torch.view_as_real(b.detach()).cpu() if b.is_complex() else b.detach().cpu()
+        y = torch.view_as_real(a.detach()) if a.is_complex() else a.detach()
+        assert rel_err(x.numpy(), y.numpy()) < 1e-6, tuple(a.shape)
