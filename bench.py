@@ -170,6 +170,15 @@ def _traffic(names, launches=None, block="c2"):
         return None
 
 
+def _rocprof_block(block="c2"):
+    """profiles/block_rocprof.json (tools/profile_round.sh -> tools/block_rocprof_summary.py): the same block under rocprofv3
+    --kernel-trace with this file's warm protocol, per-dispatch; None when the file is absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "block_rocprof.json")))[block]
+    except Exception:
+        return None
+
+
 def spectral_block_roofline(dev):
     """BASELINE's second figure: SpectralConv2d(64,64,421,421,20,20), batch 16, forward and backward against the algorithmic
     bytes of SURVEY.md section 8(d) (fwd 1478.2 MB, bwd 1504.4 MB)."""
@@ -255,6 +264,17 @@ def extra_workloads(dev):
                                  ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch)
     out = {}
 
+    def spectral_names(fn):
+        """names of the spectral-path kernels (transforms, per-mode GEMMs) one call of fn launches - tests/test_hip_bench_shapes.py
+        checks that each of them is reached by a full-size oracle comparison"""
+        _native.profile_begin(100000)
+        try:
+            fn()
+            torch.cuda.synchronize(dev)
+        finally:
+            rec = _native.profile_end()
+        return sorted({n for n, _, _ in rec if "dft" in n or "mode_gemm" in n})
+
     def guarded(key, fn):
         try:
             out[key] = fn()
@@ -268,7 +288,8 @@ def extra_workloads(dev):
         tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
         a, u = synthetic_darcy_batch(BATCH, S, 1234, dev)
         ms = _train_ms(lambda: tr.step(a, u), dev)
-        return {"config": "UNO_9(3,64,pad=5) 421^2 batch 16 driven as darcy_flow_uno2d.py:94-133 drives it (channels-last nn.Linear, "
+        return {"spectral_kernels": spectral_names(lambda: tr.step(a, u)),
+                "config": "UNO_9(3,64,pad=5) 421^2 batch 16 driven as darcy_flow_uno2d.py:94-133 drives it (channels-last nn.Linear, "
                           "F.gelu, permute, F.pad, torch.cat, host-built grid) on the product operator blocks",
                 "ms_per_step": ms, "samples_per_s": BATCH / ms * 1e3}
 
@@ -277,10 +298,12 @@ def extra_workloads(dev):
         m = UNO(14, 32).to(dev)
         xx, yy = torch.randn(32, 64, 64, 10, device=dev), torch.randn(32, 64, 64, 40, device=dev)
         opt = ComplexAdam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        names = spectral_names(lambda: ns2d_rollout_loss(m, xx, yy, T_f=2, step=1).backward())
+        opt.zero_grad(set_to_none=True)
         gs = GraphedStep(m, opt, lambda a_, b_: ns2d_rollout_loss(m, a_, b_, T_f=40, step=1), (xx, yy))
         ms = _train_ms(lambda: gs.step(xx, yy), dev, steps=4, warmup=1)
         return {"config": "C3: UNO(14,32), 64^2, batch 32, T 10 -> 40 autoregressive roll-out, one backward, HIP-graph replay + eager Adam",
-                "ms_per_step": ms, "samples_per_s": 32 / ms * 1e3}
+                "ms_per_step": ms, "samples_per_s": 32 / ms * 1e3, "spectral_kernels": names}
 
     def ns3d(width):
         def run():
@@ -297,7 +320,7 @@ def extra_workloads(dev):
                 return loss
             ms = _train_ms(step, dev)
             return {"config": f"C4: Uno3D_T20(6,{width},pad=3), 64x64x10 -> 64x64x20, batch 8", "ms_per_step": ms,
-                    "samples_per_s": 8 / ms * 1e3}
+                    "samples_per_s": 8 / ms * 1e3, "spectral_kernels": spectral_names(step)}
         return run
 
     def c5_block():
@@ -313,22 +336,28 @@ def extra_workloads(dev):
         tb = _timed(lambda: _native.spectral_conv2d_backward(gy, xt, w1, w2, S5, S5), dev, iters=5, reps=3, warm=2)
         img, wb = B * C * S5 * S5 * 4, 2 * C * C * m * m * 8
         res = {"config": f"C5 block: SpectralConv2d(64,64,1024,1024,32,32) batch {B}",
+               "spectral_kernels": spectral_names(lambda: (_native.spectral_conv2d_forward(x, w1, w2, S5, S5),
+                                                           _native.spectral_conv2d_backward(gy, xt, w1, w2, S5, S5))),
                "f32": {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_frac_of_8TBs": (2 * img + wb) / tf / 8e12,
                        "bwd_frac_of_8TBs": (2 * img + 2 * wb) / tb / 8e12}}
         xb, gyb = x.bfloat16(), gy.bfloat16()
         del x, gy
-        yb, xtb = _native.spectral_conv2d_forward(xb, w1, w2, S5, S5)
-        tf = _timed(lambda: _native.spectral_conv2d_forward(xb, w1, w2, S5, S5), dev, iters=5, reps=3, warm=2)
-        tb = _timed(lambda: _native.spectral_conv2d_backward(gyb, xtb, w1, w2, S5, S5), dev, iters=5, reps=3, warm=2)
+        # the mixed entry points: bf16 images, weights READ as (re, im) float16 storage - the byte model below is what runs
+        w1h, w2h = (torch.view_as_real(w).half().contiguous() for w in (w1, w2))
+        yb, xtb = _native.spectral_conv2d_forward(xb, w1h, w2h, S5, S5)
+        tf = _timed(lambda: _native.spectral_conv2d_forward(xb, w1h, w2h, S5, S5), dev, iters=5, reps=3, warm=2)
+        tb = _timed(lambda: _native.spectral_conv2d_backward(gyb, xtb, w1h, w2h, S5, S5), dev, iters=5, reps=3, warm=2)
         imgb, wh = img // 2, wb // 2          # s_a = 2 (bf16 activations), s_w = 4 (complex-half weight storage)
-        res["bf16_activations"] = {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_frac_of_8TBs": (2 * imgb + wh) / tf / 8e12,
-                                   "bwd_frac_of_8TBs": (2 * imgb + 2 * wh) / tb / 8e12,
+        # backward: read the fp16 weights, write complex64 weight gradients (accumulated and returned in f32)
+        res["bf16_activations_fp16_weights"] = {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_frac_of_8TBs": (2 * imgb + wh) / tf / 8e12,
+                                   "bwd_frac_of_8TBs": (2 * imgb + wh + wb) / tb / 8e12,
                                    "rel_err_vs_f32": float((yb.float() - y).norm() / y.norm())}
         return res
 
     def c5_model():
         torch.manual_seed(0)
         B = 4
+        torch.cuda.reset_peak_memory_stats(dev)
         model = UNO_9(3, 64, pad=5).to(dev)
         tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
         a, u = synthetic_darcy_batch(B, 1024, 1234, dev)
@@ -348,6 +377,50 @@ def extra_workloads(dev):
     except ImportError:
         pass
     return out
+
+
+# ----------------------------------------------------------------------------------------------- data-parallel self-check
+def dp_selfcheck(dev, world, rank):
+    """Before anything is timed with N > 1 ranks: two training steps of a small UNO_9 on a global batch of 2 x world samples,
+    sharded over the ranks (bucketed RCCL all-reduce, several buckets) against the same two steps in ONE process on the whole
+    batch (computed redundantly on every rank, no collectives).  Gradients are SUMMED over ranks, so the flat gradient buffers
+    must agree to float32 summation order - the check tests/test_hip_dist.py::test_two_ranks_rccl_equal_single_process makes, run where the
+    devices are.  Raises on mismatch: a wrong exchange never produces a throughput number."""
+    import torch
+    import torch.distributed as dist
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    Ssc, per = 43, 2
+    a, u = synthetic_darcy_batch(per * world, Ssc, 4321, dev)            # the same global batch on every rank
+    torch.manual_seed(7)
+    m_dp = UNO_9(3, 8, pad=2).to(dev)
+    torch.manual_seed(7)
+    m_one = UNO_9(3, 8, pad=2).to(dev)
+    tr_dp = DarcyTrainer(m_dp, lr=1e-3, weight_decay=1e-3, bucket_mb=0.05)
+    tr_one = DarcyTrainer(m_one, lr=1e-3, weight_decay=1e-3)
+    from uno_amd.harness.losses import lp_loss_rel_sum
+    sl = slice(rank * per, (rank + 1) * per)
+    worst = 0.0
+    B = a.shape[0]
+    for _ in range(2):
+        # data-parallel: this rank's shard, bucketed all-reduce (SUM) overlapped with the backward pass
+        tr_dp.grads.zero_()
+        loss = lp_loss_rel_sum(m_dp(a[sl]).reshape(per, -1), u[sl].reshape(per, -1))
+        tr_dp.grads.arm(None)
+        loss.backward()
+        tr_dp.grads.finish()
+        # one process on the whole batch, no collectives
+        tr_one.grads.zero_()
+        lp_loss_rel_sum(m_one(a).reshape(B, -1), u.reshape(B, -1)).backward()
+        g_dp, g_one = tr_dp.grads.flat, tr_one.grads.flat
+        worst = max(worst, float((g_dp - g_one).norm() / g_one.norm().clamp_min(1e-30)))
+        tr_dp.opt.step()
+        tr_one.opt.step()
+    t = torch.tensor([worst], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst = float(t.item())
+    if not worst < 2e-4:
+        raise SystemExit(f"data-parallel self-check FAILED: summed gradients of {world} ranks vs one process differ by {worst:.3e}")
+    return {"ranks": world, "buckets": len(tr_dp.grads.buckets), "max_rel_grad_diff_over_2_steps": worst, "tolerance": 2e-4}
 
 
 # ----------------------------------------------------------------------------------------------- launch
@@ -415,6 +488,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    selfcheck = dp_selfcheck(dev, world, rank) if world > 1 else None
     for _ in range(args.warmup):
         trainer.step(a, u)
     sync_all()
@@ -448,6 +522,21 @@ def main():
         comm = {"backend": backend, "ranks": dist.get_world_size(), "grad_bytes": trainer.grads.flat.numel() * 4,
                 "buckets": len(trainer.grads.buckets), "bucket_mb": 32.0,
                 "blocking_allreduce_ms": (time.perf_counter() - tc) / 5 * 1e3}
+        # overlapped vs blocking exchange: the same K steps with the bucket hooks off and ONE blocking all-reduce after the
+        # backward pass; and the issue time of every bucket relative to the start of a backward pass (host clock, rank 0)
+        sync_all()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step_blocking(a, u)
+        sync_all()
+        comm["ms_per_step_blocking_allreduce"] = (time.perf_counter() - tc) / args.steps * 1e3
+        comm["ms_per_step_overlapped"] = elapsed / args.steps * 1e3
+        trainer.grads.trace = []
+        trainer.step(a, u)
+        sync_all()
+        comm["bucket_issue_ms_after_backward_start"] = [round(t * 1e3, 3) for t in trainer.grads.trace]
+        trainer.grads.trace = None
+        comm["selfcheck"] = selfcheck
     loss_val = float(loss)
     assert loss_val == loss_val, "training produced NaN"
 
@@ -467,8 +556,15 @@ def main():
         block = spectral_block_roofline(dev)
         kf = block["fwd_kernels"]
         dom = max(kf, key=lambda k: kf[k]["avg_us"] * kf[k]["launches_per_call"])
+        rp = _rocprof_block("c2")
         roofline = {
             "bound": "hbm", "kernel": "spectral block forward = " + " + ".join(sorted(kf)),
+            # the same block under rocprofv3 --kernel-trace with the same warm protocol (profiles/block_rocprof.json, per-dispatch
+            # rows in profiles/rNN_block2d_dispatches.csv): wall span of 100 timed calls / 100, and the plain sum of kernel means
+            "frac_rocprof": rp["forward"]["frac_span"] if rp else None,
+            "rocprof": ({"forward": {k: rp["forward"][k] for k in ("span_us_per_call", "kernel_sum_us_per_call", "frac_span", "frac_kernel_sum")},
+                         "backward": {k: rp["backward"][k] for k in ("span_us_per_call", "kernel_sum_us_per_call", "frac_span", "frac_kernel_sum")}}
+                        if rp else None),
             "achieved": block["fwd_bytes"] / (block["fwd_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": block["fwd_frac_of_8TBs"], "traffic": _traffic(list(kf), {k: v["launches_per_call"] for k, v in kf.items()}),
             "avg_launch_us": block["fwd_us"], "algorithmic_bytes_per_launch": block["fwd_bytes"],

@@ -100,3 +100,25 @@ def test_half_precision_weight_storage_and_argument_errors():
         spectral_conv2d_mixed(x.float(), w[0], w[1], 16, 16)            # the mixed form takes bf16 activations only
     with pytest.raises(RuntimeError):
         SpectralConv2d_Uno(3, 5, 16, 16, 4, 4).to(dev())(x)             # the reference's module contract: float32 input
+
+
+def test_mixed_precision_layer_with_default_modes_widens_instead_of_raising():
+    """enable_mixed_precision on a layer built with the reference's DEFAULT modes (dim1//2 - 1, dim2//2: beyond the bf16 kernels'
+    compiled range): the layer runs its float32 any-mode form on the widened activations and returns bf16 - same result as the
+    f32 layer on the widened input, rounded once."""
+    from uno_amd.integral_operators import OperatorBlock_2D, SpectralConv2d_Uno, enable_mixed_precision
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    conv = SpectralConv2d_Uno(3, 2, 100, 100).to(dev)
+    assert (conv.modes1, conv.modes2) == (49, 50)
+    xb = torch.randn(2, 3, 100, 100, device=dev).bfloat16()
+    ref = conv(xb.float())
+    enable_mixed_precision(conv)
+    y = conv(xb)
+    assert y.dtype == torch.bfloat16
+    assert torch.equal(y, ref.bfloat16())
+    blk = enable_mixed_precision(OperatorBlock_2D(3, 2, 100, 100, 49, 50).to(dev))
+    out = blk(xb)
+    assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
+    out.float().sum().backward()
+    assert blk.conv.weights1.grad is not None and torch.isfinite(torch.view_as_real(blk.conv.weights1.grad)).all()

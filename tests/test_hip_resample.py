@@ -8,7 +8,10 @@ from conftest import rel_err
 
 SIZES = [((20, 18), (12, 10)), ((12, 10), (21, 19)), ((90, 90), (45, 45)), ((45, 45), (22, 22)), ((22, 22), (45, 45)),
          ((45, 45), (90, 90)), ((37, 50), (29, 31)), ((223, 223), (111, 111)), ((111, 111), (223, 223)), ((16, 16), (16, 16)),
-         ((9, 300), (4, 301)), ((446, 446), (223, 223)), ((7, 3), (5, 2)), ((5, 2), (9, 3)), ((33, 5), (20, 7))]
+         ((9, 300), (4, 301)), ((446, 446), (223, 223)), ((7, 3), (5, 2)), ((5, 2), (9, 3)), ((33, 5), (20, 7)),
+         # rows whose 16 x W tile alone fits 64 KB of LDS but tile + row-operator table does not (W ~ 980..1024: an unpadded
+         # 1024^2 level resampled 1024 -> 512): must take the two-pass form, not fail at launch
+         ((40, 1024), (20, 512)), ((36, 1000), (18, 500)), ((20, 512), (40, 1024)), ((24, 960), (12, 480))]
 
 
 def test_band_tables_reconstruct_the_operator():

@@ -579,7 +579,9 @@ class AdamPlan:
             if gr.numel() != pr.numel() or m.numel() != pr.numel() or v.numel() != p.numel():
                 raise RuntimeError("uno_amd: Adam state shapes do not match the parameter")
             reals.append((pr, gr, m, v, p.numel(), 1 if cplx else 0))
-        self._keep = reals                                   # keeps the views (and their storage) alive
+        # parameters and moments are kept alive; gradient buffers are NOT (a plan must not pin the gradients of a step that
+        # released them, e.g. zero_grad(set_to_none=True)): the caller re-validates the pointer tuple (`key`) before every use
+        self._keep = [(r[0], r[2], r[3]) for r in reals]
         arr = _fp * self.n
         self.p = arr(*[r[0].data_ptr() for r in reals])
         self.g = arr(*[r[1].data_ptr() for r in reals])

@@ -265,9 +265,12 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
     const double es = bf16 ? 2.0 : 4.0;
     if (KH < 1 || KW < 1) { set_error("resample2d: empty band (%d, %d)", KH, KW); return -2; }
     const bool wide_band = KW > 16;         // the column operator's taps live in registers up to 16; beyond that: the generic two-pass form
-    if (!wide_band && tile_p0 && tile_w && NP >= 1 && NP <= 96 && (size_t)RS_TR * W * sizeof(float) <= 64 * 1024) {
+    // dynamic LDS of the fused kernel: the 16 x W tile (rows padded to 4 floats) + the dense row-operator tile.  Gated on the
+    // REAL request (W ~ 980..1024 passes a tile-only test and then asks for more than the 64 KB a launch gets without the
+    // dynamic-LDS attribute: the launch fails instead of falling through to the two-pass form)
+    const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float);
+    if (!wide_band && tile_p0 && tile_w && NP >= 1 && NP <= 96 && lds <= 64 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
-        const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float);
         ProfScope prof("uno::resample_fused_kernel", es * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
         // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
         const int sweeps = (W + 511) / 512;

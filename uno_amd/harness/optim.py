@@ -3,7 +3,7 @@ torch.optim.Adam on complex parameters: the second moment is built from g * conj
 complex modulus, one real number per complex entry), weight decay is the coupled L2 form
 (g += wd * p).  Implemented with multi-tensor (_foreach) ops over real views so a step is a handful
 of launches instead of a Python loop of complex sqrt/addcdiv per parameter.  Parameters on a HIP device are
-updated by the one-pass K10 kernel (csrc/adam.hip), one launch per tensor."""
+updated by the one-pass multi-tensor K10 kernel (csrc/adam.hip: 24 tensors per launch, one native call per step bucket)."""
 from __future__ import annotations
 
 import math
@@ -23,14 +23,17 @@ class ComplexAdam(Optimizer):
         """K10 over all device tensors of the group in one native call; the pointer tables are rebuilt only when a
         parameter or gradient buffer moved (FlatGradients keeps them fixed)."""
         from .. import _native
-        gid = (next(i for i, g in enumerate(self.param_groups) if g is group), len(params))
-        plan = self._plans.get(gid)
+        # one plan per set of buffers (the pointer tuple is the key): step buckets of one group never evict each other, and a
+        # plan is rebuilt only when a parameter, gradient or moment buffer moved (e.g. load_state_dict replaces the moments)
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
-                    for p in params)       # rebuilt if any buffer moved (e.g. load_state_dict replaces the moments)
-        if plan is None or plan.key != key:
+                    for p in params)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 4:
+                self._plans.clear()
             plan = _native.AdamPlan([p.data for p in params], [p.grad for p in params],
                                     [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params])
-            self._plans[gid] = plan
+            self._plans[key] = plan
         plan.step(step, lr, beta1, beta2, eps, wd)
 
     @staticmethod

@@ -11,6 +11,8 @@ is a SUM over the batch, hence gradients are SUMMED over ranks: the update equal
 update on the concatenated global batch."""
 from __future__ import annotations
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -83,6 +85,8 @@ class FlatGradients:
         self._group = None
         self._armed = False
         self._hooks = []
+        self.trace = None               # set to [] to record, per issued bucket, the host time since arm() (bench.py `comm`)
+        self._t_arm = 0.0
 
     def zero_(self):
         """Zero the buffer and make sure every .grad still is its view (optimizer.zero_grad(set_to_none=True) or a user
@@ -99,6 +103,7 @@ class FlatGradients:
         if not self._armed:
             return
         self._group = group
+        self._t_arm = time.perf_counter()
         self._pending = list(self._bucket_params)
         self._next = 0
         self._works = []
@@ -117,6 +122,8 @@ class FlatGradients:
 
     def _issue(self, k):
         a, b = self.buckets[k]
+        if self.trace is not None:
+            self.trace.append(time.perf_counter() - self._t_arm)
         self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
 
     def _issue_ready(self):
@@ -235,3 +242,14 @@ class DarcyTrainer:
     def step(self, a, u):
         B, S = a.shape[0], a.shape[1]
         return self.step_with(lambda: lp_loss_rel_sum(self.model(a).reshape(B, -1), u.reshape(B, -1)))
+
+    def step_blocking(self, a, u):
+        """The same step with the exchange NOT overlapped: backward first, then one blocking all-reduce of the whole flat
+        buffer (the comparison figure of bench.py's `comm` object)."""
+        B = a.shape[0]
+        self.grads.zero_()
+        loss = lp_loss_rel_sum(self.model(a).reshape(B, -1), u.reshape(B, -1))
+        loss.backward()
+        self.grads.all_reduce_sum(self.group, self.force_collectives)
+        self.opt.step()
+        return loss.detach()

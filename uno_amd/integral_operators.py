@@ -567,9 +567,17 @@ class SpectralConv2d_Uno(nn.Module):
             self.dim1 = dim1
             self.dim2 = dim2
         if self.mixed_precision and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == self.in_channels:
+            if not self._bf16_kernels():
+                # mode counts beyond the MFMA kernels' compiled range run the any-mode forms, which are float32 only: widen the
+                # activations for this layer instead of raising at run time (the reference's DEFAULT modes land here)
+                return spectral_conv2d(x.float(), self.weights1, self.weights2, self.dim1, self.dim2).to(torch.bfloat16)
             return _SpectralConv2dFn.apply(x, self.weights1, self.weights2, self.dim1, self.dim2, True)
         _check_input(x, 4, self.in_channels, "SpectralConv2d_Uno")
         return spectral_conv2d(x, self.weights1, self.weights2, self.dim1, self.dim2)
+
+    def _bf16_kernels(self):
+        """True when the bf16-image transform kernels cover this layer's mode counts (csrc/capi.hip: modes1 <= 40, modes2 <= 48)."""
+        return self.modes1 <= 40 and self.modes2 <= 48
 
 
 class pointwise_op_2D(nn.Module):
@@ -661,7 +669,8 @@ class OperatorBlock_2D(nn.Module):
     def _takes(self, x):
         """4-D device tensor the fused block kernels take: float32, or bfloat16 once the spectral layer is in mixed-precision mode."""
         return (x.is_cuda and x.dim() == 4 and
-                (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and getattr(self.conv, "mixed_precision", False))))
+                (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and getattr(self.conv, "mixed_precision", False)
+                                              and self.conv._bf16_kernels())))
 
 
 # --------------------------------------------------------------------------------------------- 3-D
