@@ -389,12 +389,12 @@ def dp_selfcheck(dev, world, rank):
     import torch
     import torch.distributed as dist
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
-    Ssc, per = 43, 2
+    Ssc, per = 72, 2              # the smallest grid class the model's fixed mode counts (18) allow
     a, u = synthetic_darcy_batch(per * world, Ssc, 4321, dev)            # the same global batch on every rank
     torch.manual_seed(7)
-    m_dp = UNO_9(3, 8, pad=2).to(dev)
+    m_dp = UNO_9(3, 8, pad=5).to(dev)
     torch.manual_seed(7)
-    m_one = UNO_9(3, 8, pad=2).to(dev)
+    m_one = UNO_9(3, 8, pad=5).to(dev)
     tr_dp = DarcyTrainer(m_dp, lr=1e-3, weight_decay=1e-3, bucket_mb=0.05)
     tr_one = DarcyTrainer(m_one, lr=1e-3, weight_decay=1e-3)
     from uno_amd.harness.losses import lp_loss_rel_sum

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 4
+#define UNO_SPECTRAL_ABI_VERSION 5
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -175,6 +175,24 @@ long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P);
 int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, void* ws, int B, int Ci, int Co,
                       long long P, int act_x, void* stream);
 
+/* uno_channel_mix / uno_channel_wgrad for a layer whose input is the channel concatenation of TWO tensors (the skip
+ * connections of the U-NO models: reference darcy_flow_uno2d.py:117-127 `torch.cat([x_c4, x_c0], dim=1)` -> conv5,
+ * `torch.cat([x_c5, x_fc0], dim=1)` -> fc1) without building the concatenation, one pass over every operand:
+ *   x1 (B, C1, P) holds input channels [0, C1), x2 (B, Ci - C1, P) the rest (x2 = NULL: one source, C1 ignored);
+ *   y1 (B, Co1, P) receives output channels [0, Co1), y2 (B, Co - Co1, P) the rest (y2 = NULL: one destination) - the
+ *   transposed call on grad_y then yields the two input gradients of the layer from ONE read of grad_y;
+ *   w is the layer's full (Co, Ci) weight (transpose_w = 1: (Ci, Co)), bias (Co) or NULL;
+ *   act_in applies to x1 only, dgelu_of (B, Co1, P) to y1 only (the pre-activation source of the pair);
+ *   y_act (B, Co, P) or NULL: additionally receives gelu(y) - the activation of a block without normalisation written by the
+ *   kernel that completes the pre-activation sum (reference integral_operators.py:282-283), single destination only.
+ * Splits must be multiples of 16 (C1) / 64 (Co1; 128 when Co is a multiple of 128) channels; uno_channel_wgrad2 needs
+ * C1 % 64 == 0 and P >= 64.  gw is the full (Co, Ci) gradient. */
+int uno_channel_mix2(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
+                     float* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
+                     const float* dgelu_of, void* stream);
+int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
+                       int Co, long long P, int act_x, void* stream);
+
 /* Final projection of the U-NO models fused with the GELU in front of it (reference darcy_flow_uno2d.py:128-131:
  * `x_fc1 = F.gelu(self.fc1(x)); x_out = self.fc2(x_fc1)` with fc2 = Linear(C, 1)), channels-first:
  *   out[b][p] = bias[0] + sum_c w[c] * gelu(pre[b][c][p])          pre (B, C, P), out (B, P), exact-erf GELU, bias may be NULL
@@ -244,6 +262,11 @@ int uno_channel_mix_bf16(const void* x, const float* w, const float* bias, void*
                          int transpose_w, int accumulate, int act_in, const void* dgelu_of, void* stream);
 int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
                            int act_x, void* stream);
+int uno_channel_mix2_bf16(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
+                          void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
+                          const void* dgelu_of, void* stream);
+int uno_channel_wgrad2_bf16(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
+                            int Co, long long P, int act_x, void* stream);
 int uno_gelu_project_forward_bf16(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P,
                                   void* stream);
 int uno_gelu_project_backward_bf16(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb,

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 _lock = threading.Lock()
@@ -49,6 +49,8 @@ _SIGNATURES = {
     "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
+    "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_gelu_project_forward": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
     "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
@@ -66,6 +68,8 @@ _SIGNATURES = {
     "uno_resample2d_bf16": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _fp]),
     "uno_channel_mix_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
     "uno_channel_wgrad_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_channel_mix2_bf16": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
+    "uno_channel_wgrad2_bf16": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_gelu_project_forward_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_backward_bf16": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
     "uno_gelu_pad_bf16": (C.c_int, [_fp, _fp, _fp] + [_i] * 6 + [_fp]),
@@ -420,6 +424,86 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
                                    _ptr(dgelu_of) if dgelu_of is not None else C.c_void_p(0), _stream(x))
     _check(rc, "uno_channel_mix")
     return y
+
+
+def channel_mix2_ok(C1: int, Co1, Co: int, P: int) -> bool:
+    """shape rules of the fused two-source / two-destination forms (csrc/channel_mix.hip)"""
+    if C1 is not None and (C1 < 16 or C1 % 16):
+        return False
+    if Co1 is not None and (Co1 < 64 or Co1 % 64):
+        return False
+    return True
+
+
+def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2=None, split_out: int | None = None,
+                 act_in: bool = False, dgelu_of=None, y_act: bool = False, accumulate: bool = False):
+    """uno_channel_mix2: y = Wm . cat(x1, x2) + bias in one pass (x2 may be None).
+    split_out = Co1: the output channels go to two tensors (B, Co1, P), (B, Co - Co1, P) -> returns (y1, y2);
+    y_act: also return gelu(y) as a second tensor -> (y, act); act_in / dgelu_of act on x1 / y1 only;
+    out (and out2): write (accumulate=True: add) into the given tensors instead of allocating."""
+    bf16 = _act_dtype(x1, "x1")
+    _require(w, torch.float32, "weight")
+    if x2 is not None:
+        _require(x2, x1.dtype, "x2")
+        if x2.shape[0] != x1.shape[0] or x2.shape[2] != x1.shape[2]:
+            raise RuntimeError("uno_amd: the two sources disagree in batch / pixel count")
+    if bias is not None:
+        _require(bias, torch.float32, "bias")
+    B, C1, P = x1.shape
+    Ci = C1 + (x2.shape[1] if x2 is not None else 0)
+    Co = w.shape[1] if transpose_w else w.shape[0]
+    if (w.shape[0] if transpose_w else w.shape[1]) != Ci:
+        raise RuntimeError(f"uno_amd: weight {tuple(w.shape)} does not match {Ci} input channels")
+    Co1 = Co if split_out is None else int(split_out)
+    if out is None:
+        y1 = torch.empty((B, Co1, P), dtype=x1.dtype, device=x1.device)
+        y2 = torch.empty((B, Co - Co1, P), dtype=x1.dtype, device=x1.device) if split_out is not None else None
+    else:
+        y1, y2 = out, out2
+        _require(y1, x1.dtype, "out")
+        if tuple(y1.shape) != (B, Co1, P) or (split_out is not None and (y2 is None or tuple(y2.shape) != (B, Co - Co1, P))):
+            raise RuntimeError("uno_amd: output tensors do not match (B, Co1, P) / (B, Co - Co1, P)")
+        if y2 is not None:
+            _require(y2, x1.dtype, "out2")
+    act = torch.empty((B, Co, P), dtype=x1.dtype, device=x1.device) if y_act else None
+    if dgelu_of is not None:
+        _require(dgelu_of, x1.dtype, "dgelu_of")
+        if tuple(dgelu_of.shape) != (B, Co1, P):
+            raise RuntimeError(f"uno_amd: dgelu_of has shape {tuple(dgelu_of.shape)}, expected {(B, Co1, P)}")
+    null = C.c_void_p(0)
+    with torch.cuda.device(x1.device):
+        fn = lib().uno_channel_mix2_bf16 if bf16 else lib().uno_channel_mix2
+        rc = fn(_ptr(x1), _ptr(x2) if x2 is not None else null, C1, _ptr(w), _ptr(bias) if bias is not None else null,
+                _ptr(y1), _ptr(y2) if y2 is not None else null, Co1, _ptr(act) if act is not None else null,
+                B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, 1 if act_in else 0,
+                _ptr(dgelu_of) if dgelu_of is not None else null, _stream(x1))
+    _check(rc, "uno_channel_mix2")
+    if split_out is not None:
+        return y1, y2
+    return (y1, act) if y_act else y1
+
+
+def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False):
+    """gy (B, Co, P), x1 (B, C1, P), x2 (B, C2, P) -> gw (Co, C1 + C2), gb (Co) or None: the weight gradient of a two-source
+    layer from one launch (act_x: x1 := gelu(x1) as it is read)."""
+    bf16 = _act_dtype(gy, "grad_output")
+    _require(x1, gy.dtype, "x1")
+    _require(x2, gy.dtype, "x2")
+    B, Co, P = gy.shape
+    C1, C2 = x1.shape[1], x2.shape[1]
+    if x1.shape[0] != B or x2.shape[0] != B or x1.shape[2] != P or x2.shape[2] != P:
+        raise RuntimeError("uno_amd: grad_output and the sources disagree in batch / pixel count")
+    Ci = C1 + C2
+    L = lib()
+    gw = torch.empty((Co, Ci), dtype=torch.float32, device=gy.device)
+    gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if need_bias else None
+    with torch.cuda.device(gy.device):
+        ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, P)), dtype=torch.uint8, device=gy.device)
+        fn = L.uno_channel_wgrad2_bf16 if bf16 else L.uno_channel_wgrad2
+        rc = fn(_ptr(gy), _ptr(x1), _ptr(x2), C1, _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws),
+                B, Ci, Co, P, 1 if act_x else 0, _stream(gy))
+    _check(rc, "uno_channel_wgrad2")
+    return gw, gb
 
 
 def channel_wgrad(gy, x, need_bias: bool = True, act_x: bool = False):

@@ -373,6 +373,31 @@ int uno_channel_mix_bf16(const void* x, const float* w, const float* bias, void*
     return channel_mix_impl(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 1, stream);
 }
 
+static int channel_mix2_impl(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
+                             void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
+                             const void* dgelu_of, int bf16, void* stream) {
+    if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
+    if (B == 0 || P == 0) return 0;
+    if (!x1 || !w || !y1) { set_error("uno_channel_mix2: null pointer"); return -1; }
+    ChannelMixArgs a{};
+    a.x = x1; a.x2 = x2; a.w = w; a.bias = bias; a.y = y1; a.y2 = y2; a.y_act = y_act; a.dgelu_of = dgelu_of;
+    a.B = B; a.Ci = Ci; a.Co = Co; a.C1 = x2 ? C1 : Ci; a.Co1 = y2 ? Co1 : Co; a.P = P;
+    a.transpose_w = transpose_w; a.accumulate = accumulate; a.act_in = act_in; a.bf16 = bf16;
+    return launch_channel_mix2(a, (hipStream_t)stream);
+}
+
+int uno_channel_mix2(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
+                     float* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
+                     const float* dgelu_of, void* stream) {
+    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 0, stream);
+}
+
+int uno_channel_mix2_bf16(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
+                          void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
+                          const void* dgelu_of, void* stream) {
+    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 1, stream);
+}
+
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
     if (B < 1 || Ci < 1 || Co < 1 || P < 1) return 0;
     return 4LL * channel_wgrad_ws_floats(B, Ci, Co, P, nullptr);
@@ -399,6 +424,24 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
 int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, void* ws, int B, int Ci, int Co, long long P,
                            int act_x, void* stream) {
     return channel_wgrad_impl(gy, x, gw, gb, ws, B, Ci, Co, P, act_x, 1, stream);
+}
+
+static int channel_wgrad2_impl(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
+                               int Co, long long P, int act_x, int bf16, void* stream) {
+    if (!x2) return channel_wgrad_impl(gy, x1, gw, gb, ws, B, Ci, Co, P, act_x, bf16, stream);
+    if (B < 1 || Ci < 2 || Co < 1 || P < 1) { set_error("uno_channel_wgrad2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
+    if (!gy || !x1 || !gw || !ws) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
+    return launch_channel_wgrad2(gy, x1, x2, C1, gw, gb, (float*)ws, B, Ci, Co, P, act_x, bf16, (hipStream_t)stream);
+}
+
+int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
+                       long long P, int act_x, void* stream) {
+    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, 0, stream);
+}
+
+int uno_channel_wgrad2_bf16(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
+                            long long P, int act_x, void* stream) {
+    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, 1, stream);
 }
 
 int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,

@@ -46,17 +46,34 @@ __device__ __forceinline__ float cm_dgelu(float x) {
 __device__ __forceinline__ float4 cm_gelu4(float4 v) { return make_float4(cm_gelu(v.x), cm_gelu(v.y), cm_gelu(v.z), cm_gelu(v.w)); }
 
 struct ChannelMixParams {
-    const void* x;          // (B, Ci, P) f32 | bf16 (BF instantiations: activations bfloat16, weights / accumulation f32)
+    const void* x;          // (B, C1, P) f32 | bf16 (BF instantiations: activations bfloat16, weights / accumulation f32)
+    const void* x2;         // (B, Ci - C1, P): input channels [C1, Ci) of a two-source call (a skip connection's torch.cat that is
+                            // never built), or nullptr with C1 == Ci
     const float* w;         // Wm(o, i) = w[o * w_so + i * w_si]
     const float* bias;      // (Co) or nullptr
-    void* y;                // (B, Co, P), x's element type
+    void* y;                // (B, Co1, P), x's element type
+    void* y2;               // (B, Co - Co1, P): output channels [Co1, Co) of a two-destination call (the two input gradients of a
+                            // two-source layer from one pass over grad_y), or nullptr with Co1 == Co
+    void* y_act;            // nullptr, or (B, Co, P): also receives gelu(y) (the block's activation written by the kernel that
+                            // completes the pre-activation sum; single destination only)
     int B, Ci, Co, P;
+    int C1, Co1;
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
     int accumulate;         // y += instead of y =
-    const void* dgelu_of;   // nullptr, or (B, Co, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
+    const void* dgelu_of;   // nullptr, or (B, Co1, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
+                            // (first destination only)
 };
+
+// where output channel tile o0 of batch entry b lives: row o of the tile = base + (o - ob) * P
+template <typename T>
+struct CmDest { T* base; int ob; };
+template <typename T>
+__device__ __forceinline__ CmDest<T> cm_dest(const ChannelMixParams& p, int o0, int b) {
+    if (o0 >= p.Co1) return {reinterpret_cast<T*>(p.y2) + (size_t)b * (p.Co - p.Co1) * p.P, p.Co1};
+    return {reinterpret_cast<T*>(p.y) + (size_t)b * p.Co1 * p.P, 0};
+}
 
 // MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
 //         32-bit offsets from a uniform base - the per-element clamps and selects of the guarded path cost more
@@ -71,9 +88,15 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     using T = typename IoElem<BF>::type;                // float | unsigned short (bf16 bits)
-    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P;
-    T* const yall = reinterpret_cast<T*>(p.y);
-    const T* const dall = reinterpret_cast<const T*>(p.dgelu_of);
+    const int C1 = p.C1;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;                        // channels [0, C1)
+    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;  // channels [C1, Ci), row ci - C1
+    const CmDest<T> dd = cm_dest<T>(p, o0, b);
+    T* const ydst = dd.base;                     // row o of this tile: ydst + (o - dd.ob) * P
+    const bool dg = DG && o0 < p.Co1;            // gelu' factor: first destination only
+    const T* const dall = DG ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * p.P : nullptr;
+    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
+    bool act_ld = ACT;                           // the chunk in the staging registers comes from the activated source
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
     //               8 single elements (row e / 128, px e % 128);  W chunk = 16 k x 64 o -> 4 elements (k e % 16, o e / 16)
@@ -81,11 +104,15 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     float rw[4];
     const bool tr = p.w_so == 1 && p.w_si != 1;        // W contiguous along the output channel (input-gradient call)
     auto load_chunk = [&](int k0) {
+        act_ld = ACT && k0 < C1;
         if constexpr (MODE == 2) {
+            // a chunk of 16 channels lies in one source (C1 is a multiple of 16 in two-source calls)
+            const T* cb = k0 < C1 ? xb : xb2;
+            const int kb = k0 < C1 ? k0 : k0 - C1;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                rx[u] = io_ld4(xb + (unsigned)((k0 + (e / F4R)) * p.P + p0 + (e % F4R) * 4));
+                rx[u] = io_ld4(cb + (unsigned)((kb + (e / F4R)) * p.P + p0 + (e % F4R) * 4));
             }
             // W chunk as ONE 16-byte load per thread along whichever index is contiguous in memory (4 dword loads
             // per thread made W the most numerous vector-memory instruction of the tile; the address unit was the
@@ -101,8 +128,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                const int ci = k0 + (e / F4R);
-                float4 v = load4_tail(xb + (size_t)min(ci, p.Ci - 1) * p.P, p0 + (e % F4R) * 4, p.P);
+                const int ci = k0 + (e / F4R), cc = min(ci, p.Ci - 1);
+                float4 v = load4_tail(cc < C1 ? xb + (size_t)cc * p.P : xb2 + (size_t)(cc - C1) * p.P, p0 + (e % F4R) * 4, p.P);
                 if (ci >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 rx[u] = v;
             }
@@ -113,7 +140,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
                 const int ci = k0 + e / PT, pp = p0 + e % PT;
-                r[u] = (ci < p.Ci && pp < p.P) ? io_widen(xb[(size_t)ci * p.P + pp]) : 0.f;
+                r[u] = (ci < p.Ci && pp < p.P) ? io_widen(ci < C1 ? xb[(size_t)ci * p.P + pp] : xb2[(size_t)(ci - C1) * p.P + pp]) : 0.f;
             }
         }
 #pragma unroll
@@ -129,14 +156,14 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                *reinterpret_cast<float4*>(&sX[buf][(e / F4R) * XS + (e % F4R) * 4]) = ACT ? cm_gelu4(rx[u]) : rx[u];
+                *reinterpret_cast<float4*>(&sX[buf][(e / F4R) * XS + (e % F4R) * 4]) = (ACT && act_ld) ? cm_gelu4(rx[u]) : rx[u];
             }
         } else {
             const float* r = reinterpret_cast<const float*>(rx);
 #pragma unroll
             for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
-                sX[buf][(e / PT) * XS + e % PT] = ACT ? cm_gelu(r[u]) : r[u];
+                sX[buf][(e / PT) * XS + e % PT] = (ACT && act_ld) ? cm_gelu(r[u]) : r[u];
             }
         }
         if constexpr (MODE == 2) {
@@ -199,14 +226,16 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             __syncthreads();
             float4 old[4], pre[DG ? 4 : 1];
             T* dst[4];
+            size_t aoff[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
-                const size_t off = ((size_t)b * p.Co + o) * p.P + p0 + c4;
-                dst[it] = yall + off;
+                const size_t off = (size_t)(o - dd.ob) * p.P + p0 + c4;
+                dst[it] = ydst + off;
+                aoff[it] = (size_t)o * p.P + p0 + c4;
                 if (p.accumulate) old[it] = io_ld4(dst[it]);
                 else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (DG) pre[it] = io_ld4(dall + off);
+                if constexpr (DG) { if (dg) pre[it] = io_ld4(dall + off); else pre[it] = make_float4(0.f, 0.f, 0.f, 0.f); }
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -220,11 +249,12 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 for (int i = 0; i < 4; ++i) {
                     if constexpr (DG) {
                         const float pr4[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
-                        r4[i] *= cm_dgelu(pr4[i]);
+                        if (dg) r4[i] *= cm_dgelu(pr4[i]);
                     }
                     w4[i] = o4[i] + r4[i];
                 }
                 io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
+                if (aall) io_store4(aall + aoff[it], cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
             }
             __syncthreads();
         }
@@ -233,26 +263,31 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     const int o = o0 + 16 * wave + r16;
     if (MODE == 2 || o < p.Co) {
         const float bv = p.bias ? p.bias[o] : 0.f;
-        T* yrow = yall + ((size_t)b * p.Co + o) * p.P;
+        T* yrow = ydst + (size_t)(o - dd.ob) * p.P;
+        T* arow = aall ? aall + (size_t)o * p.P : nullptr;
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk;
-            const T* drow = DG ? dall + ((size_t)b * p.Co + o) * p.P : nullptr;
+            const T* drow = dg ? dall + (size_t)(o - dd.ob) * p.P : nullptr;
             if (MODE == 2 || px + 3 < p.P) {
                 float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), pre = o4;
                 if (p.accumulate) o4 = io_ld4(yrow + px);
-                if constexpr (DG) pre = io_ld4(drow + px);
+                if constexpr (DG) { if (dg) pre = io_ld4(drow + px); }
                 float w4[4] = {o4.x, o4.y, o4.z, o4.w};
                 const float pr4[4] = {pre.x, pre.y, pre.z, pre.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w4[r] += (acc[mt][r] + bv) * (DG ? cm_dgelu(pr4[r]) : 1.f);
+                for (int r = 0; r < 4; ++r) w4[r] += (acc[mt][r] + bv) * (dg ? cm_dgelu(pr4[r]) : 1.f);
                 io_store4(yrow + px, w4[0], w4[1], w4[2], w4[3]);
+                if (arow) io_store4(arow + px, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (px + r < p.P)
-                        io_store1(yrow + px + r, (p.accumulate ? io_widen(yrow[px + r]) : 0.f) +
-                                                     (acc[mt][r] + bv) * (DG ? cm_dgelu(io_widen(drow[px + r])) : 1.f));
+                    if (px + r < p.P) {
+                        const float v = (p.accumulate ? io_widen(yrow[px + r]) : 0.f) +
+                                        (acc[mt][r] + bv) * (dg ? cm_dgelu(io_widen(drow[px + r])) : 1.f);
+                        io_store1(yrow + px + r, v);
+                        if (arow) io_store1(arow + px + r, cm_gelu(v));
+                    }
             }
         }
     }
@@ -308,15 +343,19 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     }
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P;
+    const int C1 = p.C1;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;
+    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;
     const bool tr = p.w_so == 1 && p.w_si != 1;
 
     float4 rx[2], rw[2];
     auto load_chunk = [&](int k0) {
+        const T* cb = k0 < C1 ? xb : xb2;
+        const int kb = k0 < C1 ? k0 : k0 - C1;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
-            rx[u] = io_ld4(xb + (unsigned)((k0 + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+            rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
             const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + 64 * u + (tid & 15) * 4)
                                      : (unsigned)((o0 + 64 * u + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
             const f4u wv = *reinterpret_cast<const f4u*>(p.w + woff);
@@ -367,6 +406,8 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     constexpr int OS = PT + 16;
     float* sO = &sX[0][0] + wave * (8 * OS);
     const int c4 = (lane & 31) * 4;
+    const CmDest<T> dd = cm_dest<T>(p, o0, b);          // a 128-channel tile lies in one destination (Co1 % 128 == 0)
+    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int ob = o0 + 64 * g + 16 * wave;
@@ -382,10 +423,12 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
             __syncthreads();
             float4 old[4];
             T* dst[4];
+            size_t aoff[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = ob + 8 * h + 2 * it + (lane >> 5);
-                dst[it] = reinterpret_cast<T*>(p.y) + ((size_t)b * p.Co + o) * p.P + p0 + c4;
+                dst[it] = dd.base + (size_t)(o - dd.ob) * p.P + p0 + c4;
+                aoff[it] = (size_t)o * p.P + p0 + c4;
                 if (p.accumulate) old[it] = io_ld4(dst[it]);
                 else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -394,7 +437,9 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
                 const int row = 2 * it + (lane >> 5);
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
                 const float bv = __shfl(bias_l, 8 * h + row);
-                io_store4(dst[it], old[it].x + (v.x + bv), old[it].y + (v.y + bv), old[it].z + (v.z + bv), old[it].w + (v.w + bv));
+                const float w0 = old[it].x + (v.x + bv), w1 = old[it].y + (v.y + bv), w2 = old[it].z + (v.z + bv), w3 = old[it].w + (v.w + bv);
+                io_store4(dst[it], w0, w1, w2, w3);
+                if (aall) io_store4(aall + aoff[it], cm_gelu(w0), cm_gelu(w1), cm_gelu(w2), cm_gelu(w3));
             }
             __syncthreads();
         }
@@ -446,25 +491,42 @@ __global__ __launch_bounds__(256) void channel_mix_few_in_kernel(ChannelMixParam
     }
 }
 
-int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s) {
+int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
+    const int B = a.B, Ci = a.Ci, Co = a.Co, bf16 = a.bf16;
+    const long long P = a.P;
+    const bool two_src = a.x2 != nullptr, two_dst = a.y2 != nullptr;
     ChannelMixParams p;
-    p.accumulate = accumulate ? 1 : 0;
-    p.dgelu_of = dgelu_of;
-    p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
+    p.accumulate = a.accumulate ? 1 : 0;
+    p.dgelu_of = a.dgelu_of;
+    p.x = a.x; p.x2 = a.x2; p.w = a.w; p.bias = a.bias; p.y = a.y; p.y2 = a.y2; p.y_act = a.y_act;
+    p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
+    p.C1 = two_src ? a.C1 : Ci;
+    p.Co1 = two_dst ? a.Co1 : Co;
     // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
-    p.w_so = transpose_w ? 1 : Ci;
-    p.w_si = transpose_w ? Co : 1;
+    p.w_so = a.transpose_w ? 1 : Ci;
+    p.w_si = a.transpose_w ? Co : 1;
     constexpr int PT = CM_PT;
+    const int act_in = a.act_in;
+    const void* dgelu_of = a.dgelu_of;
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
-    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of;
+    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0);
+    if (two_src && (p.C1 < CM_KC || p.C1 >= Ci || p.C1 % CM_KC)) {
+        set_error("channel_mix: a two-source call splits the input channels at a multiple of %d inside (0, Ci) (got %d of %d)", CM_KC, p.C1, Ci);
+        return -2;
+    }
+    if (two_dst && (p.Co1 < CM_MT || p.Co1 >= Co || p.Co1 % CM_MT)) {
+        set_error("channel_mix: a two-destination call splits the output channels at a multiple of %d inside (0, Co) (got %d of %d)", CM_MT, p.Co1, Co);
+        return -2;
+    }
+    if (a.y_act && (two_dst || dgelu_of)) { set_error("channel_mix: the activated second output goes with a single destination and no dgelu_of"); return -2; }
     const long long npt = (P + PT - 1) / PT, ncot = wide ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
-    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024) {
+    const int accumulate = p.accumulate;
+    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024 && !two_src && !two_dst && !a.y_act) {
         ProfScope prof("uno::channel_mix_few_in_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
         const dim3 grid((unsigned)((P + 1023) / 1024), B);
 #define UNO_CMF(C) do { if (bf16) hipLaunchKernelGGL((channel_mix_few_in_kernel<C, true>), grid, dim3(256), 0, s, p); \
@@ -476,8 +538,9 @@ int launch_channel_mix(const void* x, const float* w, const float* bias, void* y
         return 0;
     }
     {
+        const double dgc = dgelu_of ? p.Co1 : 0;
         ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
-                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + (dgelu_of ? Co : 0)) + 4.0 * Ci * Co, s);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0)) + 4.0 * Ci * Co, s);
         if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else {
@@ -498,6 +561,14 @@ int launch_channel_mix(const void* x, const float* w, const float* bias, void* y
     return 0;
 }
 
+int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
+                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s) {
+    ChannelMixArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.Ci = Ci; a.Co = Co; a.P = P; a.C1 = Ci; a.Co1 = Co;
+    a.transpose_w = transpose_w; a.accumulate = accumulate; a.act_in = act_in; a.dgelu_of = dgelu_of; a.bf16 = bf16;
+    return launch_channel_mix2(a, s);
+}
+
 // ------------------------------------------------------------------------------------------------ K9
 constexpr int CW_T = 64;            // tile of output channels x tile of input channels per workgroup
 constexpr int CW_PK = 32;           // pixels per staged chunk
@@ -505,7 +576,9 @@ constexpr int CW_S = CW_PK + 2;     // LDS row stride: 2 r16 + kk hits 32 distin
 
 struct ChannelWgradParams {
     const void* gy;         // (B, Co, P) f32 | bf16
-    const void* x;          // (B, Ci, P) f32 | bf16
+    const void* x;          // (B, C1, P) f32 | bf16
+    const void* x2;         // (B, Ci - C1, P): input channels [C1, Ci) of a two-source layer (vector kernel only), or nullptr
+    int C1;                 // == Ci without a second source
     float* part;            // (nsplit, Co, Ci + 1) partial sums; column Ci holds the bias gradient
     int B, Ci, Co, P, nsplit;
     int act_x;              // scalar kernel: x := gelu(x)
@@ -627,10 +700,16 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     // of a 4-byte-aligned struct the compiler split these into pairs of 8-byte loads once the registers had to stay
     // live across the MFMA block, doubling the vector-memory instructions
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // the 64 input channels of this tile lie in one source (C1 % 64 == 0 in two-source calls): xs = its tensor, Cs its channel
+    // count, il the tile's first channel inside it; the GELU-on-read form applies to the first source only
+    const bool src2 = i0 >= p.C1;
+    const T* xs = reinterpret_cast<const T*>(src2 ? p.x2 : p.x);
+    const int Cs = src2 ? p.Ci - p.C1 : p.C1, il = src2 ? i0 - p.C1 : i0;
+    const bool actx = ACTX && !src2;
     auto load_chunk = [&](int idx) {
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK;
         const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.x) + (size_t)b * p.Ci * p.P), 0, p.Ci * p.P * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (size_t)b * Cs * p.P), 0, Cs * p.P * ES, 0x00020000);
         const int px = pp + c4, pc = min(px, p.P - 4);
         sh_cur = px - pc;
 #pragma unroll
@@ -639,12 +718,12 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
             if constexpr (BF) {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 tg = __builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 2, 0, 0);
-                const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(i0 + row, p.Ci - 1) * p.P + pc) * 2, 0, 0);
+                const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(il + row, Cs - 1) * p.P + pc) * 2, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x << 16), __uint_as_float(tg.x & 0xffff0000u), __uint_as_float(tg.y << 16), __uint_as_float(tg.y & 0xffff0000u));
                 rxv[u] = make_float4(__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u), __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u));
             } else {
                 const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 4, 0, 0);
-                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(i0 + row, p.Ci - 1) * p.P + pc) * 4, 0, 0);
+                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(il + row, Cs - 1) * p.P + pc) * 4, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
                 rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
             }
@@ -662,8 +741,8 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
             const float4 g = shifted(rg[u], o0 + row < p.Co);
-            float4 v = shifted(rxv[u], i0 + row < p.Ci);
-            if constexpr (ACTX) v = cm_gelu4(v);             // gelu(0) = 0: the zero fill survives
+            float4 v = shifted(rxv[u], il + row < Cs);
+            if constexpr (ACTX) { if (actx) v = cm_gelu4(v); }             // gelu(0) = 0: the zero fill survives
             *reinterpret_cast<float4*>(sG + row * CWV_S + c4) = g;
             *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = v;
             bs[u] += (g.x + g.y) + (g.z + g.w);
@@ -829,12 +908,21 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
 
 int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          int act_x, int bf16, hipStream_t s) {
+    return launch_channel_wgrad2(gy, x, nullptr, Ci, gw, gb, ws, B, Ci, Co, P, act_x, bf16, s);
+}
+
+int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
+                          long long P, int act_x, int bf16, hipStream_t s) {
     if ((long long)(Ci > Co ? Ci : Co) * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
         set_error("channel_wgrad: tensor too large (channels * pixels must stay below 2^29)");
         return -2;
     }
+    if (x2 && (P < 64 || C1 < CW_T || C1 >= Ci || C1 % CW_T)) {
+        set_error("channel_wgrad: a two-source call needs >= 64 pixels and a split at a multiple of %d inside (0, Ci) (got %d of %d)", CW_T, C1, Ci);
+        return -2;
+    }
     ChannelWgradParams p;
-    p.gy = gy; p.x = x; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = act_x ? 1 : 0;
+    p.gy = gy; p.x = x; p.x2 = x2; p.C1 = x2 ? C1 : Ci; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = act_x ? 1 : 0;
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     p.span = (long long)cps * pk;

@@ -195,6 +195,13 @@ int launch_cdft_generic(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_resample2d(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
                       const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s);
+// K8 arguments in full: two sources (input channels [0, C1) from x, [C1, Ci) from x2), two destinations (output channels
+// [0, Co1) to y, [Co1, Co) to y2; dgelu_of goes with y), optional activated copy y_act = gelu(y); nullptr x2 / y2 / y_act = plain
+struct ChannelMixArgs {
+    const void* x; const void* x2; const float* w; const float* bias; void* y; void* y2; void* y_act; const void* dgelu_of;
+    int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
+};
+int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s);
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s);
 int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
@@ -213,5 +220,7 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          int act_x, int bf16, hipStream_t s);
+int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
+                          long long P, int act_x, int bf16, hipStream_t s);
 
 }  // namespace uno
