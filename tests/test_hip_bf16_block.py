@@ -61,6 +61,30 @@ def test_channel_mix_bf16(shape, variant):
     _cmp_bf(got, want)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 700), (2, 128, 128, 64, 515), (1, 16, 48, 128, 300)])
+def test_two_source_forms_bf16(cfg):
+    """uno_channel_mix2 / uno_channel_wgrad2 on bf16 activations == the f32 kernels on the widened inputs, rounded once."""
+    from uno_amd import _native
+    B, C1, C2, Co, P = cfg
+    g = torch.Generator().manual_seed(C1 + C2 + P)
+    x1, x2 = (_bf(torch.randn(B, c, P, generator=g)).to(dev()) for c in (C1, C2))
+    w = (torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5).to(dev())
+    b = torch.randn(Co, generator=g).to(dev())
+    for act in (False, True):
+        _cmp_bf(_native.channel_mix2(x1, x2, w, b, act_in=act), _native.channel_mix2(x1.float(), x2.float(), w, b, act_in=act))
+    y, a = _native.channel_mix2(x1, x2, w, b, y_act=True)
+    yf, af = _native.channel_mix2(x1.float(), x2.float(), w, b, y_act=True)
+    _cmp_bf(y, yf); _cmp_bf(a, af)
+    if C1 % 64 == 0:
+        gy = _bf(torch.randn(B, Co, P, generator=g)).to(dev())
+        g1, g2 = _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=C1, dgelu_of=x1)
+        f1, f2 = _native.channel_mix2(gy.float(), None, w, None, transpose_w=True, split_out=C1, dgelu_of=x1.float())
+        _cmp_bf(g1, f1); _cmp_bf(g2, f2)
+        gw, gb = _native.channel_wgrad2(gy, x1, x2, act_x=True)
+        gw2, gb2 = _native.channel_wgrad2(gy.float(), x1.float(), x2.float(), act_x=True)
+        assert rel_err(gw.cpu().numpy(), gw2.cpu().numpy()) < TOL_F and rel_err(gb.cpu().numpy(), gb2.cpu().numpy()) < TOL_F
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 64, 431 * 3), (3, 5, 7, 50), (1, 64, 64, 64 * 9 + 5), (2, 130, 20, 1000)])
 @pytest.mark.parametrize("act_x", [False, True])
 def test_channel_wgrad_bf16(shape, act_x):

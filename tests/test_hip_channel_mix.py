@@ -178,3 +178,116 @@ def test_channel_mix_cat_with_deferred_gelu():
     assert rel(y, y2.detach()) < 2e-6
     for g_, r_ in zip(got, ref):
         assert g_.shape == r_.shape and rel(g_, r_) < 2e-5
+
+
+# ------------------------------------------------------------------ two sources / two destinations / activated second output
+TWO = [
+    # B, C1, C2, Co, P
+    (2, 64, 64, 64, 446 * 9 + 3),      # fc1 of the Darcy model (cat([conv5 out, lifted]) -> 64), ragged last pixel tile
+    (2, 128, 128, 64, 223 * 7),        # conv5's 1x1 convolution on cat([conv4 out, c0])
+    (3, 16, 48, 40, 515),              # split at one 16-channel chunk, Co not a tile multiple
+    (2, 32, 16, 128, 700),             # wide (128-channel) kernel with two sources
+    (1, 64, 192, 256, 130),
+    (2, 48, 20, 33, 77),               # second source with a ragged chunk (guarded path)
+    (2, 64, 64, 64, 3),                # rows shorter than 4 pixels: scalar path
+]
+
+
+def _gelu64(t):
+    return torch.nn.functional.gelu(t.double())
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", TWO)
+@pytest.mark.parametrize("act_in", [False, True])
+def test_two_source_forward(B, C1, C2, Co, P, act_in):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + 3 * C2 + Co + P)
+    x1, x2 = torch.randn(B, C1, P, generator=g).cuda(), torch.randn(B, C2, P, generator=g).cuda()
+    w, b = torch.randn(Co, C1 + C2, generator=g).cuda(), torch.randn(Co, generator=g).cuda()
+    y = _native.channel_mix2(x1, x2, w, b, act_in=act_in)
+    ref = _ref(torch.cat([_gelu64(x1) if act_in else x1.double(), x2.double()], 1), w, b)
+    assert rel(y, ref) < 2e-6
+    base = torch.randn(B, Co, P, generator=g).cuda()
+    out = base.clone()
+    _native.channel_mix2(x1, x2, w, b, act_in=act_in, out=out, accumulate=True)
+    assert rel(out, ref + base.double()) < 2e-6
+    if not act_in:
+        y2, act = _native.channel_mix2(x1, x2, w, b, y_act=True)
+        assert torch.equal(y2, y) and rel(act, _gelu64(y)) < 2e-6
+        y1, a1 = _native.channel_mix2(x1, None, w[:, :C1].contiguous(), b, y_act=True)       # single source + activated copy
+        assert rel(y1, _ref(x1, w[:, :C1], b)) < 2e-6 and rel(a1, _gelu64(y1)) < 2e-6
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", [c for c in TWO if c[1] % 64 == 0])
+@pytest.mark.parametrize("dgelu", [False, True])
+def test_two_destination_input_gradients(B, C1, C2, Co, P, dgelu):
+    """the transposed call on grad_y: channels [0, C1) of W^T gy (optionally * gelu'(pre)) and channels [C1, C1 + C2) land in two
+    tensors from one pass; the accumulating form adds into both"""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + C2 + Co)
+    gy = torch.randn(B, Co, P, generator=g).cuda()
+    w = torch.randn(Co, C1 + C2, generator=g).cuda()
+    pre = torch.randn(B, C1, P, generator=g).cuda() if dgelu else None
+    g1, g2 = _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=C1, dgelu_of=pre)
+    ref = torch.matmul(w.double().t(), gy.double())
+    r1, r2 = ref[:, :C1], ref[:, C1:]
+    if dgelu:
+        pd = pre.double().requires_grad_(True)
+        torch.nn.functional.gelu(pd).sum().backward()
+        r1 = r1 * pd.grad
+    assert g1.shape == (B, C1, P) and g2.shape == (B, C2, P)
+    assert rel(g1, r1) < 2e-6 and rel(g2, r2) < 2e-6
+    if not dgelu:
+        b1, b2 = torch.randn(B, C1, P, generator=g).cuda(), torch.randn(B, C2, P, generator=g).cuda()
+        o1, o2 = b1.clone(), b2.clone()
+        _native.channel_mix2(gy, None, w, None, transpose_w=True, out=o1, out2=o2, split_out=C1, accumulate=True)
+        assert rel(o1, r1 + b1.double()) < 2e-6 and rel(o2, r2 + b2.double()) < 2e-6
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", [c for c in TWO if c[1] % 64 == 0 and c[4] >= 64])
+@pytest.mark.parametrize("act_x", [False, True])
+def test_two_source_wgrad(B, C1, C2, Co, P, act_x):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + C2 + Co + 1)
+    gy = torch.randn(B, Co, P, generator=g).cuda()
+    x1, x2 = torch.randn(B, C1, P, generator=g).cuda(), torch.randn(B, C2, P, generator=g).cuda()
+    gw, gb = _native.channel_wgrad2(gy, x1, x2, act_x=act_x)
+    xc = torch.cat([_gelu64(x1) if act_x else x1.double(), x2.double()], 1)
+    assert gw.shape == (Co, C1 + C2)
+    assert rel(gw, torch.einsum("bop,bip->oi", gy.double(), xc)) < 2e-5
+    assert rel(gb, gy.double().sum(dim=(0, 2))) < 2e-5
+
+
+def test_two_source_argument_errors():
+    from uno_amd import _native
+    x1, x2 = torch.randn(1, 24, 200).cuda(), torch.randn(1, 8, 200).cuda()
+    w = torch.randn(64, 32).cuda()
+    with pytest.raises(RuntimeError):            # sources split inside a 16-channel chunk
+        _native.channel_mix2(x1, x2, w, None)
+    gy = torch.randn(1, 64, 200).cuda()
+    with pytest.raises(RuntimeError):            # destinations split inside a 64-channel tile
+        _native.channel_mix2(gy, None, torch.randn(64, 100).cuda(), None, transpose_w=True, split_out=40)
+
+
+@pytest.mark.parametrize("C1,C2", [(64, 64), (24, 8), (128, 64)])
+@pytest.mark.parametrize("gelu_first", [False, True])
+def test_channel_mix_cat_autograd_vs_torch(C1, C2, gelu_first):
+    """channel_mix_cat (fused two-source kernels where the split rules allow, two accumulating calls otherwise) against
+    F.conv1d on the concatenation in float64: output, both input gradients, weight and bias gradients."""
+    from uno_amd.integral_operators import channel_mix_cat
+    torch.manual_seed(C1 + C2)
+    B, Co, P = 2, 64, 1000
+    x1 = torch.randn(B, C1, P).cuda().requires_grad_(True)
+    x2 = torch.randn(B, C2, P).cuda().requires_grad_(True)
+    w = torch.randn(Co, C1 + C2).cuda().requires_grad_(True)
+    b = torch.randn(Co).cuda().requires_grad_(True)
+    gy = torch.randn(B, Co, P).cuda()
+    y = channel_mix_cat([x1, x2], w, b, gelu_first=gelu_first)
+    y.backward(gy)
+    xd1, xd2, wd, bd = (t.detach().double().requires_grad_(True) for t in (x1, x2, w, b))
+    a1 = torch.nn.functional.gelu(xd1) if gelu_first else xd1
+    yr = torch.matmul(wd, torch.cat([a1, xd2], 1)) + bd.view(1, -1, 1)
+    yr.backward(gy.double())
+    assert rel(y.detach(), yr.detach()) < 2e-6
+    assert rel(x1.grad, xd1.grad) < 2e-6 and rel(x2.grad, xd2.grad) < 2e-6
+    assert rel(w.grad, wd.grad) < 2e-5 and rel(b.grad, bd.grad) < 2e-5

@@ -31,7 +31,7 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 __all__ = [
-    "enable_mixed_precision",
+    "enable_mixed_precision", "GradJoin",
     "SpectralConv1d_Uno", "pointwise_op_1D", "OperatorBlock_1D",
     "SpectralConv2d_Uno", "pointwise_op_2D", "OperatorBlock_2D",
     "SpectralConv3d_Uno", "pointwise_op_3D", "OperatorBlock_3D",
@@ -149,6 +149,99 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     return y.view(B, w.shape[0], *x.shape[2:])
 
 
+class GradJoin:
+    """One gradient buffer for a tensor with TWO consumers (a skip connection: reference darcy_flow_uno2d.py:117-127 feeds `x_c0`
+    to conv1 and, concatenated, to conv5; `x_fc0` to conv0 and to fc1) instead of two gradient tensors and an element-wise sum.
+
+    The consumer that comes LATER in the forward pass (its backward runs first) is called with `defer_grad=join`: its backward does
+    not materialise its contribution; it leaves (a) its truncated gradient spectrum for that input - the inverse transform is
+    linear, two spectra on one grid are added in the (tiny) spectral domain and transformed ONCE - and (b) closures that accumulate
+    its point-wise contribution into a given buffer.  The consumer that comes FIRST in the forward pass (`join=join`; its backward
+    runs last - it depends on everything downstream of its output) merges the spectra into its own before the inverse transform,
+    then lets the closures accumulate into its gradient buffer, and returns the complete gradient.  The deferring consumer returns
+    None for that input.  Used by the harness models; without a join object every layer behaves as before."""
+
+    def __init__(self):
+        self.owner = False          # set by the first consumer's forward when it will produce the joined gradient
+        self.spectra = []           # (gX (B, C, 2 m1, m2) c64, grid (H, W)) left by deferring consumers
+        self.pending = []           # callables(out: (B, C, H, W) tensor) accumulating into out
+
+    def reset(self):
+        self.owner = False
+        self.spectra, self.pending = [], []
+
+    def can_defer(self, x):
+        return self.owner and x.requires_grad
+
+    def merge(self, gX, grid):
+        """own gradient spectrum (B, C, 2 m1, m2) + the deferred ones, embedded by frequency into the largest mode box"""
+        if not self.spectra:
+            return gX
+        specs = [gX] + [s for s, g in self.spectra if g == tuple(grid)]
+        if len(specs) != len(self.spectra) + 1:
+            raise RuntimeError("GradJoin: a deferred gradient spectrum belongs to another grid")
+        M1 = max(s.shape[2] // 2 for s in specs)
+        M2 = max(s.shape[3] for s in specs)
+        base = next((s for s in specs[1:] if s.shape[2] // 2 == M1 and s.shape[3] == M2), None)   # a deferred copy is ours to modify
+        if base is None:
+            base = torch.zeros((*gX.shape[:2], 2 * M1, M2), dtype=gX.dtype, device=gX.device)
+        for s in specs:
+            if s is base:
+                continue
+            m1, m2 = s.shape[2] // 2, s.shape[3]
+            base[:, :, :m1, :m2] += s[:, :, :m1]                         # frequencies 0 .. m1 - 1
+            base[:, :, 2 * M1 - m1:, :m2] += s[:, :, m1:]                # frequencies -m1 .. -1
+        self.spectra = []
+        return base
+
+    def apply(self, out):
+        for fn in self.pending:
+            fn(out)
+        self.pending = []
+
+
+# ---- a layer on the channel concatenation of two tensors, never built: one pass over every operand where the kernels' split
+# rules allow (csrc/channel_mix.hip: sources split at a multiple of 16 channels, destinations / weight-gradient tiles at 64),
+# two accumulating calls otherwise
+def _mix2_forward(x1, x2, w, bias, act_in=False, out=None, accumulate=False):
+    """Wm . cat(x1, x2) + bias -> (B, Co, P); w (Co, C1 + C2).  out + accumulate: out += ..."""
+    C1 = x1.shape[1]
+    if C1 % 16 == 0:
+        return _native.channel_mix2(x1, x2, w, bias, act_in=act_in, out=out, accumulate=accumulate)
+    w1, w2 = w[:, :C1].contiguous(), w[:, C1:].contiguous()
+    if out is None:
+        out = _native.channel_mix(x1, w1, bias, act_in=act_in)
+    elif accumulate:
+        _native.channel_mix(x1, w1, bias, act_in=act_in, out=out)        # out= of the one-source call accumulates
+    else:
+        out.copy_(_native.channel_mix(x1, w1, bias, act_in=act_in))
+    _native.channel_mix(x2, w2, None, out=out)
+    return out
+
+
+def _mix2_input_grads(gy, w, C1, dgelu_of=None, out1=None, out2=None):
+    """(W[:, :C1]^T gy [* gelu'(dgelu_of)], W[:, C1:]^T gy) from one read of gy; out1 / out2: accumulate into these."""
+    if C1 % 64 == 0 and (w.shape[1] - C1) >= 1:
+        if out1 is not None and out2 is not None:
+            _native.channel_mix2(gy, None, w, None, transpose_w=True, out=out1, out2=out2, split_out=C1, dgelu_of=dgelu_of, accumulate=True)
+            return out1, out2
+        if out1 is None and out2 is None:
+            return _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=C1, dgelu_of=dgelu_of)
+    w1, w2 = w[:, :C1].contiguous(), w[:, C1:].contiguous()
+    g1 = _native.channel_mix(gy, w1, None, transpose_w=True, dgelu_of=dgelu_of, out=out1)
+    g2 = _native.channel_mix(gy, w2, None, transpose_w=True, out=out2)
+    return g1, g2
+
+
+def _mix2_wgrad(gy, x1, x2, need_bias, act_x=False):
+    """gw (Co, C1 + C2), gb of a two-source layer."""
+    if x1.shape[1] % 64 == 0 and gy.shape[2] >= 64:
+        return _native.channel_wgrad2(gy, x1, x2, need_bias=need_bias, act_x=act_x)
+    gw1, gb = _native.channel_wgrad(gy, x1, need_bias=need_bias, act_x=act_x)
+    gw2, _ = _native.channel_wgrad(gy, x2, need_bias=False)
+    return torch.cat([gw1, gw2], dim=1), gb
+
+
 class _ChannelMixCatFn(torch.autograd.Function):
     """y[b] = W . cat(a1[b], x2[b]) + bias without the concatenation: W[:, :C1] . a1 writes y, W[:, C1:] . x2
     accumulates into it; the input gradients come out as two contiguous tensors (no strided slices of a joint one).
@@ -156,45 +249,54 @@ class _ChannelMixCatFn(torch.autograd.Function):
     call returns the gradient of x1 itself (its epilogue multiplies by gelu'(x1)): the activation tensor never exists."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, gelu_first):
-        x1, x2 = _plain(x1), _plain(x2)
-        C1 = x1.shape[1]
-        w1, w2 = w[:, :C1].contiguous(), w[:, C1:].contiguous()
-        y = _native.channel_mix(x1, w1, None if bias is None else _plain(bias), act_in=gelu_first)
-        _native.channel_mix(x2, w2, None, out=y)
-        ctx.save_for_backward(x1, x2, w1, w2)
+    def forward(ctx, x1, x2, w, bias, gelu_first, defer=None, grid=None):
+        x1, x2, w = _plain(x1), _plain(x2), _plain(w)
+        y = _mix2_forward(x1, x2, w, None if bias is None else _plain(bias), act_in=gelu_first)
+        ctx.save_for_backward(x1, x2, w)
         ctx.has_bias = bias is not None
         ctx.gelu_first = gelu_first
+        ctx.defer = defer if (defer is not None and defer.can_defer(x2)) else None
+        ctx.grid = grid
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x1, x2, w1, w2 = ctx.saved_tensors
+        x1, x2, w = ctx.saved_tensors
         gy = _plain(gy)
+        C1 = x1.shape[1]
         g1 = g2 = None
-        if ctx.needs_input_grad[0]:
-            g1 = _native.channel_mix(gy, w1, None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
-        if ctx.needs_input_grad[1]:
-            g2 = _native.channel_mix(gy, w2, None, transpose_w=True)
+        if ctx.defer is not None and ctx.needs_input_grad[1]:
+            # x2's gradient is accumulated later into the buffer of x2's other consumer (GradJoin): no tensor, no sum
+            if ctx.needs_input_grad[0]:
+                g1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
+            w2 = w[:, C1:].contiguous()
+            B, C2 = x2.shape[0], x2.shape[1]
+            ctx.defer.pending.append(lambda out: _native.channel_mix(gy, w2, None, transpose_w=True, out=out.view(B, C2, -1)))
+        elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            g1, g2 = _mix2_input_grads(gy, w, C1, dgelu_of=x1 if ctx.gelu_first else None)
+        elif ctx.needs_input_grad[0]:
+            g1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
+        elif ctx.needs_input_grad[1]:
+            g2 = _native.channel_mix(gy, w[:, C1:].contiguous(), None, transpose_w=True)
         gw = gb = None
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            gw1, gb = _native.channel_wgrad(gy, x1, need_bias=ctx.has_bias, act_x=ctx.gelu_first)
-            gw2, _ = _native.channel_wgrad(gy, x2, need_bias=False)
-            gw = torch.cat([gw1, gw2], dim=1)
-        return g1, g2, gw, gb, None
+            gw, gb = _mix2_wgrad(gy, x1, x2, ctx.has_bias, act_x=ctx.gelu_first)
+        return g1, g2, gw, gb, None, None, None
 
 
-def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_first: bool = False) -> torch.Tensor:
+def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_first: bool = False, defer_grad=None) -> torch.Tensor:
     """channel_mix(torch.cat(xs, dim=1), weight, bias) - the projection after a skip connection (reference
     darcy_flow_uno2d.py:122-127: `torch.cat([x_c5, x_fc0], dim=1)` then `fc1`) - without materialising the
     concatenation when there are two float32 device tensors.  gelu_first: xs[0] is a PRE-activation tensor and stands
-    for gelu(xs[0]) (the block in front deferred its GELU to this consumer)."""
+    for gelu(xs[0]) (the block in front deferred its GELU to this consumer).  defer_grad: a GradJoin whose owner is xs[1]'s other
+    consumer - xs[1]'s gradient is then accumulated into that consumer's buffer (fused device path only)."""
     if len(xs) == 2 and all(_dev_act(x) for x in xs) and xs[0].dtype == xs[1].dtype and weight.dtype == torch.float32:
         x1, x2 = xs
         B = x1.shape[0]
         w = weight.reshape(weight.shape[0], -1)
-        y = _ChannelMixCatFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias, bool(gelu_first))
+        y = _ChannelMixCatFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias, bool(gelu_first),
+                                   defer_grad, tuple(x2.shape[2:]))
         return y.view(B, w.shape[0], *x1.shape[2:])
     xs = list(xs)
     if gelu_first:
@@ -335,8 +437,17 @@ class _OperatorBlock2dFn(torch.autograd.Function):
     separate element-wise pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo, half_weights=False):
+    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo, half_weights=False, fuse_gelu=False, join=None):
+        """fuse_gelu (blocks with Non_Lin and no normalisation, reference integral_operators.py:282-283): returns gelu(s); where the
+        channel mix is the kernel that completes s (no up-sampling) it writes the activation in the same pass.
+        join: GradJoin of x - this block is x's FIRST consumer and returns x's complete gradient (see GradJoin)."""
         from .resample import resample_forward
+        ctx.join = None
+        if join is not None:
+            join.reset()
+            if x.requires_grad:
+                join.owner = True
+                ctx.join = join
         x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
         if half_weights:
             w1, w2 = _half_weights(w1, w2)
@@ -347,30 +458,51 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo)
         same = (H, W) == (Ho, Wo)
         mix_last = same or Ho * Wo < H * W          # the 1x1 convolution runs on whichever side has fewer pixels
+        out = s
         if mix_last:
             act = x if same else resample_forward(x, Ho, Wo)
-            _native.channel_mix(act.view(B, Ci, -1), cwm, cb, out=s.view(B, Co, -1))
+            if fuse_gelu:
+                _, out = _native.channel_mix2(act.view(B, Ci, -1), None, cwm, cb, out=s.view(B, Co, -1), accumulate=True, y_act=True)
+                out = out.view(B, Co, Ho, Wo)
+            else:
+                _native.channel_mix(act.view(B, Ci, -1), cwm, cb, out=s.view(B, Co, -1))
         else:
             act = x
             t = _native.channel_mix(x.view(B, Ci, -1), cwm, cb)
             resample_forward(t.view(B, Co, H, W), Ho, Wo, out=s)
-        ctx.save_for_backward(xt, w1, w2, cwm, act)
+            if fuse_gelu:
+                out = F.gelu(s)
+        ctx.save_for_backward(xt, w1, w2, cwm, act, s if fuse_gelu else None)
         ctx.geom = (H, W, same, mix_last, cb is not None, tuple(cw.shape))
-        return s
+        return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gs):
         from .resample import resample_adjoint
-        xt, w1, w2, cwm, act = ctx.saved_tensors
+        xt, w1, w2, cwm, act, pre = ctx.saved_tensors
         H, W, same, mix_last, has_bias, cw_shape = ctx.geom
         gs = _plain(gs)
+        if pre is not None:                 # the block's GELU: gradient at the pre-activation sum
+            gs = torch.ops.aten.gelu_backward(gs, pre)
         B, Co, Ho, Wo = gs.shape
         Ci = cwm.shape[1]
         need_gx = ctx.needs_input_grad[0]
         need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need_gc = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
-        gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw)
+        join = ctx.join
+        if join is not None and need_gx and join.spectra:
+            # stage by stage: the deferred gradient spectra of x's other consumer are added to this block's before ONE inverse transform
+            m1, m2 = w1.shape[2], w1.shape[3]
+            gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)
+            gw1 = gw2 = None
+            if need_gw:
+                gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2)
+            gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
+            gX = join.merge(gX, (H, W))
+            gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype)
+        else:
+            gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw)
         gcw = gcb = None
         if mix_last:
             # forward: act = R x;  s += Wm act + b
@@ -391,7 +523,11 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                 gcw, gcb = _native.channel_wgrad(g_t, act.view(B, Ci, -1), need_bias=has_bias)
         if gcw is not None:
             gcw = gcw.view(cw_shape)
-        return gx, gw1, gw2, gcw, gcb, None, None, None
+        if join is not None:
+            if need_gx:
+                join.apply(gx)              # the point-wise contributions of x's other consumer accumulate into this buffer
+            join.reset()
+        return gx, gw1, gw2, gcw, gcb, None, None, None, None, None
 
 
 class _OperatorBlock2dCatFn(torch.autograd.Function):
@@ -402,8 +538,9 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
     of a joint gradient to copy or accumulate)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo, half_weights=False):
+    def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo, half_weights=False, defer=None):
         from .resample import resample_forward
+        ctx.defer = defer if (defer is not None and defer.can_defer(x2)) else None
         x1, x2, w1, w2 = _plain(x1), _plain(x2), _plain(w1), _plain(w2)
         B, C1, H, W = x1.shape
         C2 = x2.shape[1]
@@ -411,7 +548,6 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         if half_weights:
             w1, w2 = _half_weights(w1, w2)
         cwm = _plain(cw).reshape(Co, Ci)
-        cwa, cwb = cwm[:, :C1].contiguous(), cwm[:, C1:].contiguous()
         cb = None if cb is None else _plain(cb)
         # spectral branch, stage by stage (the composite entry point takes a single source)
         xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x1.device)
@@ -425,15 +561,12 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         if mix_last:
             a1 = x1 if same else resample_forward(x1, Ho, Wo)
             a2 = x2 if same else resample_forward(x2, Ho, Wo)
-            sv = s.view(B, Co, -1)
-            _native.channel_mix(a1.view(B, C1, -1), cwa, cb, out=sv)
-            _native.channel_mix(a2.view(B, C2, -1), cwb, None, out=sv)
+            _mix2_forward(a1.view(B, C1, -1), a2.view(B, C2, -1), cwm, cb, out=s.view(B, Co, -1), accumulate=True)
         else:
             a1, a2 = x1, x2
-            t = _native.channel_mix(x1.view(B, C1, -1), cwa, cb)
-            _native.channel_mix(x2.view(B, C2, -1), cwb, None, out=t)
+            t = _mix2_forward(x1.view(B, C1, -1), x2.view(B, C2, -1), cwm, cb)
             resample_forward(t.view(B, Co, H, W), Ho, Wo, out=s)
-        ctx.save_for_backward(xt, w1, w2, cwa, cwb, a1, a2)
+        ctx.save_for_backward(xt, w1, w2, cwm, a1, a2)
         ctx.geom = (H, W, same, mix_last, cb is not None, tuple(cw.shape))
         return s
 
@@ -441,7 +574,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gs):
         from .resample import resample_adjoint
-        xt, w1, w2, cwa, cwb, a1, a2 = ctx.saved_tensors
+        xt, w1, w2, cwm, a1, a2 = ctx.saved_tensors
         H, W, same, mix_last, has_bias, cw_shape = ctx.geom
         gs = _plain(gs)
         B, Co, Ho, Wo = gs.shape
@@ -455,34 +588,71 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         if need_gw:
             gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2)
         gx1 = gx2 = None
+        defer = ctx.defer if need2 else None
         if need1 or need2:
             gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
             if need1:
                 gx1 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C1, channel_offset=0, dtype=gs.dtype)
-            if need2:
+            if defer is not None:
+                # x2's gradient is completed by x2's first consumer (GradJoin): leave the spectrum, transform nothing
+                defer.spectra.append((gX[:, C1:].contiguous(), (H, W)))
+            elif need2:
                 gx2 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C2, channel_offset=C1, dtype=gs.dtype)
         gcw = gcb = None
+        both = gx1 is not None and gx2 is not None
+        if defer is not None:
+            # point-wise part of x2's gradient: accumulated into the joined buffer later; x1's part now
+            cw2 = cwm[:, C1:].contiguous()
+            if mix_last:
+                g_src = gs.view(B, Co, -1)
+                if same:
+                    defer.pending.append(lambda out: _native.channel_mix(g_src, cw2, None, transpose_w=True, out=out.view(B, C2, -1)))
+                else:
+                    defer.pending.append(lambda out: resample_adjoint(
+                        _native.channel_mix(g_src, cw2, None, transpose_w=True).view(B, C2, Ho, Wo), H, W, out=out))
+            else:
+                g_src = resample_adjoint(gs, H, W).view(B, Co, -1)
+                defer.pending.append(lambda out: _native.channel_mix(g_src, cw2, None, transpose_w=True, out=out.view(B, C2, -1)))
+            if gx1 is not None:
+                cw1 = cwm[:, :C1].contiguous()
+                if mix_last and not same:
+                    resample_adjoint(_native.channel_mix(g_src, cw1, None, transpose_w=True).view(B, C1, Ho, Wo), H, W, out=gx1)
+                else:
+                    _native.channel_mix(g_src, cw1, None, transpose_w=True, out=gx1.view(B, C1, -1))
+            if need_gc:
+                gcw, gcb = _mix2_wgrad(g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), has_bias)
+                gcw = gcw.view(cw_shape)
+            return gx1, None, gw1, gw2, gcw, gcb, None, None, None, None
         if mix_last:
             g_src = gs.view(B, Co, -1)
-            for gx, cwx, Cx in ((gx1, cwa, C1), (gx2, cwb, C2)):
-                if gx is None:
-                    continue
-                if same:
-                    _native.channel_mix(g_src, cwx, None, transpose_w=True, out=gx.view(B, Cx, -1))
-                else:
-                    g_act = _native.channel_mix(g_src, cwx, None, transpose_w=True)
-                    resample_adjoint(g_act.view(B, Cx, Ho, Wo), H, W, out=gx)
+            if both and same:
+                _mix2_input_grads(g_src, cwm, C1, out1=gx1.view(B, C1, -1), out2=gx2.view(B, C2, -1))
+            elif both:
+                g_a1, g_a2 = _mix2_input_grads(g_src, cwm, C1)
+                resample_adjoint(g_a1.view(B, C1, Ho, Wo), H, W, out=gx1)
+                resample_adjoint(g_a2.view(B, C2, Ho, Wo), H, W, out=gx2)
+            else:
+                for gx, cwx, Cx in ((gx1, cwm[:, :C1], C1), (gx2, cwm[:, C1:], C2)):
+                    if gx is None:
+                        continue
+                    if same:
+                        _native.channel_mix(g_src, cwx.contiguous(), None, transpose_w=True, out=gx.view(B, Cx, -1))
+                    else:
+                        g_act = _native.channel_mix(g_src, cwx.contiguous(), None, transpose_w=True)
+                        resample_adjoint(g_act.view(B, Cx, Ho, Wo), H, W, out=gx)
         else:
             g_src = resample_adjoint(gs, H, W).view(B, Co, -1)
-            if gx1 is not None:
-                _native.channel_mix(g_src, cwa, None, transpose_w=True, out=gx1.view(B, C1, -1))
-            if gx2 is not None:
-                _native.channel_mix(g_src, cwb, None, transpose_w=True, out=gx2.view(B, C2, -1))
+            if both:
+                _mix2_input_grads(g_src, cwm, C1, out1=gx1.view(B, C1, -1), out2=gx2.view(B, C2, -1))
+            else:
+                if gx1 is not None:
+                    _native.channel_mix(g_src, cwm[:, :C1].contiguous(), None, transpose_w=True, out=gx1.view(B, C1, -1))
+                if gx2 is not None:
+                    _native.channel_mix(g_src, cwm[:, C1:].contiguous(), None, transpose_w=True, out=gx2.view(B, C2, -1))
         if need_gc:
-            gwa, gcb = _native.channel_wgrad(g_src, a1.view(B, C1, -1), need_bias=has_bias)
-            gwb, _ = _native.channel_wgrad(g_src, a2.view(B, C2, -1), need_bias=False)
-            gcw = torch.cat([gwa, gwb], dim=1).view(cw_shape)
-        return gx1, gx2, gw1, gw2, gcw, gcb, None, None, None
+            gcw, gcb = _mix2_wgrad(g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), has_bias)
+            gcw = gcw.view(cw_shape)
+        return gx1, gx2, gw1, gw2, gcw, gcb, None, None, None, None
 
 
 def spectral_conv2d(x, weights1, weights2, dim1, dim2):
@@ -616,15 +786,16 @@ class OperatorBlock_2D(nn.Module):
         if Normalize:
             self.normalize_layer = nn.InstanceNorm2d(int(out_codim), affine=True)
 
-    def forward(self, x, dim1=None, dim2=None):
-        out = self._branches(x, dim1, dim2)
+    def forward(self, x, dim1=None, dim2=None, join=None):
+        """join (optional, beyond the reference signature): a GradJoin of x when x has a second consumer further down the network."""
+        if self.non_lin and not self.normalize:
+            return self._branches(x, dim1, dim2, gelu=True, join=join)
+        out = self._branches(x, dim1, dim2, join=join)
         if self.normalize:
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
-        if self.non_lin:
-            out = F.gelu(out)
         return out
 
-    def forward_cat(self, xs, dim1=None, dim2=None, defer_gelu=False):
+    def forward_cat(self, xs, dim1=None, dim2=None, defer_gelu=False, defer_grad=None):
         """self(torch.cat(xs, dim=1), dim1, dim2) for a skip connection (reference darcy_flow_uno2d.py:117-125) - two
         float32 device tensors are consumed in place, the concatenation is never built.  defer_gelu (blocks without
         normalisation only): return the PRE-activation sum; the caller's consumer applies the GELU as it reads it."""
@@ -645,14 +816,15 @@ class OperatorBlock_2D(nn.Module):
         if dim1 is not None:
             conv.dim1, conv.dim2 = dim1, dim2
         out = _OperatorBlock2dCatFn.apply(xs[0], xs[1], conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2),
-                                          xs[0].dtype == torch.bfloat16)
+                                          xs[0].dtype == torch.bfloat16, defer_grad)
         if defer_gelu:
             return out
         if self.normalize:
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
         return F.gelu(out) if self.non_lin else out
 
-    def _branches(self, x, dim1, dim2):
+    def _branches(self, x, dim1, dim2, gelu=False, join=None):
+        """conv(x) + w(x) [then GELU when `gelu`: written by the kernel that completes the sum where the fused path runs]"""
         conv, w = self.conv, self.w
         if dim1 is not None:        # the spectral layer keeps a call-time override, the point-wise one does not (:182-184, :236-238)
             conv.dim1, conv.dim2 = dim1, dim2
@@ -662,9 +834,10 @@ class OperatorBlock_2D(nn.Module):
         fused = (self._takes(x) and (conv.dim1, conv.dim2) == (d1, d2)
                  and x.shape[1] == conv.in_channels and w.conv.weight.dtype == torch.float32)
         if not fused:               # CPU tensors raise inside the spectral layer; mismatched grids raise at the sum
-            return conv(x) + w(x, d1, d2)
+            out = conv(x) + w(x, d1, d2)
+            return F.gelu(out) if gelu else out
         return _OperatorBlock2dFn.apply(x, conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2),
-                                        x.dtype == torch.bfloat16)
+                                        x.dtype == torch.bfloat16, bool(gelu), join)
 
     def _takes(self, x):
         """4-D device tensor the fused block kernels take: float32, or bfloat16 once the spectral layer is in mixed-precision mode."""
