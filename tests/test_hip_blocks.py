@@ -239,3 +239,41 @@ def test_forward_cat_equals_block_of_concatenation(hw, out_hw, normalize):
     # call-time grid override goes through the same path and persists on the spectral layer, as in forward()
     y3 = blk.forward_cat([a, b], out_hw[0] + 2, out_hw[1] + 1)
     assert y3.shape[-2:] == (out_hw[0] + 2, out_hw[1] + 1) and (blk.conv.dim1, blk.conv.dim2) == (out_hw[0] + 2, out_hw[1] + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(24, 24, 5), (24, 12, 4), (12, 24, 4)], ids=["same", "down", "up"])
+def test_grad_join_equals_the_summed_gradients(geom):
+    """A tensor with two consumers (skip connection): with a GradJoin the later consumer (two-source block / two-source channel mix)
+    leaves its contribution - spectrum + accumulating closures - to the first consumer, which returns the complete gradient.
+    Same gradients as autograd's sum of two gradient tensors (all three resampling directions of the deferring block, different
+    mode counts in the two blocks)."""
+    from uno_amd.integral_operators import GradJoin, OperatorBlock_2D, channel_mix_cat
+    torch.manual_seed(3)
+    S, So, mB = geom
+    B, C = 2, 64
+    blkA = OperatorBlock_2D(C, 32, 16, 16, 3, 3, Normalize=True).to(dev())            # first consumer of x (modes 3)
+    blkB = OperatorBlock_2D(2 * C, 64, So, So, mB, mB).to(dev())                      # later consumer: block on cat([z, x]) (modes mB)
+    fc = torch.nn.Linear(64 + C, 64).to(dev())                                        # later consumer: channel mix on cat([u, x])
+    x0 = torch.randn(B, C, S, S, device=dev())
+    z0 = torch.randn(B, C, S, S, device=dev())
+    u0 = torch.randn(B, 64, S, S, device=dev())
+    res = {}
+    for mode in ("plain", "join"):
+        x, z, u = (t.clone().requires_grad_(True) for t in (x0, z0, u0))
+        for m in (blkA, blkB, fc):
+            m.zero_grad(set_to_none=True)
+        xa = x * 1.0                                                                    # x itself is a leaf: the joined tensor is xa
+        jb, jf = (GradJoin(), GradJoin()) if mode == "join" else (None, None)
+        a1 = blkA(xa, 16, 16, join=jb)
+        b = blkB.forward_cat([z, xa], So, So, defer_gelu=True, defer_grad=jb)
+        loss = a1.square().sum() + b.sin().sum()
+        xb = x * 2.0
+        a3 = blkA(xb, 16, 16, join=jf)
+        c = channel_mix_cat([u, xb], fc.weight, fc.bias, gelu_first=True, defer_grad=jf)
+        loss = loss + a3.cos().sum() + c.square().sum()
+        loss.backward()
+        res[mode] = [x.grad.clone(), z.grad.clone(), u.grad.clone()] + [p.grad.clone() for m in (blkA, blkB, fc) for p in m.parameters()]
+    for a, b in zip(res["plain"], res["join"]):
+        ar, br = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
+        assert float((ar - br).norm()) <= 2e-5 * float(ar.norm()) + 1e-12

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import (OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, gelu_channel_mix, gelu_pad2d,
+from ..integral_operators import (GradJoin, OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, gelu_channel_mix, gelu_pad2d,
                                   gelu_project)
 
 
@@ -62,17 +62,26 @@ class UNO_9(nn.Module):
         lifted = gelu_pad2d(lifted, margin, margin)            # gelu, then pad the end of both axes
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
 
-        c0 = self.conv0(lifted, d1 // 2, d2 // 2)
-        c1 = self.conv1(c0, d1 // 4, d2 // 4)
-        c2 = self.conv2(c1, d1 // 4, d2 // 4)
-        # skip connections: conv5 consumes cat([conv4 output, c0]) and fc1 cat([conv5 output, lifted]) from their two
-        # sources; the concatenations are never built
-        skip5 = [self.conv4(c2, d1 // 2, d2 // 2), c0]
-        if hasattr(self.conv5, "forward_cat") and self.conv5.non_lin and not self.conv5.normalize:
-            # conv5's GELU is deferred to its only consumer: fc1 applies it while reading the pre-activation tensor
-            c5 = channel_mix_cat([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True), lifted], self.fc1.weight, self.fc1.bias,
-                                 gelu_first=True)
+        product = hasattr(self.conv5, "forward_cat")          # MI355X operator blocks (the CPU baseline builds the model on oracle blocks)
+        if product and self.conv5.non_lin and not self.conv5.normalize:
+            # `lifted` and `c0` feed two layers each (skip connections).  Their gradients are JOINED: the later consumer leaves its
+            # contribution (a truncated spectrum + accumulating closures) to the first consumer, which transforms the summed spectrum
+            # once and returns the complete gradient - no second gradient tensor, no element-wise sum (GradJoin)
+            jl, jc = GradJoin(), GradJoin()
+            c0 = self.conv0(lifted, d1 // 2, d2 // 2, join=jl)
+            c1 = self.conv1(c0, d1 // 4, d2 // 4, join=jc)
+            c2 = self.conv2(c1, d1 // 4, d2 // 4)
+            # skip connections: conv5 consumes cat([conv4 output, c0]) and fc1 cat([conv5 output, lifted]) from their two
+            # sources; the concatenations are never built.  conv5's GELU is deferred to its only consumer: fc1 applies it while
+            # reading the pre-activation tensor
+            skip5 = [self.conv4(c2, d1 // 2, d2 // 2), c0]
+            c5 = channel_mix_cat([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True, defer_grad=jc), lifted], self.fc1.weight,
+                                 self.fc1.bias, gelu_first=True, defer_grad=jl)
         else:
+            c0 = self.conv0(lifted, d1 // 2, d2 // 2)
+            c1 = self.conv1(c0, d1 // 4, d2 // 4)
+            c2 = self.conv2(c1, d1 // 4, d2 // 4)
+            skip5 = [self.conv4(c2, d1 // 2, d2 // 2), c0]
             c5 = channel_mix_cat([_block_cat(self.conv5, skip5, d1, d2), lifted], self.fc1.weight, self.fc1.bias)
         out = gelu_project(c5, self.fc2.weight, self.fc2.bias)
         return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()     # crop the padding, back to (B, S, S, 1) (one channel: tiny)

@@ -170,9 +170,6 @@ class GradJoin:
         self.owner = False
         self.spectra, self.pending = [], []
 
-    def can_defer(self, x):
-        return self.owner and x.requires_grad
-
     def merge(self, gX, grid):
         """own gradient spectrum (B, C, 2 m1, m2) + the deferred ones, embedded by frequency into the largest mode box"""
         if not self.spectra:
@@ -255,7 +252,7 @@ class _ChannelMixCatFn(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, w)
         ctx.has_bias = bias is not None
         ctx.gelu_first = gelu_first
-        ctx.defer = defer if (defer is not None and defer.can_defer(x2)) else None
+        ctx.defer = defer if (defer is not None and defer.owner and ctx.needs_input_grad[1]) else None
         ctx.grid = grid
         return y
 
@@ -266,7 +263,7 @@ class _ChannelMixCatFn(torch.autograd.Function):
         gy = _plain(gy)
         C1 = x1.shape[1]
         g1 = g2 = None
-        if ctx.defer is not None and ctx.needs_input_grad[1]:
+        if ctx.defer is not None and ctx.defer.owner and ctx.needs_input_grad[1]:     # owner still pending: its backward has not run yet
             # x2's gradient is accumulated later into the buffer of x2's other consumer (GradJoin): no tensor, no sum
             if ctx.needs_input_grad[0]:
                 g1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
@@ -445,7 +442,7 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         ctx.join = None
         if join is not None:
             join.reset()
-            if x.requires_grad:
+            if ctx.needs_input_grad[0]:
                 join.owner = True
                 ctx.join = join
         x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
@@ -540,7 +537,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo, half_weights=False, defer=None):
         from .resample import resample_forward
-        ctx.defer = defer if (defer is not None and defer.can_defer(x2)) else None
+        ctx.defer = defer if (defer is not None and defer.owner and ctx.needs_input_grad[1]) else None
         x1, x2, w1, w2 = _plain(x1), _plain(x2), _plain(w1), _plain(w2)
         B, C1, H, W = x1.shape
         C2 = x2.shape[1]
@@ -588,7 +585,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         if need_gw:
             gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2)
         gx1 = gx2 = None
-        defer = ctx.defer if need2 else None
+        defer = ctx.defer if (need2 and ctx.defer is not None and ctx.defer.owner) else None    # owner's backward still to come
         if need1 or need2:
             gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
             if need1:
