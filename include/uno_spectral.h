@@ -140,6 +140,14 @@ int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int
 /* gw[c][i,o] = sum_b conj(xtrunc[b,i]) * go[b,o] per mode. */
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co,
                    int ncorner, int modes_per_corner, void* stream);
+/* uno_mode_wgrad with accumulate != 0: gw[c] += (in-place accumulation into a parameter's gradient buffer). */
+int uno_mode_wgrad_acc(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
+                       int modes_per_corner, int accumulate, void* stream);
+/* uno_spectral_conv2d_backward in all three storage formats (io_format 0: f32 images; 1: bf16 images; 2: bf16 images + fp16 (re, im)
+ * weights) with accumulate_gw != 0: gw1 / gw2 += instead of =. */
+int uno_spectral_conv2d_backward_acc(const void* gy, const float* xtrunc, const void* w1, const void* w2, void* gx,
+                                     float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                     int m1, int m2, int io_format, int accumulate_gw, void* stream);
 
 /* Separable banded resampling out = A . in . B^T of n_img images (H, W) -> (Ho, Wo): the resampling half of
  * pointwise_op_2D (reference integral_operators.py:240-242, bicubic / align_corners / antialias) and, with the
@@ -186,12 +194,13 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
  *   y_act (B, Co, P) or NULL: additionally receives gelu(y) - the activation of a block without normalisation written by the
  *   kernel that completes the pre-activation sum (reference integral_operators.py:282-283), single destination only.
  * Splits must be multiples of 16 (C1) / 64 (Co1; 128 when Co is a multiple of 128) channels; uno_channel_wgrad2 needs
- * C1 % 64 == 0 and P >= 64.  gw is the full (Co, Ci) gradient. */
+ * C1 % 64 == 0 and P >= 64 (x2 = NULL: any shape).  gw is the full (Co, Ci) gradient; accumulate != 0: gw / gb += (the kernels
+ * write a parameter's gradient buffer in place: the unrolled roll-out of ns_train_2d.py:46-68 sums 40 contributions per weight). */
 int uno_channel_mix2(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
                      float* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
                      const float* dgelu_of, void* stream);
 int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
-                       int Co, long long P, int act_x, void* stream);
+                       int Co, long long P, int act_x, int accumulate, void* stream);
 
 /* Final projection of the U-NO models fused with the GELU in front of it (reference darcy_flow_uno2d.py:128-131:
  * `x_fc1 = F.gelu(self.fc1(x)); x_out = self.fc2(x_fc1)` with fc2 = Linear(C, 1)), channels-first:
@@ -266,7 +275,7 @@ int uno_channel_mix2_bf16(const void* x1, const void* x2, int C1, const float* w
                           void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
                           const void* dgelu_of, void* stream);
 int uno_channel_wgrad2_bf16(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
-                            int Co, long long P, int act_x, void* stream);
+                            int Co, long long P, int act_x, int accumulate, void* stream);
 int uno_gelu_project_forward_bf16(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P,
                                   void* stream);
 int uno_gelu_project_backward_bf16(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb,

@@ -194,11 +194,15 @@ def test_flat_gradients_rebind_after_zero_grad_set_to_none():
     lin = torch.nn.Linear(4, 3)
     fg = FlatGradients(lin.parameters())
     lin(torch.ones(2, 4)).sum().backward()
+    fg.finish()                            # gradients autograd produced outside the buffer are collected into it
     assert fg.flat.abs().sum() > 0
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(lin.parameters(), fg.views))
     for p in lin.parameters():
         p.grad = None                      # what optimizer.zero_grad() does by default
     fg.zero_()
+    assert all(p.grad is None for p in lin.parameters())     # a step starts with released gradients: written once, never added
     lin(torch.ones(2, 4)).sum().backward()
+    fg.finish()
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(lin.parameters(), fg.views))
     assert torch.allclose(fg.flat[:12].view(3, 4), torch.full((3, 4), 2.0)) and torch.allclose(fg.flat[12:], torch.full((3,), 2.0))
 
@@ -211,9 +215,12 @@ def test_flat_gradients_odd_real_prefix_before_complex_param():
     b = torch.nn.Parameter(torch.zeros(5))
     z2 = torch.nn.Parameter(torch.zeros(3, dtype=torch.cfloat))
     fg = FlatGradients([a, z, b, z2], bucket_mb=1e-5)
-    assert z.grad.is_complex() and tuple(z.grad.shape) == (2, 2) and tuple(z2.grad.shape) == (3,)
+    assert fg.views[1].is_complex() and tuple(fg.views[1].shape) == (2, 2) and tuple(fg.views[3].shape) == (3,)
+    assert z._uno_grad_buffer is fg.views[1]
     loss = (a * 2).sum() + (z * (1 + 2j)).real.sum() + (b * 3).sum() + (z2 * (0 + 1j)).imag.sum()
     loss.backward()
+    fg.finish()
+    assert z.grad.data_ptr() == fg.views[1].data_ptr()
     assert torch.allclose(a.grad, torch.full((3,), 2.0)) and torch.allclose(b.grad, torch.full((5,), 3.0))
     assert torch.allclose(z.grad, torch.full((2, 2), 1 - 2j, dtype=torch.cfloat))
     # every view lies inside the flat buffer and the buckets cover all of them
@@ -221,7 +228,7 @@ def test_flat_gradients_odd_real_prefix_before_complex_param():
     hi = max(e for _, e in fg.buckets)
     assert lo == 0 and hi <= fg.flat.numel()
     fg.zero_()
-    assert float(z.grad.abs().sum()) == 0.0 and float(a.grad.abs().sum()) == 0.0
+    assert z.grad is None and a.grad is None
 
 
 def test_complex_adam_per_parameter_step_counts():

@@ -277,3 +277,66 @@ def test_grad_join_equals_the_summed_gradients(geom):
     for a, b in zip(res["plain"], res["join"]):
         ar, br = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
         assert float((ar - br).norm()) <= 2e-5 * float(ar.norm()) + 1e-12
+
+
+@pytest.mark.gpu
+def test_weight_gradients_are_written_in_place():
+    """(a) with a FlatGradients buffer the weight-gradient kernels write each gradient into its view and autograd adopts an alias
+    of it (no copy, no add); (b) a layer used several times in one graph (roll-out) accumulates into .grad in place; both give the
+    gradients of the ordinary path (fresh tensors + autograd sums)."""
+    import uno_amd.integral_operators as io
+    from uno_amd.harness.train import FlatGradients
+    from uno_amd.integral_operators import OperatorBlock_2D, channel_mix, gelu_channel_mix
+    torch.manual_seed(1)
+    blk = OperatorBlock_2D(8, 8, 20, 20, 4, 4).to(dev())
+    lin = torch.nn.Linear(8, 8).to(dev())
+    params = list(blk.parameters()) + list(lin.parameters())
+    x = torch.randn(2, 8, 20, 20, device=dev())
+
+    def loss_fn():
+        h = x
+        for _ in range(3):                                     # the same layers three times: 3 contributions per parameter
+            h = blk(h)
+            h = gelu_channel_mix(channel_mix(h, lin.weight, lin.bias), lin.weight, lin.bias)
+        return h.square().sum()
+
+    ref = {}
+    for mode in (False, True):
+        io.INPLACE_PARAM_GRADS = mode
+        try:
+            for p in params:
+                p.grad = None
+                if hasattr(p, "_uno_grad_buffer"):
+                    del p._uno_grad_buffer
+            loss_fn().backward()
+            got = [p.grad.clone() for p in params]
+            if not mode:
+                ref = got
+            else:
+                for a, b in zip(ref, got):
+                    ar, br = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
+                    assert float((ar - br).norm()) <= 2e-6 * float(ar.norm()) + 1e-12
+        finally:
+            io.INPLACE_PARAM_GRADS = True
+    # (a) flat buffer: one use per parameter, every gradient lands in its view without a copy
+    fg = FlatGradients(params)
+    fg.zero_()
+    blk(x).square().sum().backward()
+    for p, v in zip(fg.params, fg.views):
+        if p.grad is not None:
+            assert p.grad.data_ptr() == v.data_ptr(), "gradient was not written into the flat buffer"
+    single = [None if p.grad is None else p.grad.clone() for p in params]
+    io.INPLACE_PARAM_GRADS = False
+    try:
+        for p in params:
+            p.grad = None
+        blk(x).square().sum().backward()
+        for a, p in zip(single, params):
+            if p.grad is not None:
+                ar, br = (torch.view_as_real(t) if t.is_complex() else t for t in (a, p.grad))
+                assert float((ar - br).norm()) <= 2e-6 * float(br.norm()) + 1e-12
+    finally:
+        io.INPLACE_PARAM_GRADS = True
+        for p in params:
+            if hasattr(p, "_uno_grad_buffer"):
+                del p._uno_grad_buffer

@@ -50,7 +50,9 @@ _SIGNATURES = {
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
-    "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
+    "uno_mode_wgrad_acc": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
+    "uno_spectral_conv2d_backward_acc": (C.c_int, [_fp] * 8 + [_i] * 11 + [_fp]),
     "uno_gelu_project_forward": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
     "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
@@ -69,7 +71,7 @@ _SIGNATURES = {
     "uno_channel_mix_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
     "uno_channel_wgrad_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_channel_mix2_bf16": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
-    "uno_channel_wgrad2_bf16": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
+    "uno_channel_wgrad2_bf16": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_forward_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_backward_bf16": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
     "uno_gelu_pad_bf16": (C.c_int, [_fp, _fp, _fp] + [_i] * 6 + [_fp]),
@@ -169,8 +171,9 @@ def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
     return y, xt
 
 
-def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_gw=True):
-    """-> (gx or None (gy's dtype: f32 | bf16), gw1 or None, gw2 or None (c64))."""
+def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_gw=True, gw_out=None, accumulate_gw=False):
+    """-> (gx or None (gy's dtype: f32 | bf16), gw1 or None, gw2 or None (c64)).
+    gw_out = (gw1, gw2): write (accumulate_gw: add) the weight gradients into these complex64 tensors instead of fresh ones."""
     bf16 = _act_dtype(gy, "grad_output")
     _require(xt, torch.complex64, "xtrunc")
     wh = _weights_half(w1, w2, bf16)
@@ -181,15 +184,22 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
     L = lib()
     with torch.cuda.device(gy.device):
         gx = torch.empty((B, Ci, H, W), dtype=gy.dtype, device=gy.device) if need_gx else None
-        gw1 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
-        gw2 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
+        if need_gw and gw_out is not None:
+            gw1, gw2 = gw_out
+            for t in gw_out:
+                _require(t, torch.complex64, "weight-gradient buffer")
+                if tuple(t.shape) != (Ci, Co, m1, m2):
+                    raise RuntimeError("uno_amd: weight-gradient buffer has the wrong shape")
+        else:
+            accumulate_gw = False
+            gw1 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
+            gw2 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
         ws = torch.empty(max(1, L.uno_spectral_conv2d_bwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=gy.device)
         null = C.c_void_p(0)
-        fn = L.uno_spectral_conv2d_backward_mixed if wh else (L.uno_spectral_conv2d_backward_bf16 if bf16 else L.uno_spectral_conv2d_backward)
-        rc = fn(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2),
-                                            _ptr(gx) if need_gx else null,
-                                            _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
-                                            _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(gy))
+        rc = L.uno_spectral_conv2d_backward_acc(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2), _ptr(gx) if need_gx else null,
+                                                _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
+                                                _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, 2 if wh else (1 if bf16 else 0),
+                                                1 if accumulate_gw else 0, _stream(gy))
     _check(rc, "uno_spectral_conv2d_backward")
     return gx, gw1, gw2
 
@@ -301,15 +311,24 @@ def mode_mix(inp, weights, op: int):
     return out
 
 
-def mode_wgrad(xt, go, weight_shape, ncorner: int):
+def mode_wgrad(xt, go, weight_shape, ncorner: int, out=None, accumulate: bool = False):
+    """out: list of `ncorner` complex64 tensors of `weight_shape` to write (accumulate: add) the gradients into."""
     _require(xt, torch.complex64, "xtrunc")
     _require(go, torch.complex64, "grad spectrum")
     B, Ci = xt.shape[:2]
     Co = go.shape[1]
-    gws = [torch.empty(weight_shape, dtype=torch.complex64, device=xt.device) for _ in range(ncorner)]
+    if out is None:
+        accumulate = False
+        gws = [torch.empty(weight_shape, dtype=torch.complex64, device=xt.device) for _ in range(ncorner)]
+    else:
+        gws = list(out)
+        for t in gws:
+            _require(t, torch.complex64, "weight-gradient buffer")
+            if tuple(t.shape) != tuple(weight_shape):
+                raise RuntimeError("uno_amd: weight-gradient buffer has the wrong shape")
     Mc = gws[0][0, 0].numel()
     with torch.cuda.device(xt.device):
-        rc = lib().uno_mode_wgrad(_ptr(xt), _ptr(go), _ptr_array(gws), B, Ci, Co, ncorner, Mc, _stream(xt))
+        rc = lib().uno_mode_wgrad_acc(_ptr(xt), _ptr(go), _ptr_array(gws), B, Ci, Co, ncorner, Mc, 1 if accumulate else 0, _stream(xt))
     _check(rc, "uno_mode_wgrad")
     return gws
 
@@ -483,25 +502,40 @@ def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2
     return (y1, act) if y_act else y1
 
 
-def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False):
-    """gy (B, Co, P), x1 (B, C1, P), x2 (B, C2, P) -> gw (Co, C1 + C2), gb (Co) or None: the weight gradient of a two-source
-    layer from one launch (act_x: x1 := gelu(x1) as it is read)."""
+def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False, out_w=None, out_b=None, accumulate: bool = False):
+    """gy (B, Co, P), x1 (B, C1, P), x2 (B, C2, P) or None -> gw (Co, C1 + C2), gb (Co) or None: the weight gradient of a
+    (two-source) layer from one launch (act_x: x1 := gelu(x1) as it is read).  out_w / out_b: write (accumulate: add) into these
+    float32 tensors of Co * Ci / Co elements instead of fresh ones (out_b is required with need_bias when out_w is given)."""
     bf16 = _act_dtype(gy, "grad_output")
     _require(x1, gy.dtype, "x1")
-    _require(x2, gy.dtype, "x2")
     B, Co, P = gy.shape
-    C1, C2 = x1.shape[1], x2.shape[1]
-    if x1.shape[0] != B or x2.shape[0] != B or x1.shape[2] != P or x2.shape[2] != P:
+    C1 = x1.shape[1]
+    C2 = 0
+    if x2 is not None:
+        _require(x2, gy.dtype, "x2")
+        C2 = x2.shape[1]
+        if x2.shape[0] != B or x2.shape[2] != P:
+            raise RuntimeError("uno_amd: grad_output and the sources disagree in batch / pixel count")
+    if x1.shape[0] != B or x1.shape[2] != P:
         raise RuntimeError("uno_amd: grad_output and the sources disagree in batch / pixel count")
     Ci = C1 + C2
     L = lib()
-    gw = torch.empty((Co, Ci), dtype=torch.float32, device=gy.device)
-    gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if need_bias else None
+    if out_w is None:
+        accumulate = False
+        gw = torch.empty((Co, Ci), dtype=torch.float32, device=gy.device)
+        gb = torch.empty((Co,), dtype=torch.float32, device=gy.device) if need_bias else None
+    else:
+        gw, gb = out_w, (out_b if need_bias else None)
+        _require(gw, torch.float32, "weight-gradient buffer")
+        if gw.numel() != Co * Ci or (need_bias and (gb is None or gb.numel() != Co)):
+            raise RuntimeError("uno_amd: gradient buffers do not match the layer")
+        if gb is not None:
+            _require(gb, torch.float32, "bias-gradient buffer")
     with torch.cuda.device(gy.device):
         ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, P)), dtype=torch.uint8, device=gy.device)
         fn = L.uno_channel_wgrad2_bf16 if bf16 else L.uno_channel_wgrad2
-        rc = fn(_ptr(gy), _ptr(x1), _ptr(x2), C1, _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws),
-                B, Ci, Co, P, 1 if act_x else 0, _stream(gy))
+        rc = fn(_ptr(gy), _ptr(x1), _ptr(x2) if x2 is not None else C.c_void_p(0), C1, _ptr(gw), _ptr(gb) if gb is not None else C.c_void_p(0),
+                _ptr(ws), B, Ci, Co, P, 1 if act_x else 0, 1 if accumulate else 0, _stream(gy))
     _check(rc, "uno_channel_wgrad2")
     return gw, gb
 

@@ -138,7 +138,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
 
 // op 0: forward mix, op 1: grad wrt input spectrum, op 2: weight grad
 static int mode_gemm(int op, const float2* act, const float2* const* w, const float2* go, float2* out_act,
-                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s, int w_half = 0) {
+                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s, int w_half = 0, int accumulate = 0) {
     if (B < 0 || Ci < 1 || Co < 1 || nc < 1 || nc > 4 || Mc < 1) {
         set_error("mode gemm: bad sizes B=%d Ci=%d Co=%d corners=%d modes=%d", B, Ci, Co, nc, Mc);
         return -1;
@@ -146,7 +146,7 @@ static int mode_gemm(int op, const float2* act, const float2* const* w, const fl
     if (B == 0 && op != 2) return 0;
     const long long P = (long long)nc * Mc;
     ModeGemmParams p;
-    p.ncorner = nc; p.Mc = Mc;
+    p.ncorner = nc; p.Mc = Mc; p.accumulate = (op == 2 && accumulate) ? 1 : 0;
     p.A.half = 0; p.B.half = (op != 2 && w_half) ? 1 : 0;
     for (int c = 0; c < 4; ++c) { p.A.base[c] = nullptr; p.B.base[c] = nullptr; p.out[c] = nullptr; }
     if (op == 0) {              // O[b,o] = sum_i X[b,i] W[i,o]
@@ -168,6 +168,7 @@ static int mode_gemm(int op, const float2* act, const float2* const* w, const fl
         p.o_sm = (long long)Co * Mc; p.o_sn = Mc;
         for (int c = 0; c < nc; ++c) { p.A.base[c] = act + (long long)c * Mc; p.B.base[c] = go + (long long)c * Mc; p.out[c] = out_w[c]; }
         if (B == 0) {
+            if (accumulate) return 0;
             for (int c = 0; c < nc; ++c)
                 if (hipMemsetAsync(out_w[c], 0, sizeof(float2) * (size_t)Ci * Co * Mc, s) != hipSuccess) { set_error("memset failed"); return -5; }
             return 0;
@@ -324,14 +325,24 @@ int uno_mode_mix_f16w(const float* in, const void* const* w, float* out, int op,
     return mode_mix_impl(in, reinterpret_cast<const float* const*>(w), out, op, B, Ci, Co, ncorner, modes_per_corner, stream, 1);
 }
 
-int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
-                   int modes_per_corner, void* stream) {
+static int mode_wgrad_impl(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
+                           int modes_per_corner, int accumulate, void* stream) {
     if (!gw || (B > 0 && (!xtrunc || !go))) { set_error("uno_mode_wgrad: null pointer"); return -1; }
     if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_wgrad: ncorner=%d out of range", ncorner); return -1; }
     for (int c = 0; c < ncorner; ++c)
         if (!gw[c]) { set_error("uno_mode_wgrad: null output pointer %d", c); return -1; }
     return mode_gemm(2, reinterpret_cast<const float2*>(xtrunc), nullptr, reinterpret_cast<const float2*>(go), nullptr,
-                     reinterpret_cast<float2* const*>(gw), B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream);
+                     reinterpret_cast<float2* const*>(gw), B, Ci, Co, ncorner, modes_per_corner, (hipStream_t)stream, 0, accumulate);
+}
+
+int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
+                   int modes_per_corner, void* stream) {
+    return mode_wgrad_impl(xtrunc, go, gw, B, Ci, Co, ncorner, modes_per_corner, 0, stream);
+}
+
+int uno_mode_wgrad_acc(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
+                       int modes_per_corner, int accumulate, void* stream) {
+    return mode_wgrad_impl(xtrunc, go, gw, B, Ci, Co, ncorner, modes_per_corner, accumulate, stream);
 }
 
 static int resample2d_impl(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
@@ -427,21 +438,27 @@ int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, 
 }
 
 static int channel_wgrad2_impl(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
-                               int Co, long long P, int act_x, int bf16, void* stream) {
-    if (!x2) return channel_wgrad_impl(gy, x1, gw, gb, ws, B, Ci, Co, P, act_x, bf16, stream);
-    if (B < 1 || Ci < 2 || Co < 1 || P < 1) { set_error("uno_channel_wgrad2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
-    if (!gy || !x1 || !gw || !ws) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
-    return launch_channel_wgrad2(gy, x1, x2, C1, gw, gb, (float*)ws, B, Ci, Co, P, act_x, bf16, (hipStream_t)stream);
+                               int Co, long long P, int act_x, int accumulate, int bf16, void* stream) {
+    if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
+    if (!gw) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
+    if (B == 0 || P == 0) {
+        if (accumulate) return 0;
+        if (hipMemsetAsync(gw, 0, sizeof(float) * Co * Ci, (hipStream_t)stream) != hipSuccess ||
+            (gb && hipMemsetAsync(gb, 0, sizeof(float) * Co, (hipStream_t)stream) != hipSuccess)) { set_error("uno_channel_wgrad2: memset failed"); return -5; }
+        return 0;
+    }
+    if (!gy || !x1 || !ws) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
+    return launch_channel_wgrad2(gy, x1, x2, x2 ? C1 : Ci, gw, gb, (float*)ws, B, Ci, Co, P, act_x, accumulate, bf16, (hipStream_t)stream);
 }
 
 int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
-                       long long P, int act_x, void* stream) {
-    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, 0, stream);
+                       long long P, int act_x, int accumulate, void* stream) {
+    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, accumulate, 0, stream);
 }
 
 int uno_channel_wgrad2_bf16(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
-                            long long P, int act_x, void* stream) {
-    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, 1, stream);
+                            long long P, int act_x, int accumulate, void* stream) {
+    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, accumulate, 1, stream);
 }
 
 int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
@@ -730,14 +747,33 @@ int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const flo
     float* gO = Z2 + 2LL * B * Co * Ho * C;
     float* gX = gO + 2LL * B * Co * 4 * Mc;
     if (int rc = fwd_transform3d(gy, gO, Z2, B * Co, Ho, Wo, To, m1, m2, m3, 1.0f, 1, s)) return rc;
-    if (gw)
-        if (int rc = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, stream)) return rc;
-    if (gx) {
-        if (int rc = uno_mode_mix(gO, w, gX, 1, B, Ci, Co, 4, (int)Mc, stream)) return rc;
-        const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
-        if (int rc = inv_transform3d(gX, gx, Z1, B * Ci, H, W, T, m1, m2, m3, inv_n, 0, s)) return rc;
+    // As in the 2-D backward: the weight gradient only shares the read-only gO with the input-gradient chain and runs on the
+    // side stream next to the input-gradient GEMM and the inverse transform (in the 3-D layer the two per-mode GEMMs are a
+    // quarter of the backward call each: 4 corners of weights against 2 in 2-D)
+    SideStream* side = (gw && gx) ? side_stream_of_current_device() : nullptr;
+    int rc_w = 0;
+    if (gw) {
+        if (side) {
+            side->mu.lock();
+            if (hipEventRecord(side->fork_ev, s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork_ev, 0) != hipSuccess) {
+                side->mu.unlock();
+                side = nullptr;
+            }
+        }
+        rc_w = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, side ? (void*)side->s : stream);
     }
-    return 0;
+    int rc_x = 0;
+    if (gx && rc_w == 0) {
+        rc_x = uno_mode_mix(gO, w, gX, 1, B, Ci, Co, 4, (int)Mc, stream);
+        const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
+        if (rc_x == 0) rc_x = inv_transform3d(gX, gx, Z1, B * Ci, H, W, T, m1, m2, m3, inv_n, 0, s);
+    }
+    if (side) {
+        const bool joined = hipEventRecord(side->join_ev, side->s) == hipSuccess && hipStreamWaitEvent(s, side->join_ev, 0) == hipSuccess;
+        side->mu.unlock();
+        if (!joined) { set_error("%s: side-stream join failed", who); return -5; }
+    }
+    return rc_w ? rc_w : rc_x;
 }
 
 static int spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
@@ -770,7 +806,7 @@ int uno_spectral_conv2d_forward_bf16(const void* x, const float* w1, const float
 
 static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const float* w1, const float* w2, float* gx,
                                     float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
-                                    int m1, int m2, void* stream, int bf16, int w_half = 0) {
+                                    int m1, int m2, void* stream, int bf16, int w_half = 0, int accumulate_gw = 0) {
     if (B > 0 && (!gy || !xtrunc || !w1 || !w2 || !ws)) { set_error("uno_spectral_conv2d_backward: null pointer"); return -1; }
     if ((gw1 == nullptr) != (gw2 == nullptr)) { set_error("uno_spectral_conv2d_backward: gw1/gw2 must both be given or both be NULL"); return -1; }
     if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_spectral_conv2d_backward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
@@ -780,7 +816,7 @@ static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const 
     float* gO = static_cast<float*>(ws);
     float* gX = gO + 2LL * B * Co * P;
     if (B == 0) {
-        if (gw1) {
+        if (gw1 && !accumulate_gw) {
             if (hipMemsetAsync(gw1, 0, 8ULL * Ci * Co * m1 * m2, s) != hipSuccess || hipMemsetAsync(gw2, 0, 8ULL * Ci * Co * m1 * m2, s) != hipSuccess) {
                 set_error("memset failed"); return -5;
             }
@@ -802,7 +838,7 @@ static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const 
                 side = nullptr;
             }
         }
-        rc_w = uno_mode_wgrad(xtrunc, gO, gwv, B, Ci, Co, 2, m1 * m2, side ? (void*)side->s : stream);
+        rc_w = mode_wgrad_impl(xtrunc, gO, gwv, B, Ci, Co, 2, m1 * m2, accumulate_gw, side ? (void*)side->s : stream);
     }
     int rc_x = 0;
     if (gx && rc_w == 0) {
@@ -830,6 +866,15 @@ int uno_spectral_conv2d_backward_bf16(const void* gy, const float* xtrunc, const
                                       int m1, int m2, void* stream) {
     return spectral_conv2d_backward(static_cast<const float*>(gy), xtrunc, w1, w2, static_cast<float*>(gx), gw1, gw2, ws, B, Ci, Co,
                                     H, W, Ho, Wo, m1, m2, stream, 1);
+}
+
+int uno_spectral_conv2d_backward_acc(const void* gy, const float* xtrunc, const void* w1, const void* w2, void* gx,
+                                     float* gw1, float* gw2, void* ws, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                                     int m1, int m2, int io_format, int accumulate_gw, void* stream) {
+    if (io_format < 0 || io_format > 2) { set_error("uno_spectral_conv2d_backward_acc: io_format %d (0 f32, 1 bf16, 2 bf16 + fp16 weights)", io_format); return -1; }
+    return spectral_conv2d_backward(static_cast<const float*>(gy), xtrunc, static_cast<const float*>(w1), static_cast<const float*>(w2),
+                                    static_cast<float*>(gx), gw1, gw2, ws, B, Ci, Co, H, W, Ho, Wo, m1, m2, stream, io_format >= 1,
+                                    io_format == 2, accumulate_gw ? 1 : 0);
 }
 
 int uno_spectral_conv2d_forward_mixed(const void* x, const void* w1, const void* w2, void* y, float* xtrunc, void* ws,

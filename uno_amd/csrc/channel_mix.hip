@@ -855,7 +855,8 @@ __global__ __launch_bounds__(256) void channel_wgrad_few_in_kernel(ChannelWgradP
 
 // fixed-order sum of the split-K partials (deterministic): gw (Co, Ci), gb (Co).  32 consecutive elements x 8
 // interleaved groups of splits per workgroup, the 8 group sums combined in order through LDS.
-__global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* part, float* gw, float* gb, int Co, int Ci, int nsplit) {
+__global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* part, float* gw, float* gb, int Co, int Ci, int nsplit,
+                                                                   int accumulate) {
     __shared__ float sh[8][33];
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
@@ -881,8 +882,9 @@ __global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* 
 #pragma unroll
         for (int g = 1; g < 8; ++g) t += sh[g][el];
         const int o = e / (Ci + 1), i = e % (Ci + 1);
-        if (i < Ci) gw[(size_t)o * Ci + i] = t;
-        else if (gb) gb[o] = t;
+        // accumulate: the results are added to what gw / gb hold (a parameter's gradient buffer written in place)
+        if (i < Ci) gw[(size_t)o * Ci + i] = accumulate ? gw[(size_t)o * Ci + i] + t : t;
+        else if (gb) gb[o] = accumulate ? gb[o] + t : t;
     }
 }
 
@@ -908,11 +910,11 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
 
 int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          int act_x, int bf16, hipStream_t s) {
-    return launch_channel_wgrad2(gy, x, nullptr, Ci, gw, gb, ws, B, Ci, Co, P, act_x, bf16, s);
+    return launch_channel_wgrad2(gy, x, nullptr, Ci, gw, gb, ws, B, Ci, Co, P, act_x, 0, bf16, s);
 }
 
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
-                          long long P, int act_x, int bf16, hipStream_t s) {
+                          long long P, int act_x, int accumulate, int bf16, hipStream_t s) {
     if ((long long)(Ci > Co ? Ci : Co) * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
         set_error("channel_wgrad: tensor too large (channels * pixels must stay below 2^29)");
         return -2;
@@ -938,7 +940,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
 #undef UNO_CWF
         }
         const int nf = Co * (Ci + 1);
-        hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((nf + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit);
+        hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((nf + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
@@ -959,7 +961,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
         }
     }
     const int n = Co * (Ci + 1);
-    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit);
+    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

@@ -184,8 +184,12 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     for (int e = tid; e < 16 * 16 * QC; e += 256) {
         const int q = e & (QC - 1), mn = e / QC;
         const int m = mn >> 4, n = mn & 15;
-        if (q < nmodes && m0 + m < p.M && n0 + n < p.N)
-            Ob[(long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q] = sO[mn * (QC + 1) + q];
+        if (q < nmodes && m0 + m < p.M && n0 + n < p.N) {
+            float2* dst = Ob + (long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q;
+            float2 v = sO[mn * (QC + 1) + q];
+            if (p.accumulate) { const float2 o = *dst; v.x += o.x; v.y += o.y; }
+            *dst = v;
+        }
     }
 }
 
@@ -322,9 +326,13 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
         const int n = n0 + 4 * nt + mx;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float2 v = make_float2(lane_pull(to_mem, vr[i]), lane_pull(to_mem, vi[i]));
+            float2 v = make_float2(lane_pull(to_mem, vr[i]), lane_pull(to_mem, vi[i]));
             const int m = m0 + 4 * mt + i;
-            if (qv && n < p.N && m < p.M) Ob[(long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq] = v;
+            if (qv && n < p.N && m < p.M) {
+                float2* dst = Ob + (long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq;
+                if (p.accumulate) { const float2 o = *dst; v.x += o.x; v.y += o.y; }
+                *dst = v;
+            }
         }
     };
     if (KS == 1) {

@@ -128,6 +128,7 @@ struct ModeGemmParams {
     float2* out[4];
     long long o_sm, o_sn;
     int M, N, K, ncorner, Mc;
+    int accumulate;         // out += instead of out = (weight gradients written straight into a parameter's gradient buffer)
 };
 
 // Pruned complex DFT along the leading axis of (n_img, H, C) <-> corner-major (n_img, 4, m1, m2, m3).
@@ -221,6 +222,6 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
 int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          int act_x, int bf16, hipStream_t s);
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
-                          long long P, int act_x, int bf16, hipStream_t s);
+                          long long P, int act_x, int accumulate, int bf16, hipStream_t s);
 
 }  // namespace uno

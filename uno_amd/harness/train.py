@@ -57,7 +57,8 @@ class FlatGradients:
             else:
                 assert p.dtype == torch.float32
                 view = seg.view(p.shape)
-            p.grad = view
+            p.grad = None
+            p._uno_grad_buffer = view       # where the weight-gradient kernels write this parameter's gradient (integral_operators._grad_target)
             self.views.append(view)
             offsets.append(off)
             off += n
@@ -89,12 +90,22 @@ class FlatGradients:
         self._t_arm = 0.0
 
     def zero_(self):
-        """Zero the buffer and make sure every .grad still is its view (optimizer.zero_grad(set_to_none=True) or a user
-        assignment would otherwise leave gradients outside the buffer that gets all-reduced)."""
-        self.flat.zero_()
-        for p, view in zip(self.params, self.views):
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                p.grad = view
+        """Start of a step: every .grad is released (None).  The backward pass then writes each gradient ONCE into its view of the
+        flat buffer - the library's weight-gradient kernels write there directly and autograd adopts an alias of the view as
+        .grad (no zero fill, no `.grad +=` pass); gradients that arrive as ordinary tensors (a few small ones: normalisation
+        affines, the final projection) are copied in by collect()."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self, only=None):
+        """Make every existing .grad live in the flat buffer: a gradient that autograd produced outside it is copied into its view
+        and .grad re-pointed (called per parameter by the bucket hooks, and for all parameters at the end of a backward pass)."""
+        pairs = zip(self.params, self.views) if only is None else ((self.params[only], self.views[only]),)
+        for p, view in pairs:
+            g = p.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+                p.grad = view.view(view.shape)
 
     # ------------------------------------------------------------------ overlapped all-reduce
     def arm(self, group=None, force=False):
@@ -116,6 +127,7 @@ class FlatGradients:
 
         def hook(_param):
             if self._armed:
+                self.collect(i)             # the gradient must be in the flat buffer before its bucket is sent
                 self._pending[k] -= 1
                 self._issue_ready()
         return hook
@@ -133,6 +145,7 @@ class FlatGradients:
 
     def finish(self):
         """Call after backward(): issues the buckets that are still open and waits for all of them."""
+        self.collect()
         if not self._armed:
             return
         while self._next < len(self.buckets):
@@ -145,6 +158,7 @@ class FlatGradients:
 
     def all_reduce_sum(self, group=None, force=False):
         """One blocking SUM over the whole buffer (no overlap)."""
+        self.collect()
         if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 

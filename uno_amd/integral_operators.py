@@ -90,6 +90,7 @@ class _SpectralConv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, Ho, Wo, half_weights=False):
+        ctx.params = (w1, w2)
         x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
         if half_weights:                    # complex64 master weights, read through float16 (re, im) copies
             w1, w2 = _half_weights(w1, w2)
@@ -104,8 +105,12 @@ class _SpectralConv2dFn(torch.autograd.Function):
         xt, w1, w2 = ctx.saved_tensors
         need_gx = ctx.needs_input_grad[0]
         need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        tg = _grad_targets(ctx.params) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
         gx, gw1, gw2 = _native.spectral_conv2d_backward(_plain(gy), xt, w1, w2, ctx.in_hw[0], ctx.in_hw[1],
-                                                        need_gx=need_gx, need_gw=need_gw)
+                                                        need_gx=need_gx, need_gw=need_gw,
+                                                        gw_out=(tg[0][0], tg[1][0]) if tg else None, accumulate_gw=bool(tg and tg[0][1]))
+        if tg:
+            gw1, gw2 = tg[0][2], tg[1][2]
         return gx, gw1, gw2, None, None, None
 
 
@@ -113,11 +118,12 @@ class _ChannelMixFn(torch.autograd.Function):
     """y[b] = W . x[b] + bias on (B, C, pixels) views with the K8 / K9 kernels (csrc/channel_mix.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, leaves=None):
         x, w = _plain(x), _plain(w)
         y = _native.channel_mix(x, w, None if bias is None else _plain(bias))
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.leaves = leaves
         return y
 
     @staticmethod
@@ -126,10 +132,8 @@ class _ChannelMixFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = _plain(gy)
         gx = _native.channel_mix(gy, w, None, transpose_w=True) if ctx.needs_input_grad[0] else None
-        gw = gb = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _native.channel_wgrad(gy, x, need_bias=ctx.has_bias)
-        return gx, gw, gb
+        gw, gb = _wgrad_into(ctx.leaves, gy, x, None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return gx, gw, gb, None
 
 
 def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
@@ -141,12 +145,68 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     w = weight.reshape(weight.shape[0], Ci)
     xv = x.reshape(B, Ci, -1)
     if _dev_act(x) and w.dtype == torch.float32:
-        y = _ChannelMixFn.apply(xv, w, bias)
+        y = _ChannelMixFn.apply(xv, w, bias, (weight, bias))
     elif bias is not None:
         y = torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xv)
     else:
         y = torch.matmul(w, xv)
     return y.view(B, w.shape[0], *x.shape[2:])
+
+
+# Weight-gradient kernels write a parameter's gradient where it will live instead of handing autograd a fresh tensor to add:
+#   * parameter has no .grad yet but a registered buffer (`_uno_grad_buffer`, set by harness.FlatGradients: a view into the flat
+#     all-reduce buffer): the kernel writes the buffer, the backward returns a fresh ALIAS of it and autograd adopts that alias as
+#     .grad (no zero fill, no `.grad +=` pass; post-accumulate hooks - the bucketed all-reduce - fire as usual);
+#   * parameter already has a .grad (a layer used several times in one graph: the 40-step roll-out of ns_train_2d.py:46-68) and
+#     no post-accumulate hooks: the kernel adds into .grad in place and the backward returns None for it.
+# Anything else takes the ordinary path (fresh tensor, autograd accumulates).
+INPLACE_PARAM_GRADS = True
+
+
+def _grad_target(p):
+    """-> (destination tensor, accumulate flag, value to return to autograd) or None"""
+    if not INPLACE_PARAM_GRADS or not isinstance(p, torch.Tensor) or not p.is_leaf or not p.requires_grad or not p.is_cuda:
+        return None
+    g = p.grad
+    if g is None:
+        buf = getattr(p, "_uno_grad_buffer", None)
+        if buf is None or buf.shape != p.shape or buf.dtype != p.dtype or buf.device != p.device or not buf.is_contiguous():
+            return None
+        return buf, False, buf.view(buf.shape)
+    if getattr(p, "_post_accumulate_grad_hooks", None):
+        return None
+    if g.dtype != p.dtype or g.shape != p.shape or g.device != p.device or not g.is_contiguous():
+        return None
+    return g, True, None
+
+
+def _grad_targets(params):
+    """targets of several parameters that one kernel call writes together: all or nothing, one accumulate flag"""
+    ts = [_grad_target(p) for p in params]
+    if any(t is None for t in ts) or len({t[1] for t in ts}) != 1:
+        return None
+    return ts
+
+
+def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False):
+    """Weight / bias gradient of a channel-mix layer (K9), written in place where the layer's leaf parameters allow it.
+    leaves = (weight leaf, bias leaf or None) or None.  -> (gw or None shaped (Co, Ci), gb or None) to return to autograd."""
+    if not (need_w or need_b):
+        return None, None
+    has_bias = need_b
+    tg = None
+    if leaves is not None and need_w and (leaves[1] is not None) == has_bias:
+        tg = _grad_targets([leaves[0]] + ([leaves[1]] if has_bias else []))
+    fused = x2 is None or (x1.shape[1] % 64 == 0 and gy.shape[2] >= 64)
+    if tg is not None and fused:
+        _native.channel_wgrad2(gy, x1, x2, need_bias=has_bias, act_x=act_x, out_w=tg[0][0], out_b=tg[1][0] if has_bias else None,
+                               accumulate=tg[0][1])
+        Co, Ci = gy.shape[1], x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        gw = None if tg[0][2] is None else tg[0][2].view(Co, Ci)
+        return gw, (tg[1][2] if has_bias else None)
+    if x2 is None:
+        return _native.channel_wgrad(gy, x1, need_bias=has_bias, act_x=act_x)
+    return _mix2_wgrad(gy, x1, x2, has_bias, act_x=act_x)
 
 
 class GradJoin:
@@ -246,7 +306,8 @@ class _ChannelMixCatFn(torch.autograd.Function):
     call returns the gradient of x1 itself (its epilogue multiplies by gelu'(x1)): the activation tensor never exists."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, gelu_first, defer=None, grid=None):
+    def forward(ctx, x1, x2, w, bias, gelu_first, defer=None, grid=None, leaves=None):
+        ctx.leaves = leaves
         x1, x2, w = _plain(x1), _plain(x2), _plain(w)
         y = _mix2_forward(x1, x2, w, None if bias is None else _plain(bias), act_in=gelu_first)
         ctx.save_for_backward(x1, x2, w)
@@ -277,9 +338,8 @@ class _ChannelMixCatFn(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             g2 = _native.channel_mix(gy, w[:, C1:].contiguous(), None, transpose_w=True)
         gw = gb = None
-        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            gw, gb = _mix2_wgrad(gy, x1, x2, ctx.has_bias, act_x=ctx.gelu_first)
-        return g1, g2, gw, gb, None, None, None
+        gw, gb = _wgrad_into(ctx.leaves, gy, x1, x2, ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3], act_x=ctx.gelu_first)
+        return g1, g2, gw, gb, None, None, None, None
 
 
 def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_first: bool = False, defer_grad=None) -> torch.Tensor:
@@ -293,7 +353,7 @@ def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_fi
         B = x1.shape[0]
         w = weight.reshape(weight.shape[0], -1)
         y = _ChannelMixCatFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias, bool(gelu_first),
-                                   defer_grad, tuple(x2.shape[2:]))
+                                   defer_grad, tuple(x2.shape[2:]), (weight, bias))
         return y.view(B, w.shape[0], *x1.shape[2:])
     xs = list(xs)
     if gelu_first:
@@ -306,11 +366,12 @@ class _GeluChannelMixFn(torch.autograd.Function):
     darcy_flow_uno2d.py:98-101): GELU on read in K8 / K9, gelu'(pre) in the input-gradient epilogue."""
 
     @staticmethod
-    def forward(ctx, pre, w, bias):
+    def forward(ctx, pre, w, bias, leaves=None):
         pre, w = _plain(pre), _plain(w)
         y = _native.channel_mix(pre, w, None if bias is None else _plain(bias), act_in=True)
         ctx.save_for_backward(pre, w)
         ctx.has_bias = bias is not None
+        ctx.leaves = leaves
         return y
 
     @staticmethod
@@ -319,10 +380,8 @@ class _GeluChannelMixFn(torch.autograd.Function):
         pre, w = ctx.saved_tensors
         gy = _plain(gy)
         g_pre = _native.channel_mix(gy, w, None, transpose_w=True, dgelu_of=pre) if ctx.needs_input_grad[0] else None
-        gw = gb = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _native.channel_wgrad(gy, pre, need_bias=ctx.has_bias, act_x=True)
-        return g_pre, gw, gb
+        gw, gb = _wgrad_into(ctx.leaves, gy, pre, None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], act_x=True)
+        return g_pre, gw, gb, None
 
 
 def gelu_channel_mix(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
@@ -330,7 +389,7 @@ def gelu_channel_mix(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
     B, Ci = pre.shape[0], pre.shape[1]
     w = weight.reshape(weight.shape[0], Ci)
     if _dev_act(pre) and w.dtype == torch.float32:
-        y = _GeluChannelMixFn.apply(pre.reshape(B, Ci, -1), w, bias)
+        y = _GeluChannelMixFn.apply(pre.reshape(B, Ci, -1), w, bias, (weight, bias))
         return y.view(B, w.shape[0], *pre.shape[2:])
     return channel_mix(F.gelu(pre), weight, bias)
 
@@ -439,6 +498,7 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         channel mix is the kernel that completes s (no up-sampling) it writes the activation in the same pass.
         join: GradJoin of x - this block is x's FIRST consumer and returns x's complete gradient (see GradJoin)."""
         from .resample import resample_forward
+        ctx.leaves = (w1, w2, cw, cb)
         ctx.join = None
         if join is not None:
             join.reset()
@@ -488,18 +548,25 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         need_gc = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
         join = ctx.join
+        lw1, lw2, lcw, lcb = ctx.leaves
+        tg = _grad_targets((lw1, lw2)) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None     # weights written in place
         if join is not None and need_gx and join.spectra:
             # stage by stage: the deferred gradient spectra of x's other consumer are added to this block's before ONE inverse transform
             m1, m2 = w1.shape[2], w1.shape[3]
             gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)
             gw1 = gw2 = None
             if need_gw:
-                gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2)
+                gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
+                                              accumulate=bool(tg and tg[0][1]))
             gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
             gX = join.merge(gX, (H, W))
             gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype)
         else:
-            gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw)
+            gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw,
+                                                            gw_out=(tg[0][0], tg[1][0]) if tg else None,
+                                                            accumulate_gw=bool(tg and tg[0][1]))
+        if tg and need_gw:
+            gw1, gw2 = tg[0][2], tg[1][2]
         gcw = gcb = None
         if mix_last:
             # forward: act = R x;  s += Wm act + b
@@ -510,14 +577,16 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                     g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True)
                     resample_adjoint(g_act.view(B, Ci, Ho, Wo), H, W, out=gx)
             if need_gc:
-                gcw, gcb = _native.channel_wgrad(gs.view(B, Co, -1), act.view(B, Ci, -1), need_bias=has_bias)
+                gcw, gcb = _wgrad_into((lcw, lcb), gs.view(B, Co, -1), act.view(B, Ci, -1), None, ctx.needs_input_grad[3],
+                                       has_bias and ctx.needs_input_grad[4])
         else:
             # forward: t = Wm x + b;  s += R t
             g_t = resample_adjoint(gs, H, W).view(B, Co, -1)
             if need_gx:
                 _native.channel_mix(g_t, cwm, None, transpose_w=True, out=gx.view(B, Ci, -1))
             if need_gc:
-                gcw, gcb = _native.channel_wgrad(g_t, act.view(B, Ci, -1), need_bias=has_bias)
+                gcw, gcb = _wgrad_into((lcw, lcb), g_t, act.view(B, Ci, -1), None, ctx.needs_input_grad[3],
+                                       has_bias and ctx.needs_input_grad[4])
         if gcw is not None:
             gcw = gcw.view(cw_shape)
         if join is not None:
@@ -537,6 +606,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, w1, w2, cw, cb, Ho, Wo, half_weights=False, defer=None):
         from .resample import resample_forward
+        ctx.leaves = (w1, w2, cw, cb)
         ctx.defer = defer if (defer is not None and defer.owner and ctx.needs_input_grad[1]) else None
         x1, x2, w1, w2 = _plain(x1), _plain(x2), _plain(w1), _plain(w2)
         B, C1, H, W = x1.shape
@@ -582,8 +652,13 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         need_gc = ctx.needs_input_grad[4] or (has_bias and ctx.needs_input_grad[5])
         gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)                       # c (.) keep (.) DFT_trunc(gs)
         gw1 = gw2 = None
+        lw1, lw2, lcw, lcb = ctx.leaves
         if need_gw:
-            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2)
+            tg = _grad_targets((lw1, lw2)) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3]) else None
+            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
+                                          accumulate=bool(tg and tg[0][1]))
+            if tg:
+                gw1, gw2 = tg[0][2], tg[1][2]
         gx1 = gx2 = None
         defer = ctx.defer if (need2 and ctx.defer is not None and ctx.defer.owner) else None    # owner's backward still to come
         if need1 or need2:
@@ -617,8 +692,9 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
                 else:
                     _native.channel_mix(g_src, cw1, None, transpose_w=True, out=gx1.view(B, C1, -1))
             if need_gc:
-                gcw, gcb = _mix2_wgrad(g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), has_bias)
-                gcw = gcw.view(cw_shape)
+                gcw, gcb = _wgrad_into((lcw, lcb), g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), ctx.needs_input_grad[4],
+                                       has_bias and ctx.needs_input_grad[5])
+                gcw = None if gcw is None else gcw.view(cw_shape)
             return gx1, None, gw1, gw2, gcw, gcb, None, None, None, None
         if mix_last:
             g_src = gs.view(B, Co, -1)
@@ -647,8 +723,9 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
                 if gx2 is not None:
                     _native.channel_mix(g_src, cwm[:, C1:].contiguous(), None, transpose_w=True, out=gx2.view(B, C2, -1))
         if need_gc:
-            gcw, gcb = _mix2_wgrad(g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), has_bias)
-            gcw = gcw.view(cw_shape)
+            gcw, gcb = _wgrad_into((lcw, lcb), g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), ctx.needs_input_grad[4],
+                                   has_bias and ctx.needs_input_grad[5])
+            gcw = None if gcw is None else gcw.view(cw_shape)
         return gx1, gx2, gw1, gw2, gcw, gcb, None, None, None, None
 
 
