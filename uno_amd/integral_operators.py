@@ -153,39 +153,58 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     return y.view(B, w.shape[0], *x.shape[2:])
 
 
-# Weight-gradient kernels write a parameter's gradient where it will live instead of handing autograd a fresh tensor to add:
-#   * parameter has no .grad yet but a registered buffer (`_uno_grad_buffer`, set by harness.FlatGradients: a view into the flat
-#     all-reduce buffer): the kernel writes the buffer, the backward returns a fresh ALIAS of it and autograd adopts that alias as
-#     .grad (no zero fill, no `.grad +=` pass; post-accumulate hooks - the bucketed all-reduce - fire as usual);
-#   * parameter already has a .grad (a layer used several times in one graph: the 40-step roll-out of ns_train_2d.py:46-68) and
-#     no post-accumulate hooks: the kernel adds into .grad in place and the backward returns None for it.
-# Anything else takes the ordinary path (fresh tensor, autograd accumulates).
+# Weight-gradient kernels write a parameter's gradient where it will live instead of handing autograd fresh tensors to sum:
+#   * FIRST contribution to a parameter in a backward pass: the kernel writes (beta = 0) into the parameter's registered buffer
+#     (`_uno_grad_buffer`, set by harness.FlatGradients: a view into the flat all-reduce buffer) or into a fresh tensor, and the
+#     backward returns an ALIAS of it - autograd adopts the alias as .grad when the pass ends (no zero fill, no `.grad +=` pass;
+#     post-accumulate hooks - the bucketed all-reduce - fire as usual);
+#   * LATER contributions in the same pass (a layer used several times in one graph: the 40-step roll-out of ns_train_2d.py:46-68
+#     sums 40 gradients per weight; autograd would add them one by one in the input buffer of the parameter's AccumulateGrad
+#     node): the kernel adds (beta = 1) into that same tensor and the backward returns None for the parameter.
+# A parameter that already HAS a .grad when the pass starts (accumulation across passes) takes the ordinary path.
 INPLACE_PARAM_GRADS = True
+_PASS = {"id": None, "acc": {}}         # per backward pass (autograd graph task): id(parameter) -> tensor its gradient is being summed in
 
 
-def _grad_target(p):
-    """-> (destination tensor, accumulate flag, value to return to autograd) or None"""
+def _end_of_pass():
+    _PASS["id"], _PASS["acc"] = None, {}
+
+
+def _grad_plan(p):
+    """('acc', tensor): later contribution of this pass | ('new', registered buffer or None): first contribution | None: ordinary path"""
     if not INPLACE_PARAM_GRADS or not isinstance(p, torch.Tensor) or not p.is_leaf or not p.requires_grad or not p.is_cuda:
         return None
-    g = p.grad
-    if g is None:
-        buf = getattr(p, "_uno_grad_buffer", None)
-        if buf is None or buf.shape != p.shape or buf.dtype != p.dtype or buf.device != p.device or not buf.is_contiguous():
-            return None
-        return buf, False, buf.view(buf.shape)
-    if getattr(p, "_post_accumulate_grad_hooks", None):
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
         return None
-    if g.dtype != p.dtype or g.shape != p.shape or g.device != p.device or not g.is_contiguous():
+    if _PASS["id"] != tid:
+        _PASS["id"], _PASS["acc"] = tid, {}
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)     # drop the references when this pass completes
+    acc = _PASS["acc"].get(id(p))
+    if acc is not None:
+        return "acc", acc
+    if p.grad is not None:
         return None
-    return g, True, None
+    buf = getattr(p, "_uno_grad_buffer", None)
+    if buf is not None and (buf.shape != p.shape or buf.dtype != p.dtype or buf.device != p.device or not buf.is_contiguous()):
+        buf = None
+    return "new", buf
 
 
 def _grad_targets(params):
-    """targets of several parameters that one kernel call writes together: all or nothing, one accumulate flag"""
-    ts = [_grad_target(p) for p in params]
-    if any(t is None for t in ts) or len({t[1] for t in ts}) != 1:
+    """Targets of the parameters ONE kernel call writes together: all or nothing, one accumulate flag.
+    -> list of (destination tensor, accumulate flag, value to return to autograd) or None"""
+    plans = [_grad_plan(p) for p in params]
+    if any(pl is None for pl in plans) or len({pl[0] for pl in plans}) != 1:
         return None
-    return ts
+    if plans[0][0] == "acc":
+        return [(pl[1], True, None) for pl in plans]
+    out = []
+    for p, pl in zip(params, plans):
+        buf = pl[1] if pl[1] is not None else torch.empty(p.shape, dtype=p.dtype, device=p.device)
+        _PASS["acc"][id(p)] = buf
+        out.append((buf, False, buf.view(buf.shape)))
+    return out
 
 
 def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False):
@@ -195,10 +214,10 @@ def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False):
         return None, None
     has_bias = need_b
     tg = None
-    if leaves is not None and need_w and (leaves[1] is not None) == has_bias:
-        tg = _grad_targets([leaves[0]] + ([leaves[1]] if has_bias else []))
     fused = x2 is None or (x1.shape[1] % 64 == 0 and gy.shape[2] >= 64)
-    if tg is not None and fused:
+    if fused and leaves is not None and need_w and (leaves[1] is not None) == has_bias:
+        tg = _grad_targets([leaves[0]] + ([leaves[1]] if has_bias else []))        # committed: the call below writes them
+    if tg is not None:
         _native.channel_wgrad2(gy, x1, x2, need_bias=has_bias, act_x=act_x, out_w=tg[0][0], out_b=tg[1][0] if has_bias else None,
                                accumulate=tg[0][1])
         Co, Ci = gy.shape[1], x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
