@@ -747,33 +747,17 @@ int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const flo
     float* gO = Z2 + 2LL * B * Co * Ho * C;
     float* gX = gO + 2LL * B * Co * 4 * Mc;
     if (int rc = fwd_transform3d(gy, gO, Z2, B * Co, Ho, Wo, To, m1, m2, m3, 1.0f, 1, s)) return rc;
-    // As in the 2-D backward: the weight gradient only shares the read-only gO with the input-gradient chain and runs on the
-    // side stream next to the input-gradient GEMM and the inverse transform (in the 3-D layer the two per-mode GEMMs are a
-    // quarter of the backward call each: 4 corners of weights against 2 in 2-D)
-    SideStream* side = (gw && gx) ? side_stream_of_current_device() : nullptr;
-    int rc_w = 0;
-    if (gw) {
-        if (side) {
-            side->mu.lock();
-            if (hipEventRecord(side->fork_ev, s) != hipSuccess || hipStreamWaitEvent(side->s, side->fork_ev, 0) != hipSuccess) {
-                side->mu.unlock();
-                side = nullptr;
-            }
-        }
-        rc_w = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, side ? (void*)side->s : stream);
-    }
-    int rc_x = 0;
-    if (gx && rc_w == 0) {
-        rc_x = uno_mode_mix(gO, w, gX, 1, B, Ci, Co, 4, (int)Mc, stream);
+    // The weight gradient stays on the caller's stream (measured round 3, one box, A/B: on the side stream next to the
+    // input-gradient GEMM and the inverse transform - the 2-D arrangement - the C4 block backward took 127 us against 119.5 us
+    // in sequence: at 4 corners of weights the two per-mode GEMMs are each bound by the same weight / spectrum streams)
+    if (gw)
+        if (int rc = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, stream)) return rc;
+    if (gx) {
+        if (int rc = uno_mode_mix(gO, w, gX, 1, B, Ci, Co, 4, (int)Mc, stream)) return rc;
         const float inv_n = 1.0f / ((float)H * (float)W * (float)T);
-        if (rc_x == 0) rc_x = inv_transform3d(gX, gx, Z1, B * Ci, H, W, T, m1, m2, m3, inv_n, 0, s);
+        if (int rc = inv_transform3d(gX, gx, Z1, B * Ci, H, W, T, m1, m2, m3, inv_n, 0, s)) return rc;
     }
-    if (side) {
-        const bool joined = hipEventRecord(side->join_ev, side->s) == hipSuccess && hipStreamWaitEvent(s, side->join_ev, 0) == hipSuccess;
-        side->mu.unlock();
-        if (!joined) { set_error("%s: side-stream join failed", who); return -5; }
-    }
-    return rc_w ? rc_w : rc_x;
+    return 0;
 }
 
 static int spectral_conv2d_forward(const float* x, const float* w1, const float* w2, float* y, float* xtrunc, void* ws,
