@@ -200,6 +200,41 @@ def test_c4_ns3d_model_layers_full_size(w, layer):
     _check3d(8, Ci, Co, din, dout, modes, seed=w + layer)
 
 
+@pytest.mark.parametrize("w", [8, 32])
+@pytest.mark.parametrize("layer", range(7))
+def test_c4_ns3d_pointwise_resample_full_size(w, layer):
+    """The FFT crop / resample of pointwise_op_3D (reference integral_operators.py:448-463) at the NS-3D model's own shapes - it runs
+    on the same pruned-DFT kernel families (plane transforms + leading-axis cdft kernels with explicit frequency tables), which the
+    bench's kernel lists therefore name: forward and input gradient against the reference's op sequence in float64 on the host."""
+    from uno_amd.integral_operators import _FftResample3dFn, _resample3d_plan
+    _, Co, din, dout, _ = _t20_layers(w)[layer]
+    plan = _resample3d_plan(din, dout, dev())
+    if plan is None:
+        pytest.skip("outside the pruned-DFT resampling kernels' range: the model runs stock rocFFT here")
+    g = torch.Generator().manual_seed(w * 10 + layer)
+    x = torch.randn(8, Co, *din, generator=g)
+    gy = torch.randn(8, Co, *dout, generator=g)
+    xr = x.double().requires_grad_(True)
+    spec = torch.fft.rfftn(xr, dim=[-3, -2, -1])
+    kept = torch.zeros_like(spec)
+    h1, h2, h3 = dout[0] // 2, dout[1] // 2, dout[2] // 2
+    for rows in (slice(None, h1), slice(-h1, None)):
+        for cols in (slice(None, h2), slice(-h2, None)):
+            kept[:, :, rows, cols, :h3] = spec[:, :, rows, cols, :h3]
+    yr = torch.fft.irfftn(kept, s=dout)
+    yr.backward(gy.double())
+    xd = x.to(dev()).requires_grad_(True)
+
+    def run():
+        y = _FftResample3dFn.apply(xd, dout, plan)
+        y.backward(gy.to(dev()))
+        return y
+    y, ran = _run_profiled(run)
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL
+    assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < TOL
+    COVERED.update(n for n in ran if _spectral(n))
+
+
 # ------------------------------------------------------------------ C5: 1024^2 block, batch 4, f32 (the mixed form: tests/test_hip_c5.py)
 def test_c5_block_f32_bench_batch():
     _check2d(4, 64, 64, 1024, 1024, 1024, 1024, 32, 32, seed=1024)

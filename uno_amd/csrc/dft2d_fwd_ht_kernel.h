@@ -161,19 +161,37 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
     }
     __syncthreads();
 
-    int Kj[MT];
-    bool jvalid[MT];
+    // Column stage in +-k PAIRED form where that saves row tiles (MT >= 3): the kept rows are the frequencies +k (lo corner row k,
+    // k < m1) and -k (hi corner row 2 m1 - k, 1 <= k <= m1), and with C_k = sum_h cos(theta_k h) T[h], S_k = sum_h sin(theta_k h) T[h]
+    //     X[+k] = C_k - i S_k,      X[-k] = C_k + i S_k
+    // so the stage runs over m1 + 1 values of k (MP tiles of 16) with REAL twiddles instead of 2 m1 rows (MT tiles) with complex
+    // ones: 4 MP instead of 4 MT MFMAs per (k-step, mode tile) - 8 against 12 at modes1 = 18 / 20 (the column stage is ~40 % of
+    // this kernel's MFMA cycles), 12 against 16 at modes1 = 32.  K3 has used the same pairing since round 1.
+    constexpr bool PAIR = MT >= 3 && NT * MT < 12;      // (NT, MT) = (3, 4), (3, 5): the four accumulator sets no longer fit 256 VGPRs
+    constexpr int MP = PAIR ? MT / 2 + 1 : MT;          // >= ceil((m1 + 1) / 16) for every m1 <= 8 MT
+    int Kj[MP];
+    bool jvalid[MP];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MP; ++mt) {
         const int j = 16 * mt + r16;
-        jvalid[mt] = j < 2 * m1;
-        Kj[mt] = jvalid[mt] ? corner_freq(j, m1, H) : 0;
+        if constexpr (PAIR) {
+            jvalid[mt] = j <= m1;                       // k = j: 0 .. m1
+            Kj[mt] = jvalid[mt] ? j : 0;
+        } else {
+            jvalid[mt] = j < 2 * m1;
+            Kj[mt] = jvalid[mt] ? corner_freq(j, m1, H) : 0;
+        }
     }
-    f32x4 Xr[MT][NT], Xi[MT][NT];
+    // !PAIR: Xr / Xi = Re / Im of the spectrum rows, Yr / Yi unused.  PAIR: Xr = Re C, Xi = Re S, Yr = -Im C, Yi = -Im S
+    // (the row stage hands over Tn = -Im T)
+    f32x4 Xr[MP][NT], Xi[MP][NT], Yr[PAIR ? MP : 1][NT], Yi[PAIR ? MP : 1][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MP; ++mt)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { Xr[mt][t] = f32x4{0, 0, 0, 0}; Xi[mt][t] = f32x4{0, 0, 0, 0}; }
+        for (int t = 0; t < NT; ++t) {
+            Xr[mt][t] = f32x4{0, 0, 0, 0}; Xi[mt][t] = f32x4{0, 0, 0, 0};
+            if (PAIR || mt == 0) { Yr[PAIR ? mt : 0][t] = f32x4{0, 0, 0, 0}; Yi[PAIR ? mt : 0][t] = f32x4{0, 0, 0, 0}; }
+        }
 
     const float2* tabF = sTabF + lane;
     const float2* tab4 = sTab4 + 4 * kk + (lane & 3);
@@ -322,10 +340,10 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
             }
 
             // ---- stage B: X[j][l] += exp(-i theta(j,h)) * T[h][l], h = 16 rt + 4 kk + s
-            unsigned idxB[MT];
-            float2 twB[MT];
+            unsigned idxB[MP];
+            float2 twB[MP];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MP; ++mt) {
                 const unsigned i0 = 8u * (((unsigned)Kj[mt] * (unsigned)(16 * rt + 4 * kk)) % (unsigned)H);
                 twB[mt] = lds_tw(sTwH, i0);
                 idxB[mt] = wrap_add(i0, 8u * (unsigned)Kj[mt], H8);
@@ -333,61 +351,77 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bool hvalid = (16 * rt + 4 * kk + s) < H;
-                float2 twBn[MT];
+                float2 twBn[MP];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
+                for (int mt = 0; mt < MP; ++mt) {
                     twBn[mt] = lds_tw(sTwH, idxB[mt]);
                     idxB[mt] = wrap_add(idxB[mt], 8u * (unsigned)Kj[mt], H8);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
+                for (int mt = 0; mt < MP; ++mt) {
                     const bool v = hvalid && jvalid[mt];
                     const float ac = v ? twB[mt].x : 0.f;
-                    const float ans = v ? -twB[mt].y : 0.f;
-                    const float anc = -ac;
+                    if constexpr (PAIR) {
+                        const float as = v ? twB[mt].y : 0.f;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        Xr[mt][t] = mfma16(ac, Tr[t][s], Xr[mt][t]);
-                        Xi[mt][t] = mfma16(anc, Tn[t][s], Xi[mt][t]);
-                        Xr[mt][t] = mfma16(ans, Tn[t][s], Xr[mt][t]);
-                        Xi[mt][t] = mfma16(ans, Tr[t][s], Xi[mt][t]);
+                        for (int t = 0; t < NT; ++t) {
+                            Xr[mt][t] = mfma16(ac, Tr[t][s], Xr[mt][t]);         // Re C
+                            Yr[mt][t] = mfma16(ac, Tn[t][s], Yr[mt][t]);         // -Im C
+                            Xi[mt][t] = mfma16(as, Tr[t][s], Xi[mt][t]);         // Re S
+                            Yi[mt][t] = mfma16(as, Tn[t][s], Yi[mt][t]);         // -Im S
+                        }
+                    } else {
+                        const float ans = v ? -twB[mt].y : 0.f;
+                        const float anc = -ac;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            Xr[mt][t] = mfma16(ac, Tr[t][s], Xr[mt][t]);
+                            Xi[mt][t] = mfma16(anc, Tn[t][s], Xi[mt][t]);
+                            Xr[mt][t] = mfma16(ans, Tn[t][s], Xr[mt][t]);
+                            Xi[mt][t] = mfma16(ans, Tr[t][s], Xi[mt][t]);
+                        }
                     }
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) twB[mt] = twBn[mt];
+                for (int mt = 0; mt < MP; ++mt) twB[mt] = twBn[mt];
             }
         }
     }
 
     // ---- several waves per image: deterministic tree reduction of the partial spectra through the (now free) buffers
     if (NW > 1) __syncthreads();            // every wave of the workgroup is done with its buffer
-    for (int stride = 2; stride >= 1; stride >>= 1) {
-        if (stride >= NW) continue;
+    // one pass per accumulator pair ((Xr, Xi), and in the paired form (Yr, Yi)): MP * NT * 8 * 64 floats fit a wave's buffer
+    auto reduce_pair = [&](f32x4 (*A)[NT], f32x4 (*Bv)[NT], int stride) {
         if (wsub >= stride && wsub < 2 * stride) {
             float* dst = sBuf + (size_t)(wave - stride) * buf_stride;         // the partner's buffer
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MP; ++mt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        dst[((mt * NT + t) * 8 + r) * 64 + lane] = Xr[mt][t][r];
-                        dst[((mt * NT + t) * 8 + 4 + r) * 64 + lane] = Xi[mt][t][r];
+                        dst[((mt * NT + t) * 8 + r) * 64 + lane] = A[mt][t][r];
+                        dst[((mt * NT + t) * 8 + 4 + r) * 64 + lane] = Bv[mt][t][r];
                     }
         }
         __syncthreads();
         if (wsub < stride && wsub + stride < NW) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MP; ++mt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        Xr[mt][t][r] += buf[((mt * NT + t) * 8 + r) * 64 + lane];
-                        Xi[mt][t][r] += buf[((mt * NT + t) * 8 + 4 + r) * 64 + lane];
+                        A[mt][t][r] += buf[((mt * NT + t) * 8 + r) * 64 + lane];
+                        Bv[mt][t][r] += buf[((mt * NT + t) * 8 + 4 + r) * 64 + lane];
                     }
         }
         __syncthreads();
+    };
+    for (int stride = 2; stride >= 1; stride >>= 1) {
+        if (stride >= NW) continue;
+        reduce_pair(Xr, Xi, stride);
+        if constexpr (PAIR) reduce_pair(Yr, Yi, stride);
     }
 
     if (active && wsub == 0) {
@@ -398,13 +432,27 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
             if (l >= m2) continue;
             const float cs_ = p.scale * (p.herm ? herm_weight(l, W) : 1.0f);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MP; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = 16 * mt + 4 * kk + r;
-                    if (j < 2 * m1) {
-                        const float f = (p.mask && !row_survives(j, m1, H)) ? 0.f : cs_;
-                        out[(size_t)j * m2 + l] = make_float2(Xr[mt][t][r] * f, Xi[mt][t][r] * f);
+                    if constexpr (PAIR) {
+                        // k = j:  X[+k] = C - i S = (Re C - (-Im S)... with Yr = -Im C, Yi = -Im S:  Re = Xr - Yi, Im = -Yr - Xi;  X[-k]: S -> -S
+                        const float cr = Xr[mt][t][r], sr = Xi[mt][t][r], cn = Yr[PAIR ? mt : 0][t][r], sn = Yi[PAIR ? mt : 0][t][r];
+                        if (j < m1) {
+                            const float f = (p.mask && !row_survives(j, m1, H)) ? 0.f : cs_;
+                            out[(size_t)j * m2 + l] = make_float2((cr - sn) * f, (-cn - sr) * f);
+                        }
+                        if (j >= 1 && j <= m1) {
+                            const int jm = 2 * m1 - j;
+                            const float f = (p.mask && !row_survives(jm, m1, H)) ? 0.f : cs_;
+                            out[(size_t)jm * m2 + l] = make_float2((cr + sn) * f, (-cn + sr) * f);
+                        }
+                    } else {
+                        if (j < 2 * m1) {
+                            const float f = (p.mask && !row_survives(j, m1, H)) ? 0.f : cs_;
+                            out[(size_t)j * m2 + l] = make_float2(Xr[mt][t][r] * f, Xi[mt][t][r] * f);
+                        }
                     }
                 }
         }
