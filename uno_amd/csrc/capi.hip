@@ -126,10 +126,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
     // mode counts beyond the compiled MFMA range (the reference's default modes, integral_operators.py:153-158): any-mode form
-#ifndef UNO_FORCE_VALU_DFT
-#define UNO_FORCE_VALU_DFT 0     // ablation build (tools/dev/mkvariant.py): every 2-D transform on the plain-FMA (VALU) kernels of dft_generic.hip
-#endif
-    if (UNO_FORCE_VALU_DFT || m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, s);
+    if (m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, s);
     // many small images (3-D planes, coarse 2-D levels): plane-batched kernels (dft2d_plane.hip)
     if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
         return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);

@@ -23,12 +23,8 @@ namespace uno {
 
 constexpr int FT_TAILMAX = 5;           // tail <= 15 pairs + w = 0 + Nyquist column = 17 elements = 5 k-steps
 constexpr size_t FT_LDS_BUDGET = 160 * 1024 - 2048;
-#ifndef UNO_FT_AUX
-#define UNO_FT_AUX 2                    // cache policy of the tile loads: 2 = non-temporal
-#endif
-#ifndef UNO_FT_MAXW
-#define UNO_FT_MAXW 160                // widest image the full-tile form takes (see fwd_ft_geometry)
-#endif
+constexpr int FT_AUX = 2;               // cache policy of the tile loads: 2 = non-temporal (each line is read once)
+constexpr int FT_MAXW = 160;            // widest image the full-tile form takes (see fwd_ft_geometry)
 
 __device__ __forceinline__ f32x4 ft_mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);      // lane layout: dft2d_fwd_kernel.h
@@ -92,7 +88,7 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
         const unsigned v0 = (unsigned)(((toff & ~31) + 4 * lane) * 4);
         for (int i = 0; i < npiece; ++i)
             if (256 * i + 4 * lane < total)         // the last piece stops at the end of the tile (lanes beyond it are masked off)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(buf + 256 * i), 16, v0 + 1024u * (unsigned)i, 0, 0, UNO_FT_AUX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(buf + 256 * i), 16, v0 + 1024u * (unsigned)i, 0, 0, FT_AUX);
     };
     if (active && wsub < nrt) request_tile(wsub);
 
@@ -405,7 +401,7 @@ static bool fwd_ft_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtG
     // 421^2 243 / 212: with one wave per SIMD the row stage's LDS / VALU work and its MFMAs run back to back instead of
     // overlapping (ablations: 64 us of operand traffic + 83 us of row-stage MFMAs + 40 us of column stage + 60 us of exposed
     // tile loads), which the three waves per SIMD of the register path hide.  Large tiles therefore stay on that kernel.
-    if (p.W > UNO_FT_MAXW) return false;
+    if (p.W > FT_MAXW) return false;
     if ((size_t)MT * NT * 8 * 64 > (size_t)16 * p.W) return false;             // reduction slots must fit a tile buffer
     const int nrt = (p.H + 15) / 16, cus = ft_device_cu_count();
     long long best_cost = -1;

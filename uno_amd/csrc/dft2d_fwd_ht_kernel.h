@@ -26,9 +26,7 @@ namespace uno {
 
 constexpr size_t HT_LDS_LIMIT = 160 * 1024;         // a workgroup may own the whole LDS of the CU
 constexpr int HT_WAVES = 8;
-#ifndef UNO_HT_AUX
-#define UNO_HT_AUX 2                    // cache policy of the tile loads: 2 = non-temporal (each line is read once; measured 240 -> 193 us at the C2 block)
-#endif
+constexpr int HT_AUX = 2;               // cache policy of the tile loads: 2 = non-temporal (each line is read once; measured 240 -> 193 us at the C2 block)
 
 struct HtSplit { int cs, QL, QR, len_in, seg, s0, off0; };
 // outer half = column 0 + the pairs of chunks [0, cs): left columns [0, QL), right columns [W - QR, W); inner = the rest.
@@ -106,7 +104,7 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
     auto fetch_run = [&](int m, int len, float* dst) {
         const int ph = m & 3;
         if (4 * lane < ph + len)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, (unsigned)((m - ph + 4 * lane) * 4), 0, 0, UNO_HT_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, (unsigned)((m - ph + 4 * lane) * 4), 0, 0, HT_AUX);
     };
     auto request_outer = [&](int rt) {
         const int toff = a0 + rt * 16 * W;
@@ -471,7 +469,7 @@ static size_t fwd_ht_lds_bytes(const Dft2dParams& p, int NTF, int R4, int waves)
 static bool fwd_ht_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtGeometry* out) {
     const int NTF = R4 > 0 ? NT - 1 : NT;
     const int P = (p.W - 1) >> 1, nfull = P >> 4;
-    if (p.bf16 || p.rowfreq || nfull < 2 || p.W <= UNO_FT_MAXW) return false;
+    if (p.bf16 || p.rowfreq || nfull < 2 || p.W <= FT_MAXW) return false;
     // measured (1024 images, in-block, input cold): 421^2 227 us against 257 for the register path, 446^2 218 / 230, 223^2 51 / 47:
     // short rows make short runs (a run of the inner half of a 223-wide row is 0.4 KB), the register path keeps those
     if (p.W < 300) return false;

@@ -31,9 +31,6 @@
 
 namespace uno {
 
-#ifndef UNO_K3_NT
-#define UNO_K3_NT 0                     // 1: non-temporal stores of the full-tile form (experiment switch)
-#endif
 constexpr int STG_COLS = 64;            // columns per staged chunk (4 MFMA column tiles)
 constexpr int STG_RS = STG_COLS + 4;    // LDS row stride in floats: 16-byte aligned, 4-bank skew per row
 constexpr int INV_MAX_WAVES = 12;       // waves per workgroup (3 per SIMD: the register budget of the large instantiations)
@@ -478,17 +475,12 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 256);
                 const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 512);
                 const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + 768);
-                if (UNO_K3_NT) {
-                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(dst));
-                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(dst + 256));
-                    __builtin_nontemporal_store(v2, reinterpret_cast<f32x4*>(dst + 512));
-                    __builtin_nontemporal_store(v3, reinterpret_cast<f32x4*>(dst + 768));
-                } else {
-                    *reinterpret_cast<f32x4*>(dst) = v0;
-                    *reinterpret_cast<f32x4*>(dst + 256) = v1;
-                    *reinterpret_cast<f32x4*>(dst + 512) = v2;
-                    *reinterpret_cast<f32x4*>(dst + 768) = v3;
-                }
+                // plain stores: the non-temporal form measured 161 -> 157.5 us (noise) and would keep the block's output out of
+                // the Infinity Cache for its consumer
+                *reinterpret_cast<f32x4*>(dst) = v0;
+                *reinterpret_cast<f32x4*>(dst + 256) = v1;
+                *reinterpret_cast<f32x4*>(dst + 512) = v2;
+                *reinterpret_cast<f32x4*>(dst + 768) = v3;
                 it += 4;
             }
         };

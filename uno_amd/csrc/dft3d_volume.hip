@@ -28,13 +28,8 @@ namespace uno {
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int VOL_WAVES = 16;
-#ifndef UNO_VOL_EXP
-#define UNO_VOL_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = no planes, 2 = planes only, 3 = tables only
-#endif
 constexpr size_t VOL_LDS_LIMIT = 160 * 1024;
-#ifndef UNO_VOL_MIN_VOLUMES
-#define UNO_VOL_MIN_VOLUMES 48   // one workgroup per volume; measured (tools/dev/vol3dtime.py, widths 8 and 16): still ahead of the plane path at 64 volumes
-#endif
+constexpr int VOL_MIN_VOLUMES = 48;     // one workgroup per volume; measured (tools/dev/vol3dtime.py, widths 8 and 16): still ahead of the plane path at 64 volumes
 
 __device__ __forceinline__ float vol_xor1(float v) {       // the value held by lane ^ 1 (DPP quad_perm [1,0,3,2])
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -78,7 +73,7 @@ static VolShape vol_shape(int D1, int D2, int D3, int m1, int m2, int m3) {
 }
 
 bool vol3d_fwd_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3) {
-    if (n_vol < UNO_VOL_MIN_VOLUMES) return false;
+    if (n_vol < VOL_MIN_VOLUMES) return false;
     if (D1 < 4 || D2 < 4 || D3 < 2 || D1 > 128 || D2 > 64 || D3 > 32) return false;
     if (2 * m1 > D1 || 2 * m2 > D2 || m1 > 32 || m2 > 32 || 2 * m3 > 16 || m3 > D3 / 2 + 1) return false;      // no corner overlap
     const VolShape g = vol_shape(D1, D2, D3, m1, m2, m3);
@@ -144,7 +139,7 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_fwd_volume_kernel(Vol3dP
 
     // this wave's slots: wave, wave + 16, ...; per slot two planes (a = slot, b = partner), per plane U tile pairs
     const int my_slots = (g.nslot1 - wave + VOL_WAVES - 1) / VOL_WAVES;      // may be <= 0
-    const int n_units = (UNO_VOL_EXP == 1 || UNO_VOL_EXP == 3) ? 0 : max(my_slots, 0) * 2 * U;
+    const int n_units = max(my_slots, 0) * 2 * U;
     auto unit_plane = [&](int q) -> int {
         const int slot = wave + VOL_WAVES * (q / (2 * U));
         const int second = (q / U) & 1;
@@ -274,7 +269,6 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_fwd_volume_kernel(Vol3dP
     }
     __syncthreads();
 
-    if (UNO_VOL_EXP == 2 || UNO_VOL_EXP == 3) return;
     // ---- phase 2: leading axis out of LDS, blocks of 16 complex columns dealt to the waves.  A lane owns one complex column
     // (re and im are two MFMA column tiles), so i S needs no lane exchange and a row of the result leaves as 128 contiguous bytes.
     float2* out = reinterpret_cast<float2*>(p.out) + (size_t)vol * (size_t)(4 * m1 * m2 * m3);            // 4 corners x m1 m2 m3 complex
@@ -338,7 +332,7 @@ static VolInvShape vol_inv_shape(int D1, int D2, int D3, int m1, int m2, int m3)
 }
 
 bool vol3d_inv_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3) {
-    if (n_vol < UNO_VOL_MIN_VOLUMES) return false;
+    if (n_vol < VOL_MIN_VOLUMES) return false;
     if (D1 < 4 || D2 < 4 || D3 < 2 || D1 > 64 || D2 > 64 || D3 > 32) return false;
     if (2 * m1 > D1 || 2 * m2 > D2 || m1 > 32 || m2 > 32 || 2 * m3 > 16 || m3 > D3 / 2 + 1) return false;
     if ((long long)D1 * D2 * D3 * 4 >= (1LL << 31)) return false;
@@ -408,7 +402,7 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_inv_volume_kernel(Vol3dP
     const int vol = blockIdx.x;
     const float2* O = reinterpret_cast<const float2*>(p.in) + (size_t)vol * (size_t)(4 * m1 * m2 * m3);
     const size_t cstride = (size_t)m1 * m2 * m3;                                 // complex elements per corner
-    for (int blk = wave; blk < ((UNO_VOL_EXP == 2 || UNO_VOL_EXP == 3) ? 0 : g.NT); blk += VOL_WAVES) {
+    for (int blk = wave; blk < g.NT; blk += VOL_WAVES) {
         const int c = min(16 * blk + n16, g.C2 / 2 - 1);
         const int j2 = c / m3, l = c - j2 * m3;
         const int cc = j2 >= m2, jj2 = j2 - cc * m2;
@@ -461,7 +455,6 @@ __global__ __launch_bounds__(64 * VOL_WAVES) void dft3d_inv_volume_kernel(Vol3dP
     }
     __syncthreads();
 
-    if (UNO_VOL_EXP == 1 || UNO_VOL_EXP == 3) return;
     // ---- phase 2: planes
     float* ybase = p.out + (size_t)vol * D1 * D2 * D3;
     for (int d1 = wave; d1 < D1; d1 += VOL_WAVES) {

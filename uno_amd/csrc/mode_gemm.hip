@@ -385,10 +385,6 @@ static void launch_blocks_t(const ModeGemmParams& p, int KS, hipStream_t s) {
     else hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
 }
 
-#ifndef UNO_K2_BLOCKS
-#define UNO_K2_BLOCKS 1
-#endif
-
 // 16 modes: one staging buffer (33.8 KB, also holds the 34.8 KB output tile); 8 modes: two (34.8 KB)
 static size_t mode_gemm_lds(int qc, bool pipe) {
     const size_t sb = (size_t)2 * 2 * qc * (KC * 16 + 64 / qc), out = (size_t)16 * 16 * (qc + 1) * 2;
@@ -424,7 +420,7 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         const bool padded = 16 * groups * 5 > p.Mc * 6;                         // > 20 % idle blocks
         const bool short_k = p.K <= 32 && p.M >= 16 && p.N >= 16;               // the weight gradient: K = batch
         const bool huge_out = short_k && 8.0 * p.M * p.N * p.Mc * p.ncorner > 200e6;
-        if (UNO_K2_BLOCKS && !padded && !huge_out) {
+        if (!padded && !huge_out) {
             // short K and many rows / columns: 16 x 16 outputs per wave, so that each operand row is re-read by N / 16 (M / 16)
             // waves like in the LDS-staged form; few rows (the batch, in the forward /
             // input-gradient forms): all of them in one wave, more columns

@@ -97,9 +97,6 @@ __global__ __launch_bounds__(256) void resample_cols_generic_kernel(const TI* __
 //   phase 2 (columns): banded column operator from LDS, TR x Wo outputs written unit-stride.
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
-#ifndef UNO_K7_EXP
-#define UNO_K7_EXP 0            // timing experiments (tools/dev/mkvariant.py): 1 = phase 1 only, 2 = phase 2 only, 3 = phase 2 without stores, 4 = phase 2 without LDS reads
-#endif
 
 // MF: phase 1 on v_mfma_f32_16x16x4_f32.  The dense 16 x NP row operator of the tile is the A operand (one LDS read per k-step
 // from a table in operand layout), a lane's 16-byte piece of an input row is the B operand of FOUR column tiles (tile e = columns 4 n + e of the
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
             sWd[e] = u < NP ? tile_w[((size_t)tile * NP + u) * RS_TR + (e & 15)] : 0.f;
         }
         __syncthreads();
-        for (int c0 = 64 * wave; c0 < ((UNO_K7_EXP >= 2) ? 0 : W); c0 += 64 * nwaves) {
+        for (int c0 = 64 * wave; c0 < W; c0 += 64 * nwaves) {
             // this lane's four columns; pieces past the row end are pulled back inside the row (their results are not stored)
             const int col = min(c0 + 4 * n16, max(W - 4, 0));
             const T* colp = src + col;
@@ -220,7 +217,6 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
     }
     }
     __syncthreads();
-    if (UNO_K7_EXP == 1) return;
     T* dst = out + ((size_t)n * Ho + i0) * Wo;
     const int nr = min(RS_TR, Ho - i0);
     // phase 2: thread -> (row group g, column j): when the workgroup is wider than a row, groups take rows round-robin
@@ -244,11 +240,10 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
                 const float* v = V + r * WP;
                 float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], (UNO_K7_EXP == 4) ? (float)t : v[min(s + t, W - 1)], acc);
+                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
                 // ACCUM is a template parameter: a run-time flag here put a conditional load into the store loop and
                 // cost the plain path 60 % (227 -> 362 us at 1024 x 446^2 -> 223^2)
-                if (UNO_K7_EXP == 3) { if (acc == 123.456f) io_store1(dst + (size_t)r * Wo + j, acc); }
-                else io_store1(dst + (size_t)r * Wo + j, ACCUM ? io_widen(dst[(size_t)r * Wo + j]) + acc : acc);
+                io_store1(dst + (size_t)r * Wo + j, ACCUM ? io_widen(dst[(size_t)r * Wo + j]) + acc : acc);
             }
         }
     }
@@ -277,10 +272,7 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
         const int nthreads = ((((W + sweeps - 1) / sweeps) + 63) / 64) * 64;
         const int ntiles = (Ho + RS_TR - 1) / RS_TR;
         const dim3 grid((unsigned)(((n_img + 7) / 8) * 8) * ntiles);
-#ifndef UNO_K7_MFMA
-#define UNO_K7_MFMA 1
-#endif
-        const bool mf = UNO_K7_MFMA && W >= 4;
+        const bool mf = W >= 4;             // row operator on MFMA (rows of at least one 16-byte piece)
 #define UNO_RS_LAUNCH(A, K)                                                                                                    \
         do {                                                                                                                   \
             if (bf16 && mf) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t, true>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \

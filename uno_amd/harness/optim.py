@@ -35,6 +35,9 @@ class ComplexAdam(Optimizer):
                                     [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params])
             self._plans[key] = plan
         plan.step(step, lr, beta1, beta2, eps, wd)
+        # the kernel writes the parameters through raw pointers: tell autograd they changed (version counters guard saved tensors
+        # and key the half-precision weight copies of the mixed-precision layers)
+        torch.autograd.graph.increment_version(params)
 
     @staticmethod
     def _real(t):

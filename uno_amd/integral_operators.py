@@ -59,9 +59,21 @@ def enable_mixed_precision(module: nn.Module, enabled: bool = True) -> nn.Module
 
 
 def _half_weights(w1, w2):
-    """(Ci, Co, m1, m2, 2) float16 copies of two complex64 weight tensors (storage format of the mixed-precision kernels)."""
+    """(Ci, Co, m1, m2, 2) float16 copies of two complex64 weight tensors (storage format of the mixed-precision kernels).  The copy
+    of a parameter is kept on it and re-made only when the parameter changed (its version counter moves with every in-place
+    update - the optimiser step): repeated forward passes between updates (evaluation, roll-outs) convert nothing."""
+    out = []
     with torch.no_grad():
-        return torch.view_as_real(w1.detach()).half().contiguous(), torch.view_as_real(w2.detach()).half().contiguous()
+        for w in (w1, w2):
+            cached = getattr(w, "_uno_half", None)
+            if cached is None or cached[0] != w._version or cached[1].device != w.device or cached[2] != w.data_ptr():
+                cached = (w._version, torch.view_as_real(w.detach()).half().contiguous(), w.data_ptr())
+                try:
+                    w._uno_half = cached
+                except (AttributeError, RuntimeError):
+                    pass
+            out.append(cached[1])
+    return out[0], out[1]
 
 
 def _plain(t: torch.Tensor) -> torch.Tensor:
