@@ -15,7 +15,9 @@ def rel(a, b):
     return d / n if n > 0 else d
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 1, 1, 1), (3, 16, 111, 111), (2, 8, 223, 223), (2, 4, 12, 10, 9), (2, 6, 1003)])
+# rows of 35 .. 64000 floats run the register-resident kernels (4, 8, 13, 16, 25, 32 quads per thread), 90000 the sweep kernels
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 1, 1, 1), (3, 16, 111, 111), (2, 8, 223, 223), (2, 4, 12, 10, 9), (2, 6, 1003),
+                                   (1, 3, 150, 150), (1, 2, 180, 181), (1, 2, 256, 250), (1, 2, 300, 300), (2, 2, 3)])
 @pytest.mark.parametrize("gelu", [True, False])
 @pytest.mark.parametrize("affine", [True, False])
 def test_instance_norm_gelu(shape, gelu, affine):

@@ -148,11 +148,141 @@ __global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const T* __restrict_
     });
 }
 
+// ---- register-resident forms.  The sweeps above read a row three times (forward) / twice twice (backward); only the first pass
+// is meant to come from HBM, but with every workgroup of the launch resident at once the rows in flight (2048 rows x 199 KB at the
+// 128-channel 223^2 level of the Darcy model) are far beyond the L2s, so the later sweeps stream from the Infinity Cache / HBM
+// again: 3.4 TB/s on the algorithmic bytes.  A row of up to 512 x 4 NQ floats fits the REGISTERS of its workgroup (NQ <= 32 quads
+// per thread forward, 25 backward where x and gy are both held): each element is loaded once, the statistics and the output come
+// out of registers.  Same arithmetic and the same fixed-order reductions as the sweep kernels (bit-identical results).
+template <bool GELU, typename T, int NQ>
+__global__ __launch_bounds__(IN_T) void instnorm_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, T* __restrict__ y,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps) {
+    __shared__ float red[IN_T / 64];
+    const int r = blockIdx.x, c = r % C;
+    const T* row = x + (size_t)r * N;
+    T* dst = y + (size_t)r * N;
+    const int nq = N >> 2, tail = N & 3;
+    in_f4 v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) v[i] = in_ld4(row + 4 * min((int)threadIdx.x + i * IN_T, max(nq - 1, 0)));
+    float tv[3] = {0.f, 0.f, 0.f};
+    if (threadIdx.x == 0)
+        for (int i = 0; i < tail; ++i) tv[i] = io_widen(row[4 * nq + i]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if ((int)threadIdx.x + i * IN_T < nq) s += ((v[i].v[0] + v[i].v[1]) + v[i].v[2]) + v[i].v[3];
+    if (threadIdx.x == 0) for (int i = 0; i < tail; ++i) s += tv[i];
+    const float mean = in_block_sum(s, red) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if ((int)threadIdx.x + i * IN_T < nq) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i].v[e] - mean; q = fmaf(d, d, q); }
+        }
+    if (threadIdx.x == 0) for (int i = 0; i < tail; ++i) { const float d = tv[i] - mean; q = fmaf(d, d, q); }
+    const float var = in_block_sum(q, red) / (float)N;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (threadIdx.x == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float a = g * rstd, sh = b - mean * a;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = threadIdx.x + i * IN_T;
+        if (qi < nq) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float z = fmaf(a, v[i].v[e], sh); o[e] = GELU ? in_gelu(z) : z; }
+            io_store4(dst + 4 * qi, o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < tail; ++i) { const float z = fmaf(a, tv[i], sh); io_store1(dst + 4 * nq + i, GELU ? in_gelu(z) : z); }
+}
+
+template <bool GELU, typename T, int NQ>
+__global__ __launch_bounds__(IN_T) void instnorm_bwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                T* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N) {
+    __shared__ float red[IN_T / 64];
+    const int r = blockIdx.x, c = r % C;
+    const T* row = x + (size_t)r * N;
+    const T* grow = gy + (size_t)r * N;
+    T* dst = gx + (size_t)r * N;
+    const int nq = N >> 2, tail = N & 3;
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    // held per element: xhat and g_z (the two sweeps of the other kernel recompute them from x and gy)
+    in_f4 xh[NQ], gz[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qc = min((int)threadIdx.x + i * IN_T, max(nq - 1, 0));
+        xh[i] = in_ld4(row + 4 * qc);
+        gz[i] = in_ld4(grow + 4 * qc);
+    }
+    float txh[3] = {0.f, 0.f, 0.f}, tgz[3] = {0.f, 0.f, 0.f};
+    if (threadIdx.x == 0)
+        for (int i = 0; i < tail; ++i) { txh[i] = io_widen(row[4 * nq + i]); tgz[i] = io_widen(grow[4 * nq + i]); }
+    auto to_pair = [&](float& xv, float& gv) {          // (x, gy) -> (xhat, g_z)
+        const float h = (xv - mean) * rstd;
+        gv = GELU ? in_dgelu(fmaf(g, h, b)) * gv : gv;
+        xv = h;
+    };
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const bool valid = (int)threadIdx.x + i * IN_T < nq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            to_pair(xh[i].v[e], gz[i].v[e]);
+            if (valid) { s1 += gz[i].v[e]; s2 = fmaf(gz[i].v[e], xh[i].v[e], s2); }
+        }
+        // one quad at a time: left to interleave the erf / exp chains of many quads the compiler needs ~15 temporaries per chain on
+        // top of the 2 x 4 NQ held values and spills (337 registers at NQ = 25)
+        if (GELU) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < tail; ++i) { to_pair(txh[i], tgz[i]); s1 += tgz[i]; s2 = fmaf(tgz[i], txh[i], s2); }
+    const float S1 = in_block_sum(s1, red), S2 = in_block_sum(s2, red);
+    if (threadIdx.x == 0) { s1_out[r] = S1; s2_out[r] = S2; }
+    const float m1 = S1 / (float)N, m2 = S2 / (float)N, gr = g * rstd;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qi = threadIdx.x + i * IN_T;
+        if (qi < nq)
+            io_store4(dst + 4 * qi, gr * (gz[i].v[0] - m1 - xh[i].v[0] * m2), gr * (gz[i].v[1] - m1 - xh[i].v[1] * m2),
+                      gr * (gz[i].v[2] - m1 - xh[i].v[2] * m2), gr * (gz[i].v[3] - m1 - xh[i].v[3] * m2));
+    }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < tail; ++i) io_store1(dst + 4 * nq + i, gr * (tgz[i] - m1 - txh[i] * m2));
+}
+
+// quads per thread of the register-resident forms for a row of N floats (0: the row is too long - sweep kernels)
+static int instnorm_reg_quads(long long N, int max_quads) {
+    const long long need = ((N >> 2) + IN_T - 1) / IN_T;
+    for (int nq : {4, 8, 13, 16, 25, 32})
+        if (need <= nq && nq <= max_quads) return nq;
+    return 0;
+}
+
 int launch_instnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
                         long long N, float eps, int gelu, int bf16, hipStream_t s) {
     typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
-    {
+    if (const int rq = (N >= 4 ? instnorm_reg_quads(N, 32) : 0)) {
+        ProfScope prof("uno::instnorm_fwd_reg_kernel", (bf16 ? 4.0 : 8.0) * rows * (double)N, s);
+        const dim3 grid((unsigned)rows);
+#define UNO_IN_FWD(G, TT, Q) hipLaunchKernelGGL((instnorm_fwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, (int)N, eps)
+#define UNO_IN_FWD_Q(G, TT) do { switch (rq) { case 4: UNO_IN_FWD(G, TT, 4); break; case 8: UNO_IN_FWD(G, TT, 8); break; case 13: UNO_IN_FWD(G, TT, 13); break; \
+                                   case 16: UNO_IN_FWD(G, TT, 16); break; case 25: UNO_IN_FWD(G, TT, 25); break; default: UNO_IN_FWD(G, TT, 32); } } while (0)
+        if (bf16) { if (gelu) UNO_IN_FWD_Q(true, bf_t); else UNO_IN_FWD_Q(false, bf_t); }
+        else { if (gelu) UNO_IN_FWD_Q(true, float); else UNO_IN_FWD_Q(false, float); }
+#undef UNO_IN_FWD_Q
+#undef UNO_IN_FWD
+    } else {
         ProfScope prof("uno::instnorm_fwd_kernel", (bf16 ? 4.0 : 8.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
         if (bf16) {
@@ -172,7 +302,19 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
                         void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, int bf16, hipStream_t s) {
     typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
-    {
+    // with the GELU derivative (erf + exp per element) the compiler keeps the held values in registers only up to 8 quads per
+    // thread (13: 40 spilled registers, 25: 344): longer rows take the sweep kernel there
+    if (const int rq = (N >= 4 ? instnorm_reg_quads(N, gelu ? 8 : 25) : 0)) {
+        ProfScope prof("uno::instnorm_bwd_reg_kernel", (bf16 ? 6.0 : 12.0) * rows * (double)N, s);
+        const dim3 grid((unsigned)rows);
+#define UNO_IN_BWD(G, TT, Q) hipLaunchKernelGGL((instnorm_bwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, (const TT*)gy, gamma, beta, mean, rstd, (TT*)gx, s1, s2, C, (int)N)
+#define UNO_IN_BWD_Q(G, TT) do { switch (rq) { case 4: UNO_IN_BWD(G, TT, 4); break; case 8: UNO_IN_BWD(G, TT, 8); break; case 13: UNO_IN_BWD(G, TT, 13); break; \
+                                   case 16: UNO_IN_BWD(G, TT, 16); break; default: UNO_IN_BWD(G, TT, 25); } } while (0)
+        if (bf16) { if (gelu) UNO_IN_BWD_Q(true, bf_t); else UNO_IN_BWD_Q(false, bf_t); }
+        else { if (gelu) UNO_IN_BWD_Q(true, float); else UNO_IN_BWD_Q(false, float); }
+#undef UNO_IN_BWD_Q
+#undef UNO_IN_BWD
+    } else {
         ProfScope prof("uno::instnorm_bwd_kernel", (bf16 ? 6.0 : 12.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
         if (bf16) {
