@@ -38,11 +38,8 @@ __device__ __forceinline__ float4 load4_tail(const T* row, int px, int P) {
 // exact-erf GELU (F.gelu default) and its derivative, for the fused forms: x := gelu(x) while a chunk goes to LDS
 // (`act_in`: the layer consumes the activation of a tensor that is kept pre-activation) and y := (W x) * gelu'(pre) in the
 // epilogue (`dgelu_of`: the input gradient of such a layer, handed back as the gradient of the pre-activation tensor)
-__device__ __forceinline__ float cm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float cm_dgelu(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-    return fmaf(x, 0.39894228040143267794f * expf(-0.5f * x * x), cdf);
-}
+__device__ __forceinline__ float cm_gelu(float x) { return uno_gelu(x); }
+__device__ __forceinline__ float cm_dgelu(float x) { return uno_dgelu(x); }
 __device__ __forceinline__ float4 cm_gelu4(float4 v) { return make_float4(cm_gelu(v.x), cm_gelu(v.y), cm_gelu(v.z), cm_gelu(v.w)); }
 
 struct ChannelMixParams {

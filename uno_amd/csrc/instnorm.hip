@@ -14,12 +14,8 @@
 
 namespace uno {
 
-__device__ __forceinline__ float in_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float in_dgelu(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return fmaf(x, pdf, cdf);
-}
+__device__ __forceinline__ float in_gelu(float x) { return uno_gelu(x); }
+__device__ __forceinline__ float in_dgelu(float x) { return uno_dgelu(x); }
 
 constexpr int IN_T = 512;           // threads per row
 

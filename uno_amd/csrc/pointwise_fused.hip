@@ -14,12 +14,8 @@
 
 namespace uno {
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return fmaf(x, pdf, cdf);
-}
+__device__ __forceinline__ float gelu_f(float x) { return uno_gelu(x); }
+__device__ __forceinline__ float dgelu_f(float x) { return uno_dgelu(x); }
 
 // up to four consecutive floats row[px .. px+3] with zeros from `n` on (n = valid floats in the row, n >= 4)
 // T = float, or unsigned short = bfloat16 bits (config C5: activations bf16, weights and every accumulation f32; widened on
@@ -149,8 +145,8 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restri
             const float wc = sw[c];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float cdf = 0.5f * (1.f + erff(v[i] * 0.70710678118654752440f));
-                const float pdf = 0.39894228040143267794f * expf(-0.5f * v[i] * v[i]);
+                const float cdf = 0.5f * (1.f + uno_erf(v[i] * 0.70710678118654752440f));
+                const float pdf = 0.39894228040143267794f * __expf(-0.5f * v[i] * v[i]);
                 o[i] = fmaf(v[i], pdf, cdf) * (wc * g[i]);
                 s = fmaf(g[i], v[i] * cdf, s);              // g is zero past the row end
             }

@@ -14,6 +14,41 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// erf in float32 as ONE branch-free rational function (odd degree-13 / even degree-8 in the clamped argument, the approximant of
+// Eigen's / XLA's float erf): 12 fmas, a reciprocal with one Newton step, no exp.  Maximum error 4.5e-7 (absolute and relative)
+// over the real line, i.e. the exact-erf GELU 0.5 x (1 + erf(x / sqrt 2)) of the reference (F.gelu, integral_operators.py:282)
+// comes out with the SAME error against float64 as torch's own float32 kernel (relative L2 7e-8, largest element error 1.4e-6:
+// measured on 2 M points, tools/dev/erf_accuracy.py).  The library erff is a branching piecewise form (|x| < 1 polynomial, else
+// exp-based): the lanes of a wave take both paths, ~3x the instructions - and the GELU forms sit on the load / store paths of
+// K8, K9, K11, K12, K13, where they were the co-limiter (the fused-GELU instantiations ran 20-50 % behind the plain ones).
+__device__ __forceinline__ float uno_erf(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -4.f), 4.f);          // |x| >= 4: erf = +-1 in float32
+    const float t = x * x;
+    float p = -2.72614225801306e-10f;
+    p = fmaf(p, t, 2.77068142495902e-08f);
+    p = fmaf(p, t, -2.10102402082508e-06f);
+    p = fmaf(p, t, -5.69250639462346e-05f);
+    p = fmaf(p, t, -7.34990630326855e-04f);
+    p = fmaf(p, t, -2.95459980854025e-03f);
+    p = fmaf(p, t, -1.60960333262415e-02f);
+    p *= x;
+    float q = -1.45660718464996e-05f;
+    q = fmaf(q, t, -2.13374055278905e-04f);
+    q = fmaf(q, t, -1.68282697438203e-03f);
+    q = fmaf(q, t, -7.37332916720468e-03f);
+    q = fmaf(q, t, -1.42647390514189e-02f);
+    float r = __builtin_amdgcn_rcpf(q);
+    r = r * fmaf(-q, r, 2.f);                                    // one Newton step: the quotient is correctly rounded to ~0.5 ulp
+    return p * r;
+}
+// exact-erf GELU and its derivative (Phi(x) + x phi(x)); exp through v_exp_f32 (2 ulp: the term is <= 0.4 |x| e^{-x^2 / 2})
+__device__ __forceinline__ float uno_gelu(float x) { return 0.5f * x * (1.f + uno_erf(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float uno_dgelu(float x) {
+    const float cdf = 0.5f * (1.f + uno_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
 // idx, inc and lim are byte offsets into a float2 table of lim/8 entries; idx < lim, inc < lim.
 __device__ __forceinline__ unsigned wrap_add(unsigned idx, unsigned inc, unsigned lim) {
     unsigned t = idx + inc;
