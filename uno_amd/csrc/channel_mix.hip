@@ -114,8 +114,9 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             // W chunk as ONE 16-byte load per thread along whichever index is contiguous in memory (4 dword loads
             // per thread made W the most numerous vector-memory instruction of the tile; the address unit was the
             // busiest block of the CU)
-            const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + (tid & 15) * 4)
-                                     : (unsigned)((o0 + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
+            // (rows / columns of W past the last output channel of a partial tile are clamped: their products are never stored)
+            const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + min(o0 + (tid & 15) * 4, p.Co - 4))
+                                     : (unsigned)(min(o0 + (tid >> 2), p.Co - 1) * p.w_so + k0 + (tid & 3) * 4);
             const f4u wv = *reinterpret_cast<const f4u*>(p.w + woff);
 #pragma unroll
             for (int j = 0; j < 4; ++j) rw[j] = wv.v[j];
@@ -185,17 +186,20 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
+    const bool wave_ok = MODE != 2 || o0 + 16 * wave < p.Co;         // interior path of a partial channel tile: whole waves idle
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) load_chunk((c + 1) * CM_KC);        // global -> registers while this chunk is multiplied
+        if (wave_ok) {
 #pragma unroll
-        for (int ks = 0; ks < CM_KC / 4; ++ks) {
-            // D^T = X^T W^T: A[i = px][k] = X[k][16 mt + r16], B[k][j = o] = Wm(16 wave + r16, k): a lane ends up with
-            // 4 consecutive pixels of one output channel -> one 16-byte store
-            const float wv = sW[buf][(4 * ks + kk) * CM_WS + 16 * wave + r16];
-            const float* xrow = sX[buf] + (4 * ks + kk) * XS + r16;
+            for (int ks = 0; ks < CM_KC / 4; ++ks) {
+                // D^T = X^T W^T: A[i = px][k] = X[k][16 mt + r16], B[k][j = o] = Wm(16 wave + r16, k): a lane ends up with
+                // 4 consecutive pixels of one output channel -> one 16-byte store
+                const float wv = sW[buf][(4 * ks + kk) * CM_WS + 16 * wave + r16];
+                const float* xrow = sX[buf] + (4 * ks + kk) * XS + r16;
 #pragma unroll
-            for (int mt = 0; mt < NM; ++mt) acc[mt] = mfma16(xrow[16 * mt], wv, acc[mt]);
+                for (int mt = 0; mt < NM; ++mt) acc[mt] = mfma16(xrow[16 * mt], wv, acc[mt]);
+            }
         }
         if (c + 1 < nchunk) store_chunk(buf ^ 1);
         __syncthreads();
@@ -212,7 +216,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         // bias of the wave's 16 channels: one load per lane up front, handed out by shuffle (a load per stored row inside
         // the loop below put an L2 round trip in front of every store); likewise all reads of an accumulating call are
         // issued before the first store (the compiler must keep a later load of y behind an earlier store to y)
-        const float bias_l = p.bias ? p.bias[o0 + 16 * wave + r16] : 0.f;
+        const float bias_l = (p.bias && wave_ok) ? p.bias[o0 + 16 * wave + r16] : 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if ((r16 >> 3) == h) {
@@ -224,6 +228,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             float4 old[4], pre[DG ? 4 : 1];
             T* dst[4];
             size_t aoff[4];
+            if (wave_ok) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
@@ -252,6 +257,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 }
                 io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
                 if (aall) io_store4(aall + aoff[it], cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
+            }
             }
             __syncthreads();
         }
@@ -311,7 +317,11 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
     if constexpr (TINY) {
         channel_mix_tile<0, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
     } else {
-        if (p0 + PT <= p.P && o0 + CM_MT <= p.Co && (p.Ci & (CM_KC - 1)) == 0) channel_mix_tile<2, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
+        // interior path: whole pixel tile, whole 16-channel chunks, and the output channels of the tile end on a wave boundary
+        // (a last tile with 16 / 32 / 48 valid channels - the 32-channel input gradient of the lift - keeps its whole waves and
+        // idles the others instead of falling back to the guarded path)
+        if (p0 + PT <= p.P && (p.Ci & (CM_KC - 1)) == 0 && (o0 + CM_MT <= p.Co || ((p.Co - o0) & 15) == 0))
+            channel_mix_tile<2, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
         else channel_mix_tile<1, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
     }
 }
