@@ -192,13 +192,16 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
  *   w is the layer's full (Co, Ci) weight (transpose_w = 1: (Ci, Co)), bias (Co) or NULL;
  *   act_in applies to x1 only, dgelu_of (B, Co1, P) to y1 only (the pre-activation source of the pair);
  *   y_act (B, Co, P) or NULL: additionally receives gelu(y) - the activation of a block without normalisation written by the
- *   kernel that completes the pre-activation sum (reference integral_operators.py:282-283), single destination only.
+ *   kernel that completes the pre-activation sum (reference integral_operators.py:282-283), single destination only;
+ *   proj_w (Co), proj_b (1) or NULL, proj_out (B, P): the call also writes proj_out[b][p] = proj_b + sum_o proj_w[o] gelu(y[b][o][p]),
+ *   the one-channel projection `fc2(F.gelu(fc1(x)))` that ends the models (darcy_flow_uno2d.py:128-131) in the pass that produces
+ *   y (which is still written: the backward of uno_gelu_project_forward needs it); Co <= 64, single destination.
  * Splits must be multiples of 16 (C1) / 64 (Co1; 128 when Co is a multiple of 128) channels; uno_channel_wgrad2 needs
  * C1 % 64 == 0 and P >= 64 (x2 = NULL: any shape).  gw is the full (Co, Ci) gradient; accumulate != 0: gw / gb += (the kernels
  * write a parameter's gradient buffer in place: the unrolled roll-out of ns_train_2d.py:46-68 sums 40 contributions per weight). */
 int uno_channel_mix2(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
                      float* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
-                     const float* dgelu_of, void* stream);
+                     const float* dgelu_of, const float* proj_w, const float* proj_b, float* proj_out, void* stream);
 int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
                        int Co, long long P, int act_x, int accumulate, void* stream);
 
@@ -273,7 +276,7 @@ int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, 
                            int act_x, void* stream);
 int uno_channel_mix2_bf16(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
                           void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
-                          const void* dgelu_of, void* stream);
+                          const void* dgelu_of, const float* proj_w, const float* proj_b, void* proj_out, void* stream);
 int uno_channel_wgrad2_bf16(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
                             int Co, long long P, int act_x, int accumulate, void* stream);
 int uno_gelu_project_forward_bf16(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P,

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "uno_channel_mix": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
     "uno_channel_wgrad_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
-    "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
+    "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_mode_wgrad_acc": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
     "uno_spectral_conv2d_backward_acc": (C.c_int, [_fp] * 8 + [_i] * 11 + [_fp]),
@@ -70,7 +70,7 @@ _SIGNATURES = {
     "uno_resample2d_bf16": (C.c_int, [_fp, _fp, _fp] + [_i] * 5 + [_fp, _fp, _i, _fp, _fp, _i, _fp, _fp, _i, _i, _fp]),
     "uno_channel_mix_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
     "uno_channel_wgrad_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
-    "uno_channel_mix2_bf16": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp]),
+    "uno_channel_mix2_bf16": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_channel_wgrad2_bf16": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_forward_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_backward_bf16": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
@@ -455,11 +455,12 @@ def channel_mix2_ok(C1: int, Co1, Co: int, P: int) -> bool:
 
 
 def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2=None, split_out: int | None = None,
-                 act_in: bool = False, dgelu_of=None, y_act: bool = False, accumulate: bool = False):
+                 act_in: bool = False, dgelu_of=None, y_act: bool = False, accumulate: bool = False, project=None):
     """uno_channel_mix2: y = Wm . cat(x1, x2) + bias in one pass (x2 may be None).
     split_out = Co1: the output channels go to two tensors (B, Co1, P), (B, Co - Co1, P) -> returns (y1, y2);
     y_act: also return gelu(y) as a second tensor -> (y, act); act_in / dgelu_of act on x1 / y1 only;
-    out (and out2): write (accumulate=True: add) into the given tensors instead of allocating."""
+    out (and out2): write (accumulate=True: add) into the given tensors instead of allocating;
+    project = (w2 (Co,), b2 (1,) or None): also return proj (B, P) = b2 + sum_o w2[o] gelu(y[:, o]) -> (y, proj)  (Co <= 64)."""
     bf16 = _act_dtype(x1, "x1")
     _require(w, torch.float32, "weight")
     if x2 is not None:
@@ -490,15 +491,28 @@ def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2
         if tuple(dgelu_of.shape) != (B, Co1, P):
             raise RuntimeError(f"uno_amd: dgelu_of has shape {tuple(dgelu_of.shape)}, expected {(B, Co1, P)}")
     null = C.c_void_p(0)
+    proj = pw = pb = None
+    if project is not None:
+        pw, pb = project
+        _require(pw, torch.float32, "projection weight")
+        if pw.numel() != Co:
+            raise RuntimeError(f"uno_amd: projection weight has {pw.numel()} entries for {Co} channels")
+        if pb is not None:
+            _require(pb, torch.float32, "projection bias")
+        proj = torch.empty((B, P), dtype=x1.dtype, device=x1.device)
     with torch.cuda.device(x1.device):
         fn = lib().uno_channel_mix2_bf16 if bf16 else lib().uno_channel_mix2
         rc = fn(_ptr(x1), _ptr(x2) if x2 is not None else null, C1, _ptr(w), _ptr(bias) if bias is not None else null,
                 _ptr(y1), _ptr(y2) if y2 is not None else null, Co1, _ptr(act) if act is not None else null,
                 B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, 1 if act_in else 0,
-                _ptr(dgelu_of) if dgelu_of is not None else null, _stream(x1))
+                _ptr(dgelu_of) if dgelu_of is not None else null,
+                _ptr(pw) if pw is not None else null, _ptr(pb) if pb is not None else null, _ptr(proj) if proj is not None else null,
+                _stream(x1))
     _check(rc, "uno_channel_mix2")
     if split_out is not None:
         return y1, y2
+    if project is not None:
+        return y1, proj
     return (y1, act) if y_act else y1
 
 

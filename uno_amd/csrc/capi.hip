@@ -383,7 +383,7 @@ int uno_channel_mix_bf16(const void* x, const float* w, const float* bias, void*
 
 static int channel_mix2_impl(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
                              void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
-                             const void* dgelu_of, int bf16, void* stream) {
+                             const void* dgelu_of, const float* proj_w, const float* proj_b, void* proj_out, int bf16, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (B == 0 || P == 0) return 0;
     if (!x1 || !w || !y1) { set_error("uno_channel_mix2: null pointer"); return -1; }
@@ -391,19 +391,22 @@ static int channel_mix2_impl(const void* x1, const void* x2, int C1, const float
     a.x = x1; a.x2 = x2; a.w = w; a.bias = bias; a.y = y1; a.y2 = y2; a.y_act = y_act; a.dgelu_of = dgelu_of;
     a.B = B; a.Ci = Ci; a.Co = Co; a.C1 = x2 ? C1 : Ci; a.Co1 = y2 ? Co1 : Co; a.P = P;
     a.transpose_w = transpose_w; a.accumulate = accumulate; a.act_in = act_in; a.bf16 = bf16;
+    a.proj_w = proj_w; a.proj_b = proj_b; a.proj_out = proj_out;
     return launch_channel_mix2(a, (hipStream_t)stream);
 }
 
 int uno_channel_mix2(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
                      float* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
-                     const float* dgelu_of, void* stream) {
-    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 0, stream);
+                     const float* dgelu_of, const float* proj_w, const float* proj_b, float* proj_out, void* stream) {
+    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of,
+                             proj_w, proj_b, proj_out, 0, stream);
 }
 
 int uno_channel_mix2_bf16(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
                           void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
-                          const void* dgelu_of, void* stream) {
-    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, 1, stream);
+                          const void* dgelu_of, const float* proj_w, const float* proj_b, void* proj_out, void* stream) {
+    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of,
+                             proj_w, proj_b, proj_out, 1, stream);
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {

@@ -53,6 +53,9 @@ struct ChannelMixParams {
                             // two-source layer from one pass over grad_y), or nullptr with Co1 == Co
     void* y_act;            // nullptr, or (B, Co, P): also receives gelu(y) (the block's activation written by the kernel that
                             // completes the pre-activation sum; single destination only)
+    const float* proj_w;    // nullptr, or (Co): the kernel also writes proj_out[b][p] = proj_b + sum_o proj_w[o] gelu(y[b][o][p]) - the
+    const float* proj_b;    // models' final `fc2(F.gelu(fc1(x)))` with one output channel (darcy_flow_uno2d.py:128-131) without
+    void* proj_out;         // re-reading y; needs all output channels in ONE 64-channel tile (Co <= 64)
     int B, Ci, Co, P;
     int C1, Co1;
     int w_so, w_si;
@@ -217,6 +220,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         // the loop below put an L2 round trip in front of every store); likewise all reads of an accumulating call are
         // issued before the first store (the compiler must keep a later load of y behind an earlier store to y)
         const float bias_l = (p.bias && wave_ok) ? p.bias[o0 + 16 * wave + r16] : 0.f;
+        const float pw_l = (p.proj_w && wave_ok) ? p.proj_w[o0 + 16 * wave + r16] : 0.f;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};            // projection: this lane's 4 pixels, summed over the rows it handles
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if ((r16 >> 3) == h) {
@@ -257,15 +262,42 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 }
                 io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
                 if (aall) io_store4(aall + aoff[it], cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
+                if (p.proj_w) {
+                    const float pwv = __shfl(pw_l, 8 * h + row);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ps[i] = fmaf(pwv, cm_gelu(w4[i]), ps[i]);
+                }
             }
             }
             __syncthreads();
         }
+        if (p.proj_w) {
+            // lanes l and l + 32 hold the even / odd rows of the same 4 pixels; then the four waves (16 channels each) through LDS
+            // in a fixed order (the W staging buffers are free after the K loop)
+            float* sP = &sW[0][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ps[i] += __shfl_xor(ps[i], 32);
+            if (lane < 32) *reinterpret_cast<float4*>(sP + wave * PT + c4) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+            __syncthreads();
+            if (wave == 0 && lane < 32) {
+                const float pb = p.proj_b ? p.proj_b[0] : 0.f;
+                float r4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r4[i] = pb + (((sP[c4 + i] + sP[PT + c4 + i]) + sP[2 * PT + c4 + i]) + sP[3 * PT + c4 + i]);
+                io_store4(reinterpret_cast<T*>(p.proj_out) + (size_t)b * p.P + p0 + c4, r4[0], r4[1], r4[2], r4[3]);
+            }
+        }
         return;
     }
     const int o = o0 + 16 * wave + r16;
+    float pv[NM][4];                            // projection terms proj_w[o] gelu(y[o][px]) of this lane (zero where nothing is stored)
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[mt][r] = 0.f;
     if (MODE == 2 || o < p.Co) {
         const float bv = p.bias ? p.bias[o] : 0.f;
+        const float pwv = p.proj_w ? p.proj_w[o] : 0.f;
         T* yrow = ydst + (size_t)(o - dd.ob) * p.P;
         T* arow = aall ? aall + (size_t)o * p.P : nullptr;
 #pragma unroll
@@ -282,6 +314,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 for (int r = 0; r < 4; ++r) w4[r] += (acc[mt][r] + bv) * (dg ? cm_dgelu(pr4[r]) : 1.f);
                 io_store4(yrow + px, w4[0], w4[1], w4[2], w4[3]);
                 if (arow) io_store4(arow + px, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
+                if (p.proj_w) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[mt][r] = pwv * cm_gelu(w4[r]);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -290,9 +326,28 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                                         (acc[mt][r] + bv) * (dg ? cm_dgelu(io_widen(drow[px + r])) : 1.f);
                         io_store1(yrow + px + r, v);
                         if (arow) io_store1(arow + px + r, cm_gelu(v));
+                        if (p.proj_w) pv[mt][r] = pwv * cm_gelu(v);
                     }
             }
         }
+    }
+    if (p.proj_w) {
+        // sum over the wave's 16 channels (lanes r16 = 0..15 of a lane group), then the four waves through LDS in a fixed order
+        float* sP = &sW[0][0];
+        __syncthreads();                        // every wave is past its last read of the W staging buffer
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = pv[mt][r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (r16 == 0) sP[wave * PT + 16 * mt + 4 * kk + r] = v;
+            }
+        __syncthreads();
+        const float pb = p.proj_b ? p.proj_b[0] : 0.f;
+        for (int e = tid; e < PT; e += 256)
+            if (p0 + e < p.P)
+                io_store1(reinterpret_cast<T*>(p.proj_out) + (size_t)b * p.P + p0 + e, pb + (((sP[e] + sP[PT + e]) + sP[2 * PT + e]) + sP[3 * PT + e]));
     }
 }
 
@@ -506,6 +561,11 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     p.accumulate = a.accumulate ? 1 : 0;
     p.dgelu_of = a.dgelu_of;
     p.x = a.x; p.x2 = a.x2; p.w = a.w; p.bias = a.bias; p.y = a.y; p.y2 = a.y2; p.y_act = a.y_act;
+    p.proj_w = a.proj_w; p.proj_b = a.proj_b; p.proj_out = a.proj_out;
+    if (a.proj_w && (!a.proj_out || Co > CM_MT || two_dst || a.dgelu_of)) {
+        set_error("channel_mix: the fused projection needs proj_out, Co <= %d, one destination and no dgelu_of", CM_MT);
+        return -2;
+    }
     p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
     p.C1 = two_src ? a.C1 : Ci;
     p.Co1 = two_dst ? a.Co1 : Co;
@@ -533,7 +593,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     const int accumulate = p.accumulate;
-    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024 && !two_src && !two_dst && !a.y_act) {
+    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024 && !two_src && !two_dst && !a.y_act && !a.proj_w) {
         ProfScope prof("uno::channel_mix_few_in_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
         const dim3 grid((unsigned)((P + 1023) / 1024), B);
 #define UNO_CMF(C) do { if (bf16) hipLaunchKernelGGL((channel_mix_few_in_kernel<C, true>), grid, dim3(256), 0, s, p); \
@@ -547,7 +607,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
         ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
-                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0)) + 4.0 * Ci * Co, s);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
         if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else {

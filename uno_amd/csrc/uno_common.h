@@ -235,6 +235,7 @@ int launch_resample2d(const void* in, void* out, float* tmp, int n_img, int H, i
 // [0, Co1) to y, [Co1, Co) to y2; dgelu_of goes with y), optional activated copy y_act = gelu(y); nullptr x2 / y2 / y_act = plain
 struct ChannelMixArgs {
     const void* x; const void* x2; const float* w; const float* bias; void* y; void* y2; void* y_act; const void* dgelu_of;
+    const float* proj_w; const float* proj_b; void* proj_out;       // fused one-channel projection of gelu(y) (Co <= 64), or nullptr
     int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
 };
 int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s);

@@ -15,8 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..integral_operators import (GradJoin, OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, gelu_channel_mix, gelu_pad2d,
-                                  gelu_project)
+from ..integral_operators import (GradJoin, OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, channel_mix_cat_project,
+                                  gelu_channel_mix, gelu_pad2d, gelu_project)
 
 
 class UNO_9(nn.Module):
@@ -75,8 +75,10 @@ class UNO_9(nn.Module):
             # sources; the concatenations are never built.  conv5's GELU is deferred to its only consumer: fc1 applies it while
             # reading the pre-activation tensor
             skip5 = [self.conv4(c2, d1 // 2, d2 // 2), c0]
-            c5 = channel_mix_cat([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True, defer_grad=jc), lifted], self.fc1.weight,
-                                 self.fc1.bias, gelu_first=True, defer_grad=jl)
+            # fc2(gelu(fc1(cat([gelu(conv5 pre), lifted])))): one forward kernel (the fc1 pass also reduces its 64 channels to the output)
+            out = channel_mix_cat_project([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True, defer_grad=jc), lifted], self.fc1.weight,
+                                          self.fc1.bias, self.fc2.weight, self.fc2.bias, gelu_first=True, defer_grad=jl)
+            return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()
         else:
             c0 = self.conv0(lifted, d1 // 2, d2 // 2)
             c1 = self.conv1(c0, d1 // 4, d2 // 4)

@@ -31,7 +31,7 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 __all__ = [
-    "enable_mixed_precision", "GradJoin",
+    "enable_mixed_precision", "GradJoin", "channel_mix_cat_project",
     "SpectralConv1d_Uno", "pointwise_op_1D", "OperatorBlock_1D",
     "SpectralConv2d_Uno", "pointwise_op_2D", "OperatorBlock_2D",
     "SpectralConv3d_Uno", "pointwise_op_3D", "OperatorBlock_3D",
@@ -351,8 +351,12 @@ class _ChannelMixCatFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x1, x2, w = ctx.saved_tensors
-        gy = _plain(gy)
+        x1, x2, w = ctx.saved_tensors[:3]
+        return _ChannelMixCatFn._backward(ctx, x1, x2, w, _plain(gy)) + (None, None, None, None)
+
+    @staticmethod
+    def _backward(ctx, x1, x2, w, gy):
+        """(g1, g2, gw, gb) of y = W . cat([gelu](x1), x2) + b for the output gradient gy (shared with the fused-projection form)"""
         C1 = x1.shape[1]
         g1 = g2 = None
         if ctx.defer is not None and ctx.defer.owner and ctx.needs_input_grad[1]:     # owner still pending: its backward has not run yet
@@ -368,9 +372,50 @@ class _ChannelMixCatFn(torch.autograd.Function):
             g1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
         elif ctx.needs_input_grad[1]:
             g2 = _native.channel_mix(gy, w[:, C1:].contiguous(), None, transpose_w=True)
-        gw = gb = None
         gw, gb = _wgrad_into(ctx.leaves, gy, x1, x2, ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3], act_x=ctx.gelu_first)
-        return g1, g2, gw, gb, None, None, None, None
+        return g1, g2, gw, gb
+
+
+class _ChannelMixCatProjectFn(torch.autograd.Function):
+    """out[b, p] = b2 + sum_o w2[o] gelu(y[b, o, p]),  y = W . cat([gelu](x1), x2) + b: the end of the models, `fc2(F.gelu(fc1(cat)))`
+    with one output channel (reference darcy_flow_uno2d.py:122-131), in ONE pass - the channel-mix kernel that produces y (kept:
+    its GELU derivative is needed backward) also reduces its 64-channel tile to the projected value, so y is not read again."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias, w2, b2, gelu_first, defer=None, leaves=None):
+        ctx.leaves = leaves
+        x1, x2, w, w2 = _plain(x1), _plain(x2), _plain(w), _plain(w2)
+        y, out = _native.channel_mix2(x1, x2, w, None if bias is None else _plain(bias), act_in=gelu_first,
+                                      project=(w2, None if b2 is None else _plain(b2)))
+        ctx.save_for_backward(x1, x2, w, y, w2)
+        ctx.has_bias, ctx.has_b2 = bias is not None, b2 is not None
+        ctx.gelu_first = gelu_first
+        ctx.defer = defer if (defer is not None and defer.owner and ctx.needs_input_grad[1]) else None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x1, x2, w, y, w2 = ctx.saved_tensors
+        gy, gw2, gb2 = _native.gelu_project_backward(y, w2, _plain(gout), need_bias=ctx.has_b2)
+        g1, g2, gw, gb = _ChannelMixCatFn._backward(ctx, x1, x2, w, gy)
+        return g1, g2, gw, gb, gw2, gb2, None, None, None
+
+
+def channel_mix_cat_project(xs, weight, bias, weight2, bias2, gelu_first: bool = False, defer_grad=None):
+    """gelu_project(channel_mix_cat(xs, weight, bias, gelu_first), weight2, bias2) - `fc2(F.gelu(fc1(torch.cat(xs, 1))))` of the
+    models - as one forward kernel where the shapes allow (two device tensors split at a multiple of 16 channels, at most 64
+    channels between the two layers, ONE output channel)."""
+    Co = weight.shape[0]
+    if (len(xs) == 2 and all(_dev_act(x) for x in xs) and xs[0].dtype == xs[1].dtype and weight.dtype == torch.float32
+            and weight2.shape[0] == 1 and Co <= 64 and xs[0].shape[1] % 16 == 0 and weight2.dtype == torch.float32):
+        x1, x2 = xs
+        B = x1.shape[0]
+        w = weight.reshape(Co, -1)
+        out = _ChannelMixCatProjectFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias,
+                                            weight2.reshape(Co), bias2, bool(gelu_first), defer_grad, (weight, bias))
+        return out.view(B, 1, *x1.shape[2:])
+    return gelu_project(channel_mix_cat(xs, weight, bias, gelu_first=gelu_first, defer_grad=defer_grad), weight2, bias2)
 
 
 def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_first: bool = False, defer_grad=None) -> torch.Tensor:
