@@ -291,3 +291,43 @@ def test_channel_mix_cat_autograd_vs_torch(C1, C2, gelu_first):
     assert rel(y.detach(), yr.detach()) < 2e-6
     assert rel(x1.grad, xd1.grad) < 2e-6 and rel(x2.grad, xd2.grad) < 2e-6
     assert rel(w.grad, wd.grad) < 2e-5 and rel(b.grad, bd.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", [(2, 64, 64, 64, 446 * 9 + 3), (2, 16, 48, 40, 515), (1, 32, 0, 64, 128 * 5), (2, 64, 64, 33, 77), (2, 16, 16, 16, 3)])
+@pytest.mark.parametrize("act_in", [False, True])
+def test_fused_projection(B, C1, C2, Co, P, act_in):
+    """uno_channel_mix2 with proj_w: proj[b, p] = b2 + sum_o w2[o] gelu(y[b, o, p]) from the pass that writes y (interior tiles,
+    ragged pixel tiles, partial channel tiles, the scalar path)."""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + C2 + Co + P)
+    x1 = torch.randn(B, C1, P, generator=g).cuda()
+    x2 = torch.randn(B, C2, P, generator=g).cuda() if C2 else None
+    w, b = (torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    w2, b2 = torch.randn(Co, generator=g).cuda(), torch.randn(1, generator=g).cuda()
+    y, proj = _native.channel_mix2(x1, x2, w, b, act_in=act_in, project=(w2, b2))
+    xs = [_gelu64(x1) if act_in else x1.double()] + ([x2.double()] if C2 else [])
+    yr = _ref(torch.cat(xs, 1), w, b)
+    pr = (w2.double().view(1, -1, 1) * torch.nn.functional.gelu(yr)).sum(1) + b2.double()
+    assert rel(y, yr) < 2e-6 and proj.shape == (B, P) and rel(proj, pr) < 3e-6
+
+
+def test_channel_mix_cat_project_autograd_vs_torch():
+    from uno_amd.integral_operators import channel_mix_cat_project
+    torch.manual_seed(4)
+    B, C1, C2, Co, P = 2, 64, 64, 64, 1000
+    x1 = torch.randn(B, C1, P).cuda().requires_grad_(True)
+    x2 = torch.randn(B, C2, P).cuda().requires_grad_(True)
+    w = (torch.randn(Co, C1 + C2) / 11).cuda().requires_grad_(True)
+    b = torch.randn(Co).cuda().requires_grad_(True)
+    w2 = torch.randn(1, Co).cuda().requires_grad_(True)
+    b2 = torch.randn(1).cuda().requires_grad_(True)
+    gout = torch.randn(B, 1, P).cuda()
+    out = channel_mix_cat_project([x1, x2], w, b, w2, b2, gelu_first=True)
+    out.backward(gout)
+    d = [t.detach().double().requires_grad_(True) for t in (x1, x2, w, b, w2, b2)]
+    yr = torch.matmul(d[2], torch.cat([torch.nn.functional.gelu(d[0]), d[1]], 1)) + d[3].view(1, -1, 1)
+    outr = torch.matmul(d[4], torch.nn.functional.gelu(yr)) + d[5].view(1, 1, 1)
+    outr.backward(gout.double())
+    assert rel(out.detach(), outr.detach()) < 3e-6
+    for got, ref, tol in zip((x1, x2, w, b, w2, b2), d, (3e-6, 3e-6, 2e-5, 2e-5, 2e-5, 2e-5)):
+        assert rel(got.grad, ref.grad) < tol
