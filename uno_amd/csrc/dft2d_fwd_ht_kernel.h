@@ -472,10 +472,14 @@ static bool fwd_ht_geometry(const Dft2dParams& p, int NT, int MT, int R4, FwdFtG
     if (p.bf16 || p.rowfreq || nfull < 2 || p.W <= FT_MAXW) return false;
     // measured (1024 images, in-block, input cold): 421^2 227 us against 257 for the register path, 446^2 218 / 230, 223^2 51 / 47:
     // short rows make short runs (a run of the inner half of a 223-wide row is 0.4 KB), the register path keeps those
-    if (p.W < 300) return false;
+    // round 3: from 200 columns.  The 51 / 47 us above were taken with inputs that a standalone loop keeps partly cache-resident;
+    // inside a training step (inputs cold in HBM, tools/dev/steplaunches.py) the 223^2 layers of the Darcy model take 126-131 us here
+    // against 150-162 us on the register path at modes 18 (with the paired column stage) and 113-115 against 128-160 us at modes 8
+    if (p.W < 200) return false;
     const HtSplit sp = ht_split(p.W);
     if (sp.QL + sp.QR + 3 > 256 || sp.len_in + 3 > 256 || sp.len_in < 8) return false;      // a run is one 64-lane x 16-byte fetch
-    if ((size_t)MT * NT * 8 * 64 > (size_t)(sp.s0 + 15 * sp.seg)) return false;          // reduction slots must fit a buffer
+    const int MPh = (MT >= 3 && NT * MT < 12) ? MT / 2 + 1 : MT;                          // row tiles of the (paired) column stage
+    if ((size_t)MPh * NT * 8 * 64 > (size_t)(sp.s0 + 15 * sp.seg)) return false;         // reduction slots must fit a buffer
     const int nrt = (p.H + 15) / 16, cus = ft_device_cu_count();
     long long best_cost = -1;
     for (int nw = 1; nw <= 4 && nw <= nrt; nw *= 2) {
