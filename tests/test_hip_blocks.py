@@ -340,3 +340,35 @@ def test_weight_gradients_are_written_in_place():
         for p in params:
             if hasattr(p, "_uno_grad_buffer"):
                 del p._uno_grad_buffer
+
+
+@pytest.mark.gpu
+def test_inplace_weight_gradients_never_lose_a_contribution_silently():
+    """A weight that receives gradients from the library's kernels (in place) AND from a stock torch op in the same backward pass:
+    autograd may add the stock gradient out of place and so replace the tensor the kernels keep accumulating into.  The library
+    must then either still produce the right gradient or fail loudly - never train on a partial sum."""
+    import uno_amd.integral_operators as io
+    from uno_amd.integral_operators import channel_mix
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(8, 8).to(dev())
+    x = torch.randn(2, 8, 300, device=dev())
+
+    def loss_fn():
+        y = channel_mix(x, lin.weight, lin.bias)
+        y = y + torch.matmul(lin.weight, y)                    # the same weight through a stock op
+        return channel_mix(y, lin.weight, lin.bias).square().sum()
+
+    io.INPLACE_PARAM_GRADS = False
+    try:
+        lin.zero_grad(set_to_none=True)
+        loss_fn().backward()
+        ref = lin.weight.grad.clone()
+    finally:
+        io.INPLACE_PARAM_GRADS = True
+    lin.zero_grad(set_to_none=True)
+    try:
+        loss_fn().backward()
+    except RuntimeError as e:
+        assert "INPLACE_PARAM_GRADS" in str(e)
+        return
+    assert float((lin.weight.grad - ref).norm()) <= 2e-6 * float(ref.norm())

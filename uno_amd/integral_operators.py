@@ -179,7 +179,16 @@ _PASS = {"id": None, "acc": {}}         # per backward pass (autograd graph task
 
 
 def _end_of_pass():
-    _PASS["id"], _PASS["acc"] = None, {}
+    """End of a backward pass (engine callback: every node, AccumulateGrad included, has run).  A parameter that received SEVERAL
+    contributions in place must now have a .grad that aliases the tensor they were summed in; if it does not, autograd replaced
+    that tensor on the way (a gradient for the same parameter from a path outside this library was added out of place) and the
+    later in-place contributions would be missing - fail loudly instead of training on a wrong gradient."""
+    acc, _PASS["id"], _PASS["acc"] = _PASS["acc"], None, {}
+    for t, param, count in acc.values():
+        if count[0] > 1 and param.grad is not None and param.grad.data_ptr() != t.data_ptr():
+            raise RuntimeError("uno_amd: a parameter's gradient was accumulated in place by the library's kernels, but autograd also "
+                               "received gradients for it from other operations and replaced the buffer; set "
+                               "uno_amd.integral_operators.INPLACE_PARAM_GRADS = False for this model")
 
 
 def _grad_plan(p):
@@ -194,7 +203,7 @@ def _grad_plan(p):
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)     # drop the references when this pass completes
     acc = _PASS["acc"].get(id(p))
     if acc is not None:
-        return "acc", acc
+        return "acc", acc[0]
     if p.grad is not None:
         return None
     buf = getattr(p, "_uno_grad_buffer", None)
@@ -210,11 +219,13 @@ def _grad_targets(params):
     if any(pl is None for pl in plans) or len({pl[0] for pl in plans}) != 1:
         return None
     if plans[0][0] == "acc":
+        for p in params:
+            _PASS["acc"][id(p)][2][0] += 1
         return [(pl[1], True, None) for pl in plans]
     out = []
     for p, pl in zip(params, plans):
         buf = pl[1] if pl[1] is not None else torch.empty(p.shape, dtype=p.dtype, device=p.device)
-        _PASS["acc"][id(p)] = buf
+        _PASS["acc"][id(p)] = (buf, p, [1])        # (tensor the gradient is summed in, parameter, contributions so far)
         out.append((buf, False, buf.view(buf.shape)))
     return out
 
