@@ -31,7 +31,10 @@ constexpr int KC = 8;           // reduction chunk staged in LDS
 // PIPE: software-pipelined K loop over two LDS buffers (8-mode variant on layers with few mode chunks, see the launcher)
 // BH: operand B (the weights of ops 0 / 1) is stored as half-precision (re, im) pairs - config C5's weight storage - and widened
 // as it is loaded; everything after the load is the complex64 kernel.
-template <int QC, bool PIPE, bool BH>
+// ACC: out += (weight gradients added into a parameter's gradient buffer).  A template parameter, so that the plain kernels are
+// the same code as before the accumulating form existed (a run-time flag in the store loops cost the plain weight gradient of
+// the C2 / C4 blocks 20-40 %: 30 -> 37 us, and with both loops in one kernel the pointer arrays went to scratch)
+template <int QC, bool PIPE, bool BH, bool ACC = false>
 __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     constexpr int TILE_ELEMS = 16 * KC * QC;        // complex elements of one operand chunk
     constexpr int EPT = TILE_ELEMS / 256;           // elements per thread per operand: 8 / 4
@@ -181,24 +184,34 @@ __global__ __launch_bounds__(256) void mode_gemm_kernel(ModeGemmParams p) {
     }
     __syncthreads();
     float2* Ob = p.out[corner] + q0;
-    // QC iterations per thread (16 x 16 x QC / 256), in groups of four: the old values of a group (accumulating form) are requested
-    // before its first store
-    for (int e0 = tid; e0 < 16 * 16 * QC; e0 += 4 * 256) {
-        float2* dst[4];
-        float2 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + 256 * u;
+    if constexpr (!ACC) {
+        for (int e = tid; e < 16 * 16 * QC; e += 256) {
             const int q = e & (QC - 1), mn = e / QC;
             const int m = mn >> 4, n = mn & 15;
-            const bool ok = e < 16 * 16 * QC && q < nmodes && m0 + m < p.M && n0 + n < p.N;
-            dst[u] = ok ? Ob + (long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q : nullptr;
-            v[u] = ok ? sO[mn * (QC + 1) + q] : make_float2(0.f, 0.f);
-            if (p.accumulate && ok) { const float2 o = *dst[u]; v[u].x += o.x; v[u].y += o.y; }
+            if (q < nmodes && m0 + m < p.M && n0 + n < p.N)
+                Ob[(long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q] = sO[mn * (QC + 1) + q];
         }
+    } else {
+        // QC iterations per thread (16 x 16 x QC / 256) in groups of four: the old values of a group are requested before its
+        // first store (element by element every store waits for its own read: the compiler may not move a load above an earlier
+        // store to the same array)
+        for (int e0 = tid; e0 < 16 * 16 * QC; e0 += 4 * 256) {
+            float2* dst[4];
+            float2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (dst[u]) *dst[u] = v[u];
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                const int q = e & (QC - 1), mn = e / QC;
+                const int m = mn >> 4, n = mn & 15;
+                const bool ok = e < 16 * 16 * QC && q < nmodes && m0 + m < p.M && n0 + n < p.N;
+                dst[u] = ok ? Ob + (long long)(m0 + m) * p.o_sm + (long long)(n0 + n) * p.o_sn + q : nullptr;
+                v[u] = ok ? sO[mn * (QC + 1) + q] : make_float2(0.f, 0.f);
+                if (ok) { const float2 o = *dst[u]; v[u].x += o.x; v[u].y += o.y; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u]) *dst[u] = v[u];
+        }
     }
 }
 
@@ -223,7 +236,7 @@ __device__ __forceinline__ float lane_pull(int src_lane_x4, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_x4, __float_as_int(v)));
 }
 
-template <int MTW, int NTW, int K2B_PF, bool BH>
+template <int MTW, int NTW, int K2B_PF, bool BH, bool ACC = false>
 __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p, int KS, int ngw, int per_group) {
     extern __shared__ __attribute__((aligned(16))) float smb[];
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -331,48 +344,36 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
     float2* Ob = p.out[corner];
     const bool qv = q0 + mq < p.Mc;
     // accumulator register i of MFMA lane 4 q + j is out[m = 4 mt + i][n = 4 nt + j][q0 + q]; lane 16 j + q stores it
-    // accumulating form (weight gradients added into a parameter's gradient buffer): the old values of a whole group of stores are
-    // requested BEFORE the group's first store - read-modify-write element by element put one memory round trip in front of every
-    // store (the compiler may not move a load above an earlier store to the same array): 40 -> 60 us per call at the NS-2D layers
-    auto dst_of = [&](int mt, int nt, int i) {
-        const int n = n0 + 4 * nt + mx, m = m0 + 4 * mt + i;
-        return (qv && n < p.N && m < p.M) ? Ob + (long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq : nullptr;
-    };
     auto store_tile = [&](int mt, int nt, const f32x4& vr, const f32x4& vi) {
-        float2* dst[4];
-        float2 old[4];
+        const int n = n0 + 4 * nt + mx;
+        if constexpr (!ACC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dst[i] = dst_of(mt, nt, i);
-            old[i] = (p.accumulate && dst[i]) ? *dst[i] : make_float2(0.f, 0.f);
-        }
+            for (int i = 0; i < 4; ++i) {
+                const float2 v = make_float2(lane_pull(to_mem, vr[i]), lane_pull(to_mem, vi[i]));
+                const int m = m0 + 4 * mt + i;
+                if (qv && n < p.N && m < p.M) Ob[(long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq] = v;
+            }
+        } else {
+            // the tile's four old values first, then its four stores
+            float2* dst[4];
+            float2 old[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 v = make_float2(lane_pull(to_mem, vr[i]) + old[i].x, lane_pull(to_mem, vi[i]) + old[i].y);
-            if (dst[i]) *dst[i] = v;
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 4 * mt + i;
+                dst[i] = (qv && n < p.N && m < p.M) ? Ob + (long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq : nullptr;
+                old[i] = dst[i] ? *dst[i] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (dst[i]) *dst[i] = make_float2(lane_pull(to_mem, vr[i]) + old[i].x, lane_pull(to_mem, vi[i]) + old[i].y);
         }
     };
     if (KS == 1) {
         if (!active) return;
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            float2* dst[NTW][4];
-            float2 old[NTW][4];
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dst[nt][i] = dst_of(mt, nt, i);
-                    old[nt][i] = (p.accumulate && dst[nt][i]) ? *dst[nt][i] : make_float2(0.f, 0.f);
-                }
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float2 v = make_float2(lane_pull(to_mem, Dr[mt][nt][i]) + old[nt][i].x, lane_pull(to_mem, Di[mt][nt][i]) + old[nt][i].y);
-                    if (dst[nt][i]) *dst[nt][i] = v;
-                }
-        }
+            for (int nt = 0; nt < NTW; ++nt) store_tile(mt, nt, Dr[mt][nt], Di[mt][nt]);
         return;
     }
     // K split over KS waves: every wave leaves its partial tiles in LDS as [wave][tile][re | im][reg][lane]; wave r of a split group
@@ -414,6 +415,7 @@ static void launch_blocks_t(const ModeGemmParams& p, int KS, hipStream_t s) {
     dim3 grid(((p.ncorner * nq + 7) / 8) * 8 * per_group);
     const size_t lds = KS > 1 ? (size_t)4 * MTW * NTW * 8 * 64 * sizeof(float) : 0;
     if (p.B.half) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
+    else if (p.accumulate) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
     else hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
 }
 
@@ -462,7 +464,8 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
             const long long tasks = (long long)p.ncorner * groups * ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn);
             const int KS = square ? 1 : (tasks < 1024 && p.K >= 32) ? 4 : (tasks < 2048 && p.K >= 16) ? 2 : 1;
             char name[64];
-            snprintf(name, sizeof(name), "uno::mode_gemm_blocks_kernel<%s, %s>", square ? "4, 4, 2" : wide_m ? "4, 2, 4" : "2, 4, 4", p.B.half ? "true" : "false");
+            snprintf(name, sizeof(name), "uno::mode_gemm_blocks_kernel<%s, %s, %s>", square ? "4, 4, 2" : wide_m ? "4, 2, 4" : "2, 4, 4", p.B.half ? "true" : "false",
+                     (p.accumulate && !p.B.half) ? "true" : "false");
             ProfScope prof(name, k2_bytes, s);
             if (square) launch_blocks_t<4, 4, 2>(p, KS, s);
             else if (wide_m) launch_blocks_t<4, 2, 4>(p, KS, s);
@@ -475,14 +478,19 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
         // worse with many (2 x 196 / 2 x 324 modes: 41 -> 50, 58 -> 67 us)
         const bool pipe = narrow && p.ncorner * nq <= 32;
         char name[64];
-        snprintf(name, sizeof(name), "uno::mode_gemm_kernel<%d, %s, %s>", qc, pipe ? "true" : "false", p.B.half ? "true" : "false");
+        snprintf(name, sizeof(name), "uno::mode_gemm_kernel<%d, %s, %s, %s>", qc, pipe ? "true" : "false", p.B.half ? "true" : "false",
+                 (p.accumulate && !p.B.half) ? "true" : "false");
         ProfScope prof(name, k2_bytes, s);
         if (p.B.half) {
             if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, true>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
             else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false, true>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
             else hipLaunchKernelGGL((mode_gemm_kernel<16, false, true>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
         } else {
-            if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, false>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
+            if (p.accumulate) {
+                if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, false, true>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
+                else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false, false, true>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
+                else hipLaunchKernelGGL((mode_gemm_kernel<16, false, false, true>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
+            } else if (pipe) hipLaunchKernelGGL((mode_gemm_kernel<8, true, false>), grid, dim3(256), mode_gemm_lds(8, true), s, p);
             else if (narrow) hipLaunchKernelGGL((mode_gemm_kernel<8, false, false>), grid, dim3(256), mode_gemm_lds(8, false), s, p);
             else hipLaunchKernelGGL((mode_gemm_kernel<16, false, false>), grid, dim3(256), mode_gemm_lds(16, false), s, p);
         }
