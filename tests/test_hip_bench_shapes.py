@@ -170,6 +170,31 @@ def test_c3_ns2d_layers_full_width(cfg):
     _check2d(32, Ci, Co, H, H, Ho, Ho, m, m, seed=Ci + Co + H)
 
 
+@pytest.mark.parametrize("cfg", C3_LAYERS, ids=lambda c: "x".join(map(str, c)))
+def test_c3_ns2d_accumulating_weight_gradient(cfg):
+    """The roll-out sums 40 weight gradients per layer in place (uno_mode_wgrad_acc, beta = 1: separate kernel instantiations):
+    gw += sum_b conj(X[b, i]) gO[b, o] per mode at the full-width layer shapes, against float64 on the host."""
+    from uno_amd import _native
+    Ci, Co, H, Ho, m = cfg
+    B = 32
+    g = torch.Generator().manual_seed(Ci * 3 + Co + m)
+    xt = torch.randn(B, Ci, 2 * m, m, dtype=torch.cfloat, generator=g)
+    gO = torch.randn(B, Co, 2 * m, m, dtype=torch.cfloat, generator=g)
+    base = [torch.randn(Ci, Co, m, m, dtype=torch.cfloat, generator=g) for _ in range(2)]
+    ref = [base[c].to(torch.complex128) + torch.einsum("bixy,boxy->ioxy", xt[:, :, c * m:(c + 1) * m].conj().to(torch.complex128),
+                                                         gO[:, :, c * m:(c + 1) * m].to(torch.complex128)) for c in range(2)]
+    out = [b.clone().to(dev()) for b in base]
+
+    def run():
+        return _native.mode_wgrad(xt.to(dev()), gO.to(dev()), (Ci, Co, m, m), 2, out=out, accumulate=True)
+    _, ran = _run_profiled(run)
+    for c in range(2):
+        assert rel_err(torch.view_as_real(out[c]).cpu().numpy(), torch.view_as_real(ref[c]).numpy()) < TOL, c
+    names = {n for n in ran if _spectral(n)}
+    assert names and all(n.rstrip(">").endswith("true") for n in names), names      # the accumulating instantiations
+    COVERED.update(names)
+
+
 # ------------------------------------------------------------------ C4: NS-3D (SURVEY 8(d): block + Uno3D_T20 layers), batch 8
 def test_c4_block_full_size_volume_kernels():
     """SpectralConv3d(32,32,64,64,20,16,16,8), batch 8 = 256 volumes: the one-workgroup-per-volume kernels bench.py's 3-D block

@@ -354,7 +354,11 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
                 if (qv && n < p.N && m < p.M) Ob[(long long)m * p.o_sm + (long long)n * p.o_sn + q0 + mq] = v;
             }
         } else {
-            // the tile's four old values first, then its four stores
+            // the tile's four old values first, then its four stores.  The lane exchange (ds_bpermute) runs with ALL lanes enabled,
+            // outside the guards: a lane switched off by a guard supplies nothing to the lane that pulls from it
+            float2 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = make_float2(lane_pull(to_mem, vr[i]), lane_pull(to_mem, vi[i]));
             float2* dst[4];
             float2 old[4];
 #pragma unroll
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (dst[i]) *dst[i] = make_float2(lane_pull(to_mem, vr[i]) + old[i].x, lane_pull(to_mem, vi[i]) + old[i].y);
+                if (dst[i]) *dst[i] = make_float2(v[i].x + old[i].x, v[i].y + old[i].y);
         }
     };
     if (KS == 1) {
