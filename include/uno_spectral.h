@@ -172,7 +172,9 @@ int uno_resample2d(const float* in, float* out, float* tmp, int n_img, int H, in
  * Fused activation forms for a layer whose input tensor is kept PRE-activation (the model's `fc(F.gelu(t))` patterns,
  * reference darcy_flow_uno2d.py:98-101, 128-131): act_in != 0 applies the exact-erf GELU to x as it is read (y = Wm gelu(x)
  * + bias); dgelu_of != NULL (B, Co, P) multiplies the product by gelu'(dgelu_of) - the input-gradient call then returns the
- * gradient of the pre-activation tensor.  The two are mutually exclusive. */
+ * gradient of the pre-activation tensor.  The two are mutually exclusive.  accumulate = 2 (with dgelu_of): y = (y + product) *
+ * gelu'(dgelu_of) - the call that adds the LAST contribution to the gradient of a block's activation also applies the block's
+ * GELU derivative to the completed sum (reference integral_operators.py:282-283 backward), no separate pass. */
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co,
                     long long P, int transpose_w, int accumulate, int act_in, const float* dgelu_of, void* stream);
 

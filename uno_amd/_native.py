@@ -412,10 +412,10 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
     return out
 
 
-def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bool = False, dgelu_of=None):
+def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bool = False, dgelu_of=None, dgelu_total: bool = False):
     """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias;
     out: accumulate into this (B, Co, P) tensor instead; act_in: x := gelu(x) as it is read; dgelu_of (B, Co, P): the
-    product is multiplied by gelu'(dgelu_of)."""
+    product is multiplied by gelu'(dgelu_of) - with dgelu_total (and out) the completed sum out + product is."""
     bf16 = _act_dtype(x, "x")
     _require(w, torch.float32, "weight")
     if bias is not None:
@@ -439,7 +439,8 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
                 raise RuntimeError(f"uno_amd: dgelu_of has shape {tuple(dgelu_of.shape)}, expected {(B, Co, P)}")
         fn = lib().uno_channel_mix_bf16 if bf16 else lib().uno_channel_mix
         rc = fn(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y),
-                                   B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, 1 if act_in else 0,
+                                   B, Ci, Co, P, 1 if transpose_w else 0,
+                                   (2 if (dgelu_total and dgelu_of is not None) else 1) if accumulate else 0, 1 if act_in else 0,
                                    _ptr(dgelu_of) if dgelu_of is not None else C.c_void_p(0), _stream(x))
     _check(rc, "uno_channel_mix")
     return y

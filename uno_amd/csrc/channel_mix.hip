@@ -61,7 +61,8 @@ struct ChannelMixParams {
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
-    int accumulate;         // y += instead of y =
+    int accumulate;         // 1: y += instead of y =;  2 (with dgelu_of): y = (y + product) * gelu'(dgelu_of) - the LAST contribution to a
+                            // gradient that must still pass through a GELU: the factor multiplies the completed sum
     const void* dgelu_of;   // nullptr, or (B, Co1, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
                             // (first destination only)
 };
@@ -254,11 +255,11 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 float w4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    w4[i] = o4[i] + r4[i];
                     if constexpr (DG) {
                         const float pr4[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
-                        if (dg) r4[i] *= cm_dgelu(pr4[i]);
+                        if (dg) { const float d = cm_dgelu(pr4[i]); w4[i] = p.accumulate == 2 ? w4[i] * d : fmaf(r4[i], d, o4[i]); }
                     }
-                    w4[i] = o4[i] + r4[i];
                 }
                 io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
                 if (aall) io_store4(aall + aoff[it], cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
@@ -311,7 +312,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 float w4[4] = {o4.x, o4.y, o4.z, o4.w};
                 const float pr4[4] = {pre.x, pre.y, pre.z, pre.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w4[r] += (acc[mt][r] + bv) * (dg ? cm_dgelu(pr4[r]) : 1.f);
+                for (int r = 0; r < 4; ++r) {
+                    const float d = dg ? cm_dgelu(pr4[r]) : 1.f;
+                    w4[r] = p.accumulate == 2 ? (w4[r] + (acc[mt][r] + bv)) * d : w4[r] + (acc[mt][r] + bv) * d;
+                }
                 io_store4(yrow + px, w4[0], w4[1], w4[2], w4[3]);
                 if (arow) io_store4(arow + px, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
                 if (p.proj_w) {
@@ -322,8 +326,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (px + r < p.P) {
-                        const float v = (p.accumulate ? io_widen(yrow[px + r]) : 0.f) +
-                                        (acc[mt][r] + bv) * (dg ? cm_dgelu(io_widen(drow[px + r])) : 1.f);
+                        const float d = dg ? cm_dgelu(io_widen(drow[px + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[px + r]) : 0.f;
+                        const float v = p.accumulate == 2 ? (o1 + (acc[mt][r] + bv)) * d : o1 + (acc[mt][r] + bv) * d;
                         io_store1(yrow + px + r, v);
                         if (arow) io_store1(arow + px + r, cm_gelu(v));
                         if (p.proj_w) pv[mt][r] = pwv * cm_gelu(v);
@@ -558,7 +562,8 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const long long P = a.P;
     const bool two_src = a.x2 != nullptr, two_dst = a.y2 != nullptr;
     ChannelMixParams p;
-    p.accumulate = a.accumulate ? 1 : 0;
+    p.accumulate = a.accumulate == 2 ? 2 : (a.accumulate ? 1 : 0);
+    if (p.accumulate == 2 && !a.dgelu_of) { set_error("channel_mix: accumulate = 2 (gelu' on the completed sum) needs dgelu_of"); return -2; }
     p.dgelu_of = a.dgelu_of;
     p.x = a.x; p.x2 = a.x2; p.w = a.w; p.bias = a.bias; p.y = a.y; p.y2 = a.y2; p.y_act = a.y_act;
     p.proj_w = a.proj_w; p.proj_b = a.proj_b; p.proj_out = a.proj_out;

@@ -67,14 +67,16 @@ class UNO_9(nn.Module):
             # `lifted` and `c0` feed two layers each (skip connections).  Their gradients are JOINED: the later consumer leaves its
             # contribution (a truncated spectrum + accumulating closures) to the first consumer, which transforms the summed spectrum
             # once and returns the complete gradient - no second gradient tensor, no element-wise sum (GradJoin)
-            jl, jc = GradJoin(), GradJoin()
-            c0 = self.conv0(lifted, d1 // 2, d2 // 2, join=jl)
+            # conv0 / conv2 end in a GELU (no normalisation): the block that completes the gradient of their output (conv1 with the
+            # join of c0; conv4, c2's only consumer) applies gelu'(pre) in its last accumulating kernel (`out_join`)
+            jl, jc, j2 = GradJoin(), GradJoin(), GradJoin()
+            c0 = self.conv0(lifted, d1 // 2, d2 // 2, join=jl, out_join=jc)
             c1 = self.conv1(c0, d1 // 4, d2 // 4, join=jc)
-            c2 = self.conv2(c1, d1 // 4, d2 // 4)
+            c2 = self.conv2(c1, d1 // 4, d2 // 4, out_join=j2)
             # skip connections: conv5 consumes cat([conv4 output, c0]) and fc1 cat([conv5 output, lifted]) from their two
             # sources; the concatenations are never built.  conv5's GELU is deferred to its only consumer: fc1 applies it while
             # reading the pre-activation tensor
-            skip5 = [self.conv4(c2, d1 // 2, d2 // 2), c0]
+            skip5 = [self.conv4(c2, d1 // 2, d2 // 2, join=j2), c0]
             # fc2(gelu(fc1(cat([gelu(conv5 pre), lifted])))): one forward kernel (the fc1 pass also reduces its 64 channels to the output)
             out = channel_mix_cat_project([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True, defer_grad=jc), lifted], self.fc1.weight,
                                           self.fc1.bias, self.fc2.weight, self.fc2.bias, gelu_first=True, defer_grad=jl)

@@ -266,7 +266,12 @@ class GradJoin:
     def __init__(self):
         self.owner = False          # set by the first consumer's forward when it will produce the joined gradient
         self.spectra = []           # (gX (B, C, 2 m1, m2) c64, grid (H, W)) left by deferring consumers
-        self.pending = []           # callables(out: (B, C, H, W) tensor) accumulating into out
+        self.pending = []           # (callable(out, dgelu_of=None), fusable): accumulate into out (B, C, H, W); a fusable one can also
+                                    # multiply the completed sum by gelu'(dgelu_of) in its epilogue
+        # the joined tensor is the ACTIVATION of a block without normalisation (`out_join=` of the block that produces it): its
+        # pre-activation sum, and whether the gradient handed back to that block has already been multiplied by gelu'(pre)
+        self.pre = None
+        self.dgelu_applied = False
 
     def reset(self):
         self.owner = False
@@ -293,10 +298,19 @@ class GradJoin:
         self.spectra = []
         return base
 
-    def apply(self, out):
-        for fn in self.pending:
-            fn(out)
+    def apply(self, out, final_dgelu=None):
+        """run the deferred accumulations; with final_dgelu (the producer block's pre-activation sum) the LAST one - if it is a
+        channel-mix call - also multiplies the completed gradient by gelu'(final_dgelu).  -> True when that happened"""
+        fused = False
+        n = len(self.pending)
+        for k, (fn, fusable) in enumerate(self.pending):
+            if final_dgelu is not None and fusable and k == n - 1:
+                fn(out, final_dgelu)
+                fused = True
+            else:
+                fn(out)
         self.pending = []
+        return fused
 
 
 # ---- a layer on the channel concatenation of two tensors, never built: one pass over every operand where the kernels' split
@@ -376,7 +390,9 @@ class _ChannelMixCatFn(torch.autograd.Function):
                 g1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
             w2 = w[:, C1:].contiguous()
             B, C2 = x2.shape[0], x2.shape[1]
-            ctx.defer.pending.append(lambda out: _native.channel_mix(gy, w2, None, transpose_w=True, out=out.view(B, C2, -1)))
+            ctx.defer.pending.append((lambda out, dg=None: _native.channel_mix(
+                gy, w2, None, transpose_w=True, out=out.view(B, C2, -1), dgelu_of=None if dg is None else dg.view(B, C2, -1),
+                dgelu_total=dg is not None), True))
         elif ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             g1, g2 = _mix2_input_grads(gy, w, C1, dgelu_of=x1 if ctx.gelu_first else None)
         elif ctx.needs_input_grad[0]:
@@ -580,10 +596,13 @@ class _OperatorBlock2dFn(torch.autograd.Function):
     separate element-wise pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo, half_weights=False, fuse_gelu=False, join=None):
+    def forward(ctx, x, w1, w2, cw, cb, Ho, Wo, half_weights=False, fuse_gelu=False, join=None, out_join=None):
         """fuse_gelu (blocks with Non_Lin and no normalisation, reference integral_operators.py:282-283): returns gelu(s); where the
         channel mix is the kernel that completes s (no up-sampling) it writes the activation in the same pass.
-        join: GradJoin of x - this block is x's FIRST consumer and returns x's complete gradient (see GradJoin)."""
+        join: GradJoin of x - this block is x's FIRST consumer and returns x's complete gradient (see GradJoin).
+        out_join (with fuse_gelu): the GradJoin of this block's OUTPUT; the block leaves its pre-activation sum there, and the
+        consumer that completes the output's gradient multiplies it by gelu'(pre) in its last accumulating kernel - this block's
+        backward then receives the gradient at the pre-activation sum and runs no GELU-backward pass."""
         from .resample import resample_forward
         ctx.leaves = (w1, w2, cw, cb)
         ctx.join = None
@@ -618,6 +637,10 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                 out = F.gelu(s)
         ctx.save_for_backward(xt, w1, w2, cwm, act, s if fuse_gelu else None)
         ctx.geom = (H, W, same, mix_last, cb is not None, tuple(cw.shape))
+        ctx.out_join = None
+        if fuse_gelu and out_join is not None:
+            out_join.pre, out_join.dgelu_applied = s, False
+            ctx.out_join = out_join
         return out
 
     @staticmethod
@@ -628,7 +651,13 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         H, W, same, mix_last, has_bias, cw_shape = ctx.geom
         gs = _plain(gs)
         if pre is not None:                 # the block's GELU: gradient at the pre-activation sum
-            gs = torch.ops.aten.gelu_backward(gs, pre)
+            oj = ctx.out_join
+            if oj is not None and oj.dgelu_applied and oj.pre is not None and oj.pre.data_ptr() == pre.data_ptr():
+                oj.dgelu_applied = False    # the consumer's last kernel already multiplied by gelu'(pre)
+            else:
+                gs = torch.ops.aten.gelu_backward(gs, pre)
+            if oj is not None:
+                oj.pre = None
         B, Co, Ho, Wo = gs.shape
         Ci = cwm.shape[1]
         need_gx = ctx.needs_input_grad[0]
@@ -655,11 +684,20 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         if tg and need_gw:
             gw1, gw2 = tg[0][2], tg[1][2]
         gcw = gcb = None
+        # x is the activation of a fused-GELU block (join.pre): the gradient this block returns must be multiplied by gelu'(pre).
+        # The LAST kernel that accumulates into gx does it - a deferred closure if any is pending, else this block's own
+        # transposed channel mix where that comes last; otherwise a separate pass at the end
+        xpre = join.pre if (join is not None and need_gx) else None
+        own_last = xpre is not None and not join.pending
+        dg_view = xpre.view(B, Ci, -1) if own_last else None
+        dg_done = False
         if mix_last:
             # forward: act = R x;  s += Wm act + b
             if need_gx:
                 if same:
-                    _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True, out=gx.view(B, Ci, -1))
+                    _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True, out=gx.view(B, Ci, -1), dgelu_of=dg_view,
+                                        dgelu_total=own_last)
+                    dg_done = own_last
                 else:
                     g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True)
                     resample_adjoint(g_act.view(B, Ci, Ho, Wo), H, W, out=gx)
@@ -670,7 +708,8 @@ class _OperatorBlock2dFn(torch.autograd.Function):
             # forward: t = Wm x + b;  s += R t
             g_t = resample_adjoint(gs, H, W).view(B, Co, -1)
             if need_gx:
-                _native.channel_mix(g_t, cwm, None, transpose_w=True, out=gx.view(B, Ci, -1))
+                _native.channel_mix(g_t, cwm, None, transpose_w=True, out=gx.view(B, Ci, -1), dgelu_of=dg_view, dgelu_total=own_last)
+                dg_done = own_last
             if need_gc:
                 gcw, gcb = _wgrad_into((lcw, lcb), g_t, act.view(B, Ci, -1), None, ctx.needs_input_grad[3],
                                        has_bias and ctx.needs_input_grad[4])
@@ -678,9 +717,14 @@ class _OperatorBlock2dFn(torch.autograd.Function):
             gcw = gcw.view(cw_shape)
         if join is not None:
             if need_gx:
-                join.apply(gx)              # the point-wise contributions of x's other consumer accumulate into this buffer
+                # the point-wise contributions of x's other consumer accumulate into this buffer (the last one applies gelu'(pre))
+                dg_done = join.apply(gx, xpre if not dg_done else None) or dg_done
+                if xpre is not None:
+                    if not dg_done:
+                        gx = torch.ops.aten.gelu_backward(gx, xpre)
+                    join.dgelu_applied = True
             join.reset()
-        return gx, gw1, gw2, gcw, gcb, None, None, None, None, None
+        return gx, gw1, gw2, gcw, gcb, None, None, None, None, None, None
 
 
 class _OperatorBlock2dCatFn(torch.autograd.Function):
@@ -762,16 +806,19 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         if defer is not None:
             # point-wise part of x2's gradient: accumulated into the joined buffer later; x1's part now
             cw2 = cwm[:, C1:].contiguous()
+            def mix_into(out, dg=None):
+                _native.channel_mix(g_src, cw2, None, transpose_w=True, out=out.view(B, C2, -1),
+                                    dgelu_of=None if dg is None else dg.view(B, C2, -1), dgelu_total=dg is not None)
             if mix_last:
                 g_src = gs.view(B, Co, -1)
                 if same:
-                    defer.pending.append(lambda out: _native.channel_mix(g_src, cw2, None, transpose_w=True, out=out.view(B, C2, -1)))
+                    defer.pending.append((mix_into, True))
                 else:
-                    defer.pending.append(lambda out: resample_adjoint(
-                        _native.channel_mix(g_src, cw2, None, transpose_w=True).view(B, C2, Ho, Wo), H, W, out=out))
+                    defer.pending.append((lambda out: resample_adjoint(
+                        _native.channel_mix(g_src, cw2, None, transpose_w=True).view(B, C2, Ho, Wo), H, W, out=out), False))
             else:
                 g_src = resample_adjoint(gs, H, W).view(B, Co, -1)
-                defer.pending.append(lambda out: _native.channel_mix(g_src, cw2, None, transpose_w=True, out=out.view(B, C2, -1)))
+                defer.pending.append((mix_into, True))
             if gx1 is not None:
                 cw1 = cwm[:, :C1].contiguous()
                 if mix_last and not same:
@@ -947,10 +994,11 @@ class OperatorBlock_2D(nn.Module):
         if Normalize:
             self.normalize_layer = nn.InstanceNorm2d(int(out_codim), affine=True)
 
-    def forward(self, x, dim1=None, dim2=None, join=None):
-        """join (optional, beyond the reference signature): a GradJoin of x when x has a second consumer further down the network."""
+    def forward(self, x, dim1=None, dim2=None, join=None, out_join=None):
+        """join / out_join (optional, beyond the reference signature): GradJoin objects of the input / of this block's output - see
+        GradJoin and _OperatorBlock2dFn."""
         if self.non_lin and not self.normalize:
-            return self._branches(x, dim1, dim2, gelu=True, join=join)
+            return self._branches(x, dim1, dim2, gelu=True, join=join, out_join=out_join)
         out = self._branches(x, dim1, dim2, join=join)
         if self.normalize:
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
@@ -984,7 +1032,7 @@ class OperatorBlock_2D(nn.Module):
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
         return F.gelu(out) if self.non_lin else out
 
-    def _branches(self, x, dim1, dim2, gelu=False, join=None):
+    def _branches(self, x, dim1, dim2, gelu=False, join=None, out_join=None):
         """conv(x) + w(x) [then GELU when `gelu`: written by the kernel that completes the sum where the fused path runs]"""
         conv, w = self.conv, self.w
         if dim1 is not None:        # the spectral layer keeps a call-time override, the point-wise one does not (:182-184, :236-238)
@@ -998,7 +1046,7 @@ class OperatorBlock_2D(nn.Module):
             out = conv(x) + w(x, d1, d2)
             return F.gelu(out) if gelu else out
         return _OperatorBlock2dFn.apply(x, conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2),
-                                        x.dtype == torch.bfloat16, bool(gelu), join)
+                                        x.dtype == torch.bfloat16, bool(gelu), join, out_join)
 
     def _takes(self, x):
         """4-D device tensor the fused block kernels take: float32, or bfloat16 once the spectral layer is in mixed-precision mode."""
