@@ -11,7 +11,10 @@ SIZES = [((20, 18), (12, 10)), ((12, 10), (21, 19)), ((90, 90), (45, 45)), ((45,
          ((9, 300), (4, 301)), ((446, 446), (223, 223)), ((7, 3), (5, 2)), ((5, 2), (9, 3)), ((33, 5), (20, 7)),
          # rows whose 16 x W tile alone fits 64 KB of LDS but tile + row-operator table does not (W ~ 980..1024: an unpadded
          # 1024^2 level resampled 1024 -> 512): must take the two-pass form, not fail at launch
-         ((40, 1024), (20, 512)), ((36, 1000), (18, 500)), ((20, 512), (40, 1024)), ((24, 960), (12, 480))]
+         ((40, 1024), (20, 512)), ((36, 1000), (18, 500)), ((20, 512), (40, 1024)), ((24, 960), (12, 480)),
+         # round 3: rows up to ~2400 floats run the fused kernel with a raised dynamic-LDS limit (the 1089 -> 544 level of config C5);
+         # beyond that the two-pass form
+         ((33, 1089), (16, 544)), ((16, 544), (33, 1089)), ((6, 2500), (3, 1300)), ((3, 1300), (6, 2500))]
 
 
 def test_band_tables_reconstruct_the_operator():
@@ -63,7 +66,7 @@ def test_pointwise_op_commuted_order_matches_reference_order():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sizes", [((40, 36), (20, 18)), ((20, 18), (41, 37)), ((30, 1100), (15, 600))])
+@pytest.mark.parametrize("sizes", [((40, 36), (20, 18)), ((20, 18), (41, 37)), ((30, 1100), (15, 600)), ((5, 2600), (3, 1300))])
 def test_resample_accumulates_into_out(sizes):
     """out= form (fused kernel and the two-pass fallback for rows too long for LDS): out += R x R^T."""
     from uno_amd.resample import resample_forward, resample_adjoint

@@ -249,6 +249,18 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
     }
 }
 
+// one instantiation of the fused kernel: raises its dynamic-LDS limit when a long row needs more than the 64 KB a launch gets by
+// default (rows of 1000 .. 2400 floats: the 1024^2 / 1089^2 levels of config C5), then launches
+template <bool A, int K, typename T, bool MF>
+static bool launch_fused_one(dim3 grid, int nthreads, size_t lds, hipStream_t s, const T* in, T* out, const int* tile_p0, const float* tile_w,
+                             int NP, const int* startW, const float* wtW, int KW, int H, int W, int Ho, int Wo, int n_img, int ntiles) {
+    auto k = resample_fused_kernel<A, K, T, MF>;
+    static int lds_slot[64];
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_slot)) return false;
+    hipLaunchKernelGGL(k, grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);
+    return true;
+}
+
 int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
                       const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s) {
@@ -264,7 +276,9 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
     // REAL request (W ~ 980..1024 passes a tile-only test and then asks for more than the 64 KB a launch gets without the
     // dynamic-LDS attribute: the launch fails instead of falling through to the two-pass form)
     const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float);
-    if (!wide_band && tile_p0 && tile_w && NP >= 1 && NP <= 96 && lds <= 64 * 1024) {
+    // (round 3: up to 150 KB - one workgroup per CU - through the dynamic-LDS attribute; the two-pass form took 2.0 ms per call at
+    // the 1089 -> 544 level of the C5 model where this kernel needs 0.5)
+    if (!wide_band && tile_p0 && tile_w && NP >= 1 && NP <= 96 && lds <= 150 * 1024) {
         // fused single-pass kernel: needs the dense row-tile tables and the 16 x W tile to fit in LDS
         ProfScope prof("uno::resample_fused_kernel", es * n_img * ((double)H * W + (accumulate ? 2.0 : 1.0) * Ho * Wo), s);
         // one column per thread in phase 1: the narrowest multiple of 64 threads that covers W in whole sweeps
@@ -273,16 +287,13 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
         const int ntiles = (Ho + RS_TR - 1) / RS_TR;
         const dim3 grid((unsigned)(((n_img + 7) / 8) * 8) * ntiles);
         const bool mf = W >= 4;             // row operator on MFMA (rows of at least one 16-byte piece)
+        bool lds_ok = true;
 #define UNO_RS_LAUNCH(A, K)                                                                                                    \
         do {                                                                                                                   \
-            if (bf16 && mf) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t, true>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \
-                                         startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                        \
-            else if (bf16) hipLaunchKernelGGL((resample_fused_kernel<A, K, bf_t, false>), grid, dim3(nthreads), lds, s, inb, outb, tile_p0, tile_w, NP, \
-                                         startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                        \
-            else if (mf) hipLaunchKernelGGL((resample_fused_kernel<A, K, float, true>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
-                                    startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                             \
-            else hipLaunchKernelGGL((resample_fused_kernel<A, K, float, false>), grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, \
-                                    startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);                                             \
+            if (bf16 && mf) lds_ok = launch_fused_one<A, K, bf_t, true>(grid, nthreads, lds, s, inb, outb, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
+            else if (bf16) lds_ok = launch_fused_one<A, K, bf_t, false>(grid, nthreads, lds, s, inb, outb, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
+            else if (mf) lds_ok = launch_fused_one<A, K, float, true>(grid, nthreads, lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
+            else lds_ok = launch_fused_one<A, K, float, false>(grid, nthreads, lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
         } while (0)
         // tap counts seen in the U-NO models: 4-5 (up-sampling by ~2 and its adjoint's rows), 9-10 (down-sampling by ~2)
 #define UNO_RS_PICK(A)                                                                                                         \
@@ -294,6 +305,7 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
         if (accumulate) UNO_RS_PICK(true); else UNO_RS_PICK(false);
 #undef UNO_RS_PICK
 #undef UNO_RS_LAUNCH
+        if (!lds_ok) { set_error("resample2d: cannot raise dynamic LDS to %zu", lds); return -4; }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("resample2d launch: %s", hipGetErrorString(e)); return -5; }
         return 0;

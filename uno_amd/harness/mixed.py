@@ -34,6 +34,7 @@ class MixedDarcyTrainer(DarcyTrainer):
 def c5_mixed_model_bench(dev, B: int = 4, S: int = 1024, steps: int = 4, warmup: int = 2):
     """UNO_9(3, 64, pad=5) at S x S, batch B: ms / step of the mixed-precision step (bench.py extra key)."""
     torch.manual_seed(0)
+    torch.cuda.synchronize(dev)                      # (also initialises the device context when this is the first CUDA call)
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)          # the figure below is this run's peak, not an earlier workload's
     model = UNO_9(3, 64, pad=5).to(dev)
