@@ -94,6 +94,9 @@ def test_graphed_step_equals_eager_step():
     me, oe = make()
     mg, og = make()
     gs = GraphedStep(mg, og, lambda a, b: ns2d_rollout_loss(mg, a, b, T_f=3, step=1), batches[0])
+    # the eager model's first backward pass runs the spectral weight gradients use by use and only the later ones batch them over
+    # the roll-out (integral_operators.TIME_BATCHED_WGRAD) - the capture's warm-up passes have put the graphed model in that mode
+    ns2d_rollout_loss(me, *batches[0], T_f=3, step=1).backward()
     for xx, yy in batches:
         oe.zero_grad(set_to_none=True)
         le = ns2d_rollout_loss(me, xx, yy, T_f=3, step=1)

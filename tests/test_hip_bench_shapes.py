@@ -195,6 +195,31 @@ def test_c3_ns2d_accumulating_weight_gradient(cfg):
     COVERED.update(names)
 
 
+@pytest.mark.parametrize("cfg", C3_LAYERS, ids=lambda c: "x".join(map(str, c)))
+def test_c3_ns2d_weight_gradient_batched_over_the_rollout(cfg):
+    """From the second training step on the roll-out's 40 weight gradients of a layer are ONE per-mode GEMM with K = 40 x 32 over
+    the layer's stacked spectra (integral_operators.TIME_BATCHED_WGRAD): the kernels that call dispatches at the full-width layer
+    shapes, against float64 on the host."""
+    from uno_amd import _native
+    Ci, Co, H, Ho, m = cfg
+    T, B = 40, 32
+    g = torch.Generator().manual_seed(Ci * 5 + Co + m)
+    xt = torch.randn(T * B, Ci, 2 * m, m, dtype=torch.cfloat, generator=g)
+    gO = torch.randn(T * B, Co, 2 * m, m, dtype=torch.cfloat, generator=g)
+    xd, gd = xt.to(dev()), gO.to(dev())
+    ref = [torch.einsum("bixy,boxy->ioxy", xd[:, :, c * m:(c + 1) * m].conj().to(torch.complex128),
+                        gd[:, :, c * m:(c + 1) * m].to(torch.complex128)).cpu() for c in range(2)]     # f64 einsum on the device: 40x the host time otherwise
+    refh = torch.einsum("bixy,boxy->ioxy", xt[:64, :, :m].conj().to(torch.complex128), gO[:64, :, :m].to(torch.complex128))
+    chk = torch.einsum("bixy,boxy->ioxy", xd[:64, :, :m].conj().to(torch.complex128), gd[:64, :, :m].to(torch.complex128)).cpu()
+    assert rel_err(torch.view_as_real(chk).numpy(), torch.view_as_real(refh).numpy()) < 1e-12      # the device f64 reference agrees with the host's
+    out, ran = _run_profiled(lambda: _native.mode_wgrad(xd, gd, (Ci, Co, m, m), 2))
+    for c in range(2):
+        assert rel_err(torch.view_as_real(out[c]).cpu().numpy(), torch.view_as_real(ref[c]).numpy()) < TOL, c
+    names = {n for n in ran if _spectral(n)}
+    assert names, ran
+    COVERED.update(names)
+
+
 # ------------------------------------------------------------------ C4: NS-3D (SURVEY 8(d): block + Uno3D_T20 layers), batch 8
 def test_c4_block_full_size_volume_kernels():
     """SpectralConv3d(32,32,64,64,20,16,16,8), batch 8 = 256 volumes: the one-workgroup-per-volume kernels bench.py's 3-D block

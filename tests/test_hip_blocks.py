@@ -343,6 +343,95 @@ def test_weight_gradients_are_written_in_place():
 
 
 @pytest.mark.gpu
+def test_weight_gradient_batched_over_the_uses_of_a_layer():
+    """A roll-out uses every spectral layer T times in one graph (reference ns_train_2d.py:46-68).  From the second backward pass
+    on, the layer keeps its T truncated spectra in one stack and the last use to be back-propagated computes the weight gradient
+    in ONE per-mode GEMM with K = T x batch.  Same gradients as T separate weight gradients summed by autograd; a changing number
+    of uses, a second backward over a retained graph and a pass that reaches only some of the uses stay correct."""
+    import warnings
+    import uno_amd.integral_operators as io
+    from uno_amd.harness.train import FlatGradients
+    from uno_amd.integral_operators import OperatorBlock_2D, SpectralConv2d_Uno
+    torch.manual_seed(3)
+    blk = OperatorBlock_2D(8, 8, 24, 24, 5, 5).to(dev())
+    conv = SpectralConv2d_Uno(8, 8, 24, 24, 4, 4).to(dev())
+    params = list(blk.parameters()) + list(conv.parameters())
+    x = torch.randn(3, 8, 24, 24, device=dev())
+
+    def rollout(T, keep=None):
+        h, outs = x, []
+        for _ in range(T):
+            h = torch.tanh(conv(blk(h)))
+            outs.append(h)
+        sel = outs if keep is None else [outs[i] for i in keep]
+        return sum(o.square().sum() for o in sel)
+
+    def grads(T, batched, keep=None):
+        io.TIME_BATCHED_WGRAD = batched
+        try:
+            for p in params:
+                p.grad = None
+            rollout(T, keep).backward()
+            return [p.grad.clone() for p in params]
+        finally:
+            io.TIME_BATCHED_WGRAD = True
+
+    def same(a, b, tol=3e-6):
+        for u, v in zip(a, b):
+            ur, vr = (torch.view_as_real(t) if t.is_complex() else t for t in (u, v))
+            assert float((ur - vr).norm()) <= tol * float(vr.norm()) + 1e-12
+
+    w1 = blk.conv.weights1
+    for p in (w1, conv.weights1):
+        for a in ("_uno_uses", "_uno_stack", "_uno_nostack"):
+            if hasattr(p, a):
+                delattr(p, a)
+    ref5 = grads(5, False)
+    assert w1._uno_uses == 5                                    # counted by the unbatched pass
+    got = grads(5, True)
+    st = w1._uno_stack
+    assert st.n == 5 and st.done and tuple(st.X.shape[:2]) == (5, 3), "the layer did not stack its five uses"
+    same(got, ref5)
+    # through a flat gradient buffer: the single GEMM writes into the parameter's view
+    fg = FlatGradients(params)
+    fg.zero_()
+    rollout(5).backward()
+    for p, v in zip(fg.params, fg.views):
+        assert p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+    same([p.grad for p in params], ref5)
+    for p in params:
+        del p._uno_grad_buffer
+    # fewer and more uses than the stack was sized for (7 = one full stack of 5 and a second one with 2)
+    same(grads(3, True), grads(3, False))
+    assert w1._uno_uses == 3
+    ref7 = grads(7, False)
+    w1._uno_uses = conv.weights1._uno_uses = 5
+    same(grads(7, True), ref7)
+    # retained graph: the second backward finds its stacks finished and runs use by use
+    for p in params:
+        p.grad = None
+    loss = rollout(4)
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in params]
+    loss.backward()
+    same([p.grad for p in params], [2 * g for g in first])
+    # a pass that back-propagates only the first two of four uses: complete gradient, a warning, batching off for the layer
+    ref_part = grads(4, False, keep=[1])
+    w1._uno_uses = conv.weights1._uno_uses = 4
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        part = grads(4, True, keep=[1])
+    same(part, ref_part)
+    assert any("TIME_BATCHED_WGRAD" in str(w.message) for w in rec)
+    assert w1._uno_nostack and w1._uno_uses == 0
+    same(grads(4, True), grads(4, False))                       # and stays right afterwards
+    for p in (w1, conv.weights1):
+        for a in ("_uno_uses", "_uno_stack", "_uno_nostack"):
+            if hasattr(p, a):
+                delattr(p, a)
+
+
+@pytest.mark.gpu
 def test_inplace_weight_gradients_never_lose_a_contribution_silently():
     """A weight that receives gradients from the library's kernels (in place) AND from a stock torch op in the same backward pass:
     autograd may add the stock gradient out of place and so replace the tensor the kernels keep accumulating into.  The library

@@ -9,6 +9,9 @@ dev = torch.device("cuda:0")
 
 
 GRAPH = "--graph" in sys.argv       # forward + backward replayed from a HIP graph (harness.GraphedStep)
+if "--no-time-batch" in sys.argv:   # A/B: the spectral weight gradient of the roll-out use by use (40 accumulating GEMMs per layer)
+    import uno_amd.integral_operators as _io
+    _io.TIME_BATCHED_WGRAD = False
 
 
 def run(name, model, closure, samples, steps=5, warmup=2, inputs=()):
@@ -41,7 +44,7 @@ m = UNO(14, 32).to(dev)
 xx = torch.randn(32, 64, 64, 10, device=dev); yy = torch.randn(32, 64, 64, 40, device=dev)
 run("C3 NS-2D UNO(14,32) 64^2 B=32 T_f=40", m, lambda a, b: ns2d_rollout_loss(m, a, b, T_f=40, step=1), 32, inputs=(xx, yy))
 del m
-for w in (8, 32):
+for w in (() if "--c3" in sys.argv else (8, 32)):
     torch.manual_seed(0)
     m3 = Uno3D_T20(6, w, pad=3).to(dev)
     x = torch.randn(8, 64, 64, 10, 1, device=dev); y = torch.randn(8, 64, 64, 20, device=dev)

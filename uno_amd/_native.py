@@ -151,8 +151,9 @@ def _weights_half(w1, w2, bf16):
     return False
 
 
-def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
-    """-> (y (B,Co,Ho,Wo) in x's dtype (f32 | bf16), xtrunc (B,Ci,2*m1,m2) c64)."""
+def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int, xt_out=None):
+    """-> (y (B,Co,Ho,Wo) in x's dtype (f32 | bf16), xtrunc (B,Ci,2*m1,m2) c64).  xt_out: dense complex64 tensor of that shape to
+    write the truncated input spectrum into (a slot of a layer's time stack) instead of a fresh one."""
     bf16 = _act_dtype(x, "x")
     wh = _weights_half(w1, w2, bf16)
     B, Ci, H, W = x.shape
@@ -162,7 +163,13 @@ def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int):
     L = lib()
     with torch.cuda.device(x.device):
         y = torch.empty((B, Co, Ho, Wo), dtype=x.dtype, device=x.device)
-        xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x.device)
+        if xt_out is None:
+            xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x.device)
+        else:
+            xt = xt_out
+            _require(xt, torch.complex64, "xtrunc buffer")
+            if tuple(xt.shape) != (B, Ci, 2 * m1, m2):
+                raise RuntimeError("uno_amd: xtrunc buffer has the wrong shape")
         ws = torch.empty(max(1, L.uno_spectral_conv2d_fwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=x.device)
         fn = L.uno_spectral_conv2d_forward_mixed if wh else (L.uno_spectral_conv2d_forward_bf16 if bf16 else L.uno_spectral_conv2d_forward)
         rc = fn(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws),

@@ -145,11 +145,23 @@ class UNO(nn.Module):
         p = self.padding
         lifted = F.pad(lifted, [p, p, p, p])
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
-        c0 = self.L0(lifted, int(d1 * self.factor), int(d2 * self.factor))
-        c1 = self.L1(c0, d1 // 2, d2 // 2)
-        c2 = self.L2(c1, d1 // 4, d2 // 4)
-        c3 = self.L3(c2, d1 // 4, d2 // 4)
-        c4 = torch.cat([self.L4(c3, d1 // 2, d2 // 2), c1], dim=1)
+        if hasattr(self.L6, "forward_cat") and all(b.non_lin and not b.normalize for b in (self.L2, self.L3)):
+            # c2 and c3 have ONE consumer each: that block applies gelu'(pre) of its producer in the kernel that completes the
+            # gradient (`out_join`, as in UNO_9) - no separate GELU-backward pass for L2 / L3.  (The skip tensors are NOT joined
+            # here the way UNO_9 joins them: at 64^2 x 32 samples every kernel of this model is a 10-30 us launch and the joined
+            # form trades two big element-wise sums for more small launches - measured 81.4 -> 84.3 ms per step.)
+            j2, j3 = GradJoin(), GradJoin()
+            c0 = self.L0(lifted, int(d1 * self.factor), int(d2 * self.factor))
+            c1 = self.L1(c0, d1 // 2, d2 // 2)
+            c2 = self.L2(c1, d1 // 4, d2 // 4, out_join=j2)
+            c3 = self.L3(c2, d1 // 4, d2 // 4, join=j2, out_join=j3)
+            c4 = torch.cat([self.L4(c3, d1 // 2, d2 // 2, join=j3), c1], dim=1)
+        else:
+            c0 = self.L0(lifted, int(d1 * self.factor), int(d2 * self.factor))
+            c1 = self.L1(c0, d1 // 2, d2 // 2)
+            c2 = self.L2(c1, d1 // 4, d2 // 4)
+            c3 = self.L3(c2, d1 // 4, d2 // 4)
+            c4 = torch.cat([self.L4(c3, d1 // 2, d2 // 2), c1], dim=1)
         c5 = torch.cat([self.L5(c4, int(d1 * self.factor), int(d2 * self.factor)), c0], dim=1)
         c6 = torch.cat([self.L6(c5, d1, d2), lifted], dim=1)
         if p != 0:      # the reference pads both sides but crops one (navier_stokes_uno2d.py:201,217-218); kept

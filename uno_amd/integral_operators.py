@@ -103,10 +103,12 @@ class _SpectralConv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2, Ho, Wo, half_weights=False):
         ctx.params = (w1, w2)
-        x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
+        x = _plain(x)
+        ctx.stack = _stack_take(w1, (x.shape[0], x.shape[1], 2 * w1.shape[2], w1.shape[3]), x.device, _stack_wanted(ctx, 1, x, half_weights))
+        w1, w2 = _plain(w1), _plain(w2)
         if half_weights:                    # complex64 master weights, read through float16 (re, im) copies
             w1, w2 = _half_weights(w1, w2)
-        y, xt = _native.spectral_conv2d_forward(x, w1, w2, int(Ho), int(Wo))
+        y, xt = _native.spectral_conv2d_forward(x, w1, w2, int(Ho), int(Wo), xt_out=None if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]])
         ctx.save_for_backward(xt, w1, w2)
         ctx.in_hw = (x.shape[-2], x.shape[-1])
         return y
@@ -115,14 +117,9 @@ class _SpectralConv2dFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gy):
         xt, w1, w2 = ctx.saved_tensors
-        need_gx = ctx.needs_input_grad[0]
-        need_gw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        tg = _grad_targets(ctx.params) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
-        gx, gw1, gw2 = _native.spectral_conv2d_backward(_plain(gy), xt, w1, w2, ctx.in_hw[0], ctx.in_hw[1],
-                                                        need_gx=need_gx, need_gw=need_gw,
-                                                        gw_out=(tg[0][0], tg[1][0]) if tg else None, accumulate_gw=bool(tg and tg[0][1]))
-        if tg:
-            gw1, gw2 = tg[0][2], tg[1][2]
+        gx, gw1, gw2 = _spectral_backward(_plain(gy), xt, w1, w2, ctx.in_hw[0], ctx.in_hw[1], ctx.needs_input_grad[0],
+                                          ctx.needs_input_grad[1] or ctx.needs_input_grad[2],
+                                          ctx.needs_input_grad[1] and ctx.needs_input_grad[2], ctx.params, ctx.stack)
         return gx, gw1, gw2, None, None, None
 
 
@@ -175,15 +172,37 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
 #     node): the kernel adds (beta = 1) into that same tensor and the backward returns None for the parameter.
 # A parameter that already HAS a .grad when the pass starts (accumulation across passes) takes the ordinary path.
 INPLACE_PARAM_GRADS = True
-_PASS = {"id": None, "acc": {}}         # per backward pass (autograd graph task): id(parameter) -> tensor its gradient is being summed in
+_PASS = {"id": None, "acc": {}, "stacks": {}, "uses": {}}
+# per backward pass (autograd graph task):  acc: id(parameter) -> (tensor its gradient is being summed in, parameter, [contributions]);
+# stacks: id(stack) -> (stack, weight leaves, weight shape, [slots whose gradient spectrum arrived in this pass]);
+# uses: id(weights1 leaf) -> [leaf, spectral-layer backward calls of this pass that did NOT go through a stack]
+
+
+def _pass_state():
+    """The dictionaries of the running backward pass (registered with the engine on first use), or None outside a pass."""
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        return None
+    if _PASS["id"] != tid:
+        _PASS.update(id=tid, acc={}, stacks={}, uses={})
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)     # drop the references when this pass completes
+    return _PASS
 
 
 def _end_of_pass():
     """End of a backward pass (engine callback: every node, AccumulateGrad included, has run).  A parameter that received SEVERAL
     contributions in place must now have a .grad that aliases the tensor they were summed in; if it does not, autograd replaced
     that tensor on the way (a gradient for the same parameter from a path outside this library was added out of place) and the
-    later in-place contributions would be missing - fail loudly instead of training on a wrong gradient."""
-    acc, _PASS["id"], _PASS["acc"] = _PASS["acc"], None, {}
+    later in-place contributions would be missing - fail loudly instead of training on a wrong gradient.
+    Spectral layers: remember how often each was used in this pass (the next forward passes stack that many spectra, see
+    _SpectrumStack), and finish the stacks of which only a part of the uses was back-propagated."""
+    acc, stacks, uses = _PASS["acc"], _PASS["stacks"], _PASS["uses"]
+    _PASS.update(id=None, acc={}, stacks={}, uses={})
+    for leaf, count in uses.values():
+        if not getattr(leaf, "_uno_nostack", False):
+            leaf._uno_uses = count[0]
+    for st, leaves, wshape, slots in stacks.values():
+        _stack_flush_partial(st, leaves, wshape, slots)
     for t, param, count in acc.values():
         if count[0] > 1 and param.grad is not None and param.grad.data_ptr() != t.data_ptr():
             raise RuntimeError("uno_amd: a parameter's gradient was accumulated in place by the library's kernels, but autograd also "
@@ -195,12 +214,8 @@ def _grad_plan(p):
     """('acc', tensor): later contribution of this pass | ('new', registered buffer or None): first contribution | None: ordinary path"""
     if not INPLACE_PARAM_GRADS or not isinstance(p, torch.Tensor) or not p.is_leaf or not p.requires_grad or not p.is_cuda:
         return None
-    tid = torch._C._current_graph_task_id()
-    if tid < 0:
+    if _pass_state() is None:
         return None
-    if _PASS["id"] != tid:
-        _PASS["id"], _PASS["acc"] = tid, {}
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)     # drop the references when this pass completes
     acc = _PASS["acc"].get(id(p))
     if acc is not None:
         return "acc", acc[0]
@@ -249,6 +264,168 @@ def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False):
     if x2 is None:
         return _native.channel_wgrad(gy, x1, need_bias=has_bias, act_x=act_x)
     return _mix2_wgrad(gy, x1, x2, has_bias, act_x=act_x)
+
+
+# ---- weight gradient of a spectral layer that is used SEVERAL times in one graph (the 40-step roll-out of ns_train_2d.py:46-68
+# calls every layer 40 times before one backward), batched over the uses.
+# gW[i, o, mode] = sum_t sum_b conj(X_t[b, i, mode]) gO_t[b, o, mode]: executed per use that is 40 per-mode GEMMs with K = batch
+# (32) that each read and re-write the whole weight gradient (2 x 16-26 MB for 8-16 MB of operands: 68 us per call, 15 ms of the
+# 88 ms NS-2D step).  Instead the layer keeps the truncated spectra of its uses in ONE tensor (T, B, Ci, 2 m1, m2) - K1 of use t
+# writes slot t in the forward pass, K1 of the output gradient writes slot t of a second tensor in the backward pass - and the use
+# whose backward comes LAST runs one GEMM with K = T B over both and hands the complete gradient to autograd (the other uses
+# return None for the weights).  Nothing is copied; the spectra were saved for the backward pass anyway.
+# How many slots to provide is what the layer saw in the previous backward pass (`_uno_uses` on the weights1 parameter; the first
+# pass runs use by use).  A stack is closed for new uses once a backward pass touched it or the weights changed; a pass that
+# back-propagates only some of a stack's uses finishes it at the end of the pass (gradient added to .grad directly) and turns the
+# stacking off for that layer.
+TIME_BATCHED_WGRAD = True
+
+
+class _SpectrumStack:
+    __slots__ = ("X", "G", "n", "sealed", "done", "version")
+
+    def __init__(self, cap, shape, device, version):
+        self.X = torch.empty((cap, *shape), dtype=torch.complex64, device=device)     # truncated input spectra, slot per use
+        self.G = None               # truncated output-gradient spectra (allocated for the slots in use when the first one arrives)
+        self.n = 0                  # slots handed out
+        self.sealed = False         # a backward pass has started on it: no new uses
+        self.done = False           # its gradient has been produced: late backward calls (retain_graph) run on their own
+        self.version = version
+
+
+def _stack_take(leaf, shape, device, wanted):
+    """Forward pass of a spectral layer: (stack, slot) for this use's truncated input spectrum, or None (layer used once per pass,
+    no gradient wanted, stacking off)."""
+    if not (TIME_BATCHED_WGRAD and wanted and INPLACE_PARAM_GRADS) or not isinstance(leaf, torch.Tensor) or not leaf.is_leaf:
+        return None
+    cap = getattr(leaf, "_uno_uses", 0)
+    # the per-mode GEMM addresses an operand with 32-bit byte offsets: a stack (and the stack of output-gradient spectra) stays under 2 GiB
+    per_slot = 8 * shape[0] * max(shape[1], leaf.shape[1]) * shape[2] * shape[3]
+    cap = min(cap, (2 ** 31 - 4096) // max(per_slot, 1))
+    if cap < 2 or getattr(leaf, "_uno_nostack", False):
+        return None
+    st = getattr(leaf, "_uno_stack", None)
+    if st is None or st.sealed or st.n >= st.X.shape[0] or tuple(st.X.shape[1:]) != tuple(shape) or st.X.device != device \
+            or st.version != leaf._version:
+        st = _SpectrumStack(cap, shape, device, leaf._version)
+        try:
+            leaf._uno_stack = st
+        except (AttributeError, RuntimeError):
+            return None
+    st.n += 1
+    return st, st.n - 1
+
+
+def _stack_grad_slot(st, slot, Co):
+    """Backward pass: where K1 writes the truncated spectrum of this use's output gradient, or None when the stack is finished."""
+    if st.done:
+        return None
+    st.sealed = True
+    if st.G is None:
+        T, B, _, r2, m2 = st.X.shape
+        st.G = torch.empty((st.n, B, Co, r2, m2), dtype=torch.complex64, device=st.X.device)
+    return st.G[slot]
+
+
+def _stack_wgrad(st, lo, hi, leaves, wshape, in_place):
+    xt, go = st.X[lo:hi].flatten(0, 1), st.G[lo:hi].flatten(0, 1)
+    tg = _grad_targets(leaves) if in_place else None
+    gw1, gw2 = _native.mode_wgrad(xt, go, tuple(wshape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
+                                  accumulate=bool(tg and tg[0][1]))
+    return (tg[0][2], tg[1][2]) if tg else (gw1, gw2)
+
+
+def _stack_arrived(st, slot, leaves, wshape, in_place):
+    """This use's gradient spectrum is in its slot.  -> (gw1, gw2) when it was the last of the stack's uses, else (None, None)."""
+    ps = _pass_state()
+    rec = ps["stacks"].setdefault(id(st), (st, leaves, wshape, []))
+    rec[3].append(slot)
+    if len(rec[3]) < st.n:
+        return None, None
+    del ps["stacks"][id(st)]
+    out = _stack_wgrad(st, 0, st.n, leaves, wshape, in_place)
+    if not getattr(leaves[0], "_uno_nostack", False):
+        leaves[0]._uno_uses = st.n
+    st.done, st.G = True, None
+    return out
+
+
+def _stack_flush_partial(st, leaves, wshape, slots):
+    """End of a pass that back-propagated only `slots` of the stack's uses: their weight gradient goes to .grad directly (the
+    parameters' AccumulateGrad nodes have run), the remaining uses - if a later pass reaches them - run one by one."""
+    import warnings
+    slots = sorted(slots)
+    with torch.no_grad():
+        tot = None
+        k = 0
+        while k < len(slots):
+            e = k
+            while e + 1 < len(slots) and slots[e + 1] == slots[e] + 1:
+                e += 1
+            g = _stack_wgrad(st, slots[k], slots[e] + 1, leaves, wshape, False)
+            tot = g if tot is None else (tot[0] + g[0], tot[1] + g[1])
+            k = e + 1
+        for p, g in zip(leaves, tot):
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+    st.done, st.G = True, None
+    leaves[0]._uno_uses, leaves[0]._uno_nostack = 0, True
+    warnings.warn("uno_amd: a backward pass covered only some of the uses of a spectral layer whose weight gradient is batched "
+                  "over its uses (TIME_BATCHED_WGRAD); the gradient of this pass was added to .grad after the pass (gradient hooks "
+                  "did not see it) and the batching is now off for this layer", RuntimeWarning, stacklevel=2)
+
+
+def _note_use(leaf):
+    """A spectral layer's backward ran outside a stack: count it (what the next forward passes size their stack by)."""
+    ps = _pass_state()
+    if ps is not None and isinstance(leaf, torch.Tensor) and leaf.is_leaf:
+        ps["uses"].setdefault(id(leaf), [leaf, [0]])[1][0] += 1
+
+
+def _stack_wanted(ctx, iw, x, half_weights):
+    return bool(ctx.needs_input_grad[iw] and ctx.needs_input_grad[iw + 1] and x.dtype == torch.float32 and not half_weights)
+
+
+def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, stack, join=None):
+    """Backward of the spectral branch: -> (gx or None, gw1, gw2 as autograd should receive them).
+    leaves = (weights1, weights2) as the caller passed them (in-place gradient targets); stack = (stack, slot) of the forward pass
+    or None; join: GradJoin whose deferred spectra are merged into this layer's before the inverse transform."""
+    B, Co = gs.shape[:2]
+    Ci, _, m1, m2 = w1.shape[:4]
+    gslot = _stack_grad_slot(stack[0], stack[1], Co) if (stack is not None and need_gw) else None
+    merging = join is not None and need_gx and bool(join.spectra)
+    if gslot is None and not merging:
+        tg = _grad_targets(leaves) if (need_gw and both_gw) else None
+        if need_gw:
+            _note_use(leaves[0])
+        gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw,
+                                                        gw_out=(tg[0][0], tg[1][0]) if tg else None,
+                                                        accumulate_gw=bool(tg and tg[0][1]))
+        if tg:
+            gw1, gw2 = tg[0][2], tg[1][2]
+        return gx, gw1, gw2
+    # stage by stage: the gradient spectrum goes to its slot of the layer's stack and / or the deferred gradient spectra of x's
+    # other consumer are added to this layer's before ONE inverse transform
+    gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True, out=gslot)
+    gw1 = gw2 = None
+    if gslot is not None:
+        gw1, gw2 = _stack_arrived(stack[0], stack[1], leaves, w1.shape, both_gw)
+    elif need_gw:
+        tg = _grad_targets(leaves) if both_gw else None
+        _note_use(leaves[0])
+        gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
+                                      accumulate=bool(tg and tg[0][1]))
+        if tg:
+            gw1, gw2 = tg[0][2], tg[1][2]
+    gx = None
+    if need_gx:
+        gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
+        if merging:
+            gX = join.merge(gX, (H, W))
+        gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype)
+    return gx, gw1, gw2
 
 
 class GradJoin:
@@ -611,14 +788,16 @@ class _OperatorBlock2dFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 join.owner = True
                 ctx.join = join
-        x, w1, w2 = _plain(x), _plain(w1), _plain(w2)
+        x = _plain(x)
+        B, Ci, H, W = x.shape
+        ctx.stack = _stack_take(w1, (B, Ci, 2 * w1.shape[2], w1.shape[3]), x.device, _stack_wanted(ctx, 1, x, half_weights))
+        w1, w2 = _plain(w1), _plain(w2)
         if half_weights:
             w1, w2 = _half_weights(w1, w2)
-        B, Ci, H, W = x.shape
         Co = cw.shape[0]
         cwm = _plain(cw).reshape(Co, Ci)
         cb = None if cb is None else _plain(cb)
-        s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo)
+        s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo, xt_out=None if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]])
         same = (H, W) == (Ho, Wo)
         mix_last = same or Ho * Wo < H * W          # the 1x1 convolution runs on whichever side has fewer pixels
         out = s
@@ -665,24 +844,8 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         need_gc = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
         join = ctx.join
         lw1, lw2, lcw, lcb = ctx.leaves
-        tg = _grad_targets((lw1, lw2)) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None     # weights written in place
-        if join is not None and need_gx and join.spectra:
-            # stage by stage: the deferred gradient spectra of x's other consumer are added to this block's before ONE inverse transform
-            m1, m2 = w1.shape[2], w1.shape[3]
-            gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)
-            gw1 = gw2 = None
-            if need_gw:
-                gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
-                                              accumulate=bool(tg and tg[0][1]))
-            gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
-            gX = join.merge(gX, (H, W))
-            gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype)
-        else:
-            gx, gw1, gw2 = _native.spectral_conv2d_backward(gs, xt, w1, w2, H, W, need_gx=need_gx, need_gw=need_gw,
-                                                            gw_out=(tg[0][0], tg[1][0]) if tg else None,
-                                                            accumulate_gw=bool(tg and tg[0][1]))
-        if tg and need_gw:
-            gw1, gw2 = tg[0][2], tg[1][2]
+        gx, gw1, gw2 = _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, ctx.needs_input_grad[1] and ctx.needs_input_grad[2],
+                                          (lw1, lw2), ctx.stack, join)
         gcw = gcb = None
         # x is the activation of a fused-GELU block (join.pre): the gradient this block returns must be multiplied by gelu'(pre).
         # The LAST kernel that accumulates into gx does it - a deferred closure if any is pending, else this block's own
@@ -739,16 +902,18 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         from .resample import resample_forward
         ctx.leaves = (w1, w2, cw, cb)
         ctx.defer = defer if (defer is not None and defer.owner and ctx.needs_input_grad[1]) else None
-        x1, x2, w1, w2 = _plain(x1), _plain(x2), _plain(w1), _plain(w2)
+        x1, x2 = _plain(x1), _plain(x2)
         B, C1, H, W = x1.shape
         C2 = x2.shape[1]
         Ci, Co, m1, m2 = w1.shape
+        ctx.stack = _stack_take(w1, (B, Ci, 2 * m1, m2), x1.device, _stack_wanted(ctx, 2, x1, half_weights))
+        w1, w2 = _plain(w1), _plain(w2)
         if half_weights:
             w1, w2 = _half_weights(w1, w2)
         cwm = _plain(cw).reshape(Co, Ci)
         cb = None if cb is None else _plain(cb)
         # spectral branch, stage by stage (the composite entry point takes a single source)
-        xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x1.device)
+        xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x1.device) if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]]
         _native.dft2d_forward(x1, m1, m2, 1.0 / (H * W), out=xt, channel_offset=0)
         _native.dft2d_forward(x2, m1, m2, 1.0 / (H * W), out=xt, channel_offset=C1)
         O = _native.mode_mix(xt.view(B, Ci, 2, m1 * m2), [w1, w2], 0)
@@ -781,11 +946,16 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_gw = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         need_gc = ctx.needs_input_grad[4] or (has_bias and ctx.needs_input_grad[5])
-        gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True)                       # c (.) keep (.) DFT_trunc(gs)
-        gw1 = gw2 = None
         lw1, lw2, lcw, lcb = ctx.leaves
-        if need_gw:
-            tg = _grad_targets((lw1, lw2)) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3]) else None
+        both_gw = ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+        gslot = _stack_grad_slot(ctx.stack[0], ctx.stack[1], Co) if (ctx.stack is not None and need_gw) else None
+        gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True, out=gslot)             # c (.) keep (.) DFT_trunc(gs)
+        gw1 = gw2 = None
+        if gslot is not None:
+            gw1, gw2 = _stack_arrived(ctx.stack[0], ctx.stack[1], (lw1, lw2), w1.shape, both_gw)
+        elif need_gw:
+            _note_use(lw1)
+            tg = _grad_targets((lw1, lw2)) if both_gw else None
             gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
                                           accumulate=bool(tg and tg[0][1]))
             if tg:
