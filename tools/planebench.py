@@ -1,11 +1,12 @@
-"""K1p / K3p (plane-batched pruned DFTs) timing vs image count: python tools/planebench.py [H W m1 m2]"""
+"""K1p / K3p (plane-batched pruned DFTs) timing vs image count: python tools/planebench.py [H W m1 m2 [image counts ...]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from uno_amd import _native
 dev = torch.device("cuda:0")
 H, W, m1, m2 = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (64, 20, 16, 8)
-for n in (256, 1024, 4096, 16384, 65536):
+NS = tuple(int(a) for a in sys.argv[5:]) or (256, 1024, 4096, 16384, 65536)
+for n in NS:
     x = torch.randn(n, 1, H, W, device=dev)
     O = _native.dft2d_forward(x, m1, m2)
     for name, fn, by in (("fwd", lambda: _native.dft2d_forward(x, m1, m2), 0), ("inv", lambda: _native.dft2d_inverse(O, H, W), 0)):
