@@ -140,10 +140,12 @@ class UNO(nn.Module):
 
     def forward(self, x):
         S1, S2 = x.shape[1], x.shape[2]
-        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1).permute(0, 3, 1, 2).contiguous()
+        # channels-first input in ONE pass: the cat kernel reads the permuted view of x and the (cached, channels-first) grid features
+        x = torch.cat((x.permute(0, 3, 1, 2), self.get_grid(x.shape, x.device).permute(0, 3, 1, 2)), dim=1)
         lifted = F.gelu(gelu_channel_mix(channel_mix(x, self.fc.weight, self.fc.bias), self.fc0.weight, self.fc0.bias))
         p = self.padding
-        lifted = F.pad(lifted, [p, p, p, p])
+        if p != 0:              # (F.pad with zero widths still copies the tensor: 40 copies per roll-out)
+            lifted = F.pad(lifted, [p, p, p, p])
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
         if hasattr(self.L6, "forward_cat") and all(b.non_lin and not b.normalize for b in (self.L2, self.L3)):
             # c2 and c3 have ONE consumer each: that block applies gelu'(pre) of its producer in the kernel that completes the
