@@ -407,6 +407,9 @@ def test_weight_gradient_batched_over_the_uses_of_a_layer():
     ref7 = grads(7, False)
     w1._uno_uses = conv.weights1._uno_uses = 5
     same(grads(7, True), ref7)
+    assert w1._uno_uses == 7                                    # every use of the pass counted: the next stack holds all seven
+    same(grads(7, True), ref7)
+    assert w1._uno_stack.n == 7
     # retained graph: the second backward finds its stacks finished and runs use by use
     for p in params:
         p.grad = None

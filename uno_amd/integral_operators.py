@@ -274,8 +274,9 @@ def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False):
 # writes slot t in the forward pass, K1 of the output gradient writes slot t of a second tensor in the backward pass - and the use
 # whose backward comes LAST runs one GEMM with K = T B over both and hands the complete gradient to autograd (the other uses
 # return None for the weights).  Nothing is copied; the spectra were saved for the backward pass anyway.
-# How many slots to provide is what the layer saw in the previous backward pass (`_uno_uses` on the weights1 parameter; the first
-# pass runs use by use).  A stack is closed for new uses once a backward pass touched it or the weights changed; a pass that
+# How many slots to provide is the number of uses the layer saw in the previous backward pass (`_uno_uses` on the weights1 parameter,
+# stacked or not; the first pass runs use by use, a pass with more uses than slots fills several stacks and the next one is sized
+# for all of them).  A stack is closed for new uses once a backward pass touched it or the weights changed; a pass that
 # back-propagates only some of a stack's uses finishes it at the end of the pass (gradient added to .grad directly) and turns the
 # stacking off for that layer.
 TIME_BATCHED_WGRAD = True
@@ -338,14 +339,13 @@ def _stack_wgrad(st, lo, hi, leaves, wshape, in_place):
 def _stack_arrived(st, slot, leaves, wshape, in_place):
     """This use's gradient spectrum is in its slot.  -> (gw1, gw2) when it was the last of the stack's uses, else (None, None)."""
     ps = _pass_state()
+    ps["uses"].setdefault(id(leaves[0]), [leaves[0], [0]])[1][0] += 1      # every use of the pass counts: the next stacks hold them all
     rec = ps["stacks"].setdefault(id(st), (st, leaves, wshape, []))
     rec[3].append(slot)
     if len(rec[3]) < st.n:
         return None, None
     del ps["stacks"][id(st)]
     out = _stack_wgrad(st, 0, st.n, leaves, wshape, in_place)
-    if not getattr(leaves[0], "_uno_nostack", False):
-        leaves[0]._uno_uses = st.n
     st.done, st.G = True, None
     return out
 
