@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 5
+#define UNO_SPECTRAL_ABI_VERSION 6
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -200,12 +200,18 @@ int uno_channel_wgrad(const float* gy, const float* x, float* gw, float* gb, voi
  *   y (which is still written: the backward of uno_gelu_project_forward needs it); Co <= 64, single destination.
  * Splits must be multiples of 16 (C1) / 64 (Co1; 128 when Co is a multiple of 128) channels; uno_channel_wgrad2 needs
  * C1 % 64 == 0 and P >= 64 (x2 = NULL: any shape).  gw is the full (Co, Ci) gradient; accumulate != 0: gw / gb += (the kernels
- * write a parameter's gradient buffer in place: the unrolled roll-out of ns_train_2d.py:46-68 sums 40 contributions per weight). */
+ * write a parameter's gradient buffer in place: the unrolled roll-out of ns_train_2d.py:46-68 sums 40 contributions per weight).
+ * uno_channel_wgrad2 with accumulate = 3 runs the first stage only: the split-K partial sums stay in ws
+ * (uno_channel_wgrad_ws_bytes() bytes = nparts blocks of (Co, Ci + 1) floats, bias sums in column Ci), gw / gb are not touched
+ * (may be NULL); uno_channel_wgrad_finish() then sums `nparts` CONSECUTIVE blocks - the ws of one call, or of the T calls of a
+ * roll-out laid out one after the other - into gw / gb (gb may be NULL) in the fixed order of the blocks: one second stage per
+ * layer and training step instead of one per use. */
 int uno_channel_mix2(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
                      float* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
                      const float* dgelu_of, const float* proj_w, const float* proj_b, float* proj_out, void* stream);
 int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
                        int Co, long long P, int act_x, int accumulate, void* stream);
+int uno_channel_wgrad_finish(const void* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, void* stream);
 
 /* Final projection of the U-NO models fused with the GELU in front of it (reference darcy_flow_uno2d.py:128-131:
  * `x_fc1 = F.gelu(self.fc1(x)); x_out = self.fc2(x_fc1)` with fc2 = Linear(C, 1)), channels-first:

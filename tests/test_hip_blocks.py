@@ -391,6 +391,7 @@ def test_weight_gradient_batched_over_the_uses_of_a_layer():
     got = grads(5, True)
     st = w1._uno_stack
     assert st.n == 5 and st.done and tuple(st.X.shape[:2]) == (5, 3), "the layer did not stack its five uses"
+    assert st.Pinfo is not None and st.P is None, "the block's 1x1 convolution did not defer its second stage to the last use"
     same(got, ref5)
     # through a flat gradient buffer: the single GEMM writes into the parameter's view
     fg = FlatGradients(params)
@@ -410,6 +411,28 @@ def test_weight_gradient_batched_over_the_uses_of_a_layer():
     assert w1._uno_uses == 7                                    # every use of the pass counted: the next stack holds all seven
     same(grads(7, True), ref7)
     assert w1._uno_stack.n == 7
+    # one layer on different grids within a pass: the uses share the spectral stack, the 1x1 convolution's partial sums only fit
+    # the stack's first grid - the others are computed on their own (any order of fitting / non-fitting uses, also as the last one)
+    def zigzag():
+        h = x
+        for d in (20, 16, 24, 20, 24, 16):
+            h = torch.tanh(blk(h, d, d))
+        return h.square().sum()
+    for p in params:
+        p.grad = None
+    io.TIME_BATCHED_WGRAD = False
+    try:
+        zigzag().backward()
+    finally:
+        io.TIME_BATCHED_WGRAD = True
+    refz = [None if p.grad is None else p.grad.clone() for p in params[:len(list(blk.parameters()))]]
+    for rep in range(2):
+        for p in params:
+            p.grad = None
+        zigzag().backward()
+        same([p.grad for p in blk.parameters()], refz)
+    assert w1._uno_stack.n == 6
+    blk.conv.dim1 = blk.conv.dim2 = 24          # the call-time override sticks to the spectral layer (reference integral_operators.py:182-184)
     # retained graph: the second backward finds its stacks finished and runs use by use
     for p in params:
         p.grad = None

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 _lock = threading.Lock()
@@ -51,6 +51,7 @@ _SIGNATURES = {
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
+    "uno_channel_wgrad_finish": (C.c_int, [_fp, _fp, _fp, _i, _i, C.c_longlong, _i, _fp]),
     "uno_mode_wgrad_acc": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
     "uno_spectral_conv2d_backward_acc": (C.c_int, [_fp] * 8 + [_i] * 11 + [_fp]),
     "uno_gelu_project_forward": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
@@ -524,10 +525,41 @@ def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2
     return (y1, act) if y_act else y1
 
 
-def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False, out_w=None, out_b=None, accumulate: bool = False):
+def channel_wgrad_partial_floats(B: int, Ci: int, Co: int, P: int) -> int:
+    """floats of split-K partial sums one weight-gradient call of this shape leaves (a whole number of (Co, Ci + 1) blocks)"""
+    return int(lib().uno_channel_wgrad_ws_bytes(B, Ci, Co, P)) // 4
+
+
+def channel_wgrad_finish(parts, Ci: int, Co: int, need_bias: bool, out_w=None, out_b=None, accumulate: bool = False):
+    """Second stage alone: `parts` = float32 tensor holding consecutive (Co, Ci + 1) blocks of partial sums (channel_wgrad2(...,
+    partials_out=row) for every row) -> gw (Co, Ci), gb (Co) or None, written (accumulate: added) into out_w / out_b when given."""
+    _require(parts, torch.float32, "partial sums")
+    blk = Co * (Ci + 1)
+    if parts.numel() == 0 or parts.numel() % blk:
+        raise RuntimeError("uno_amd: the partial sums are not a whole number of (Co, Ci + 1) blocks")
+    if out_w is None:
+        accumulate = False
+        gw = torch.empty((Co, Ci), dtype=torch.float32, device=parts.device)
+        gb = torch.empty((Co,), dtype=torch.float32, device=parts.device) if need_bias else None
+    else:
+        gw, gb = out_w, (out_b if need_bias else None)
+        _require(gw, torch.float32, "weight-gradient buffer")
+        if gw.numel() != Co * Ci or (need_bias and (gb is None or gb.numel() != Co)):
+            raise RuntimeError("uno_amd: gradient buffers do not match the layer")
+    with torch.cuda.device(parts.device):
+        rc = lib().uno_channel_wgrad_finish(_ptr(parts), _ptr(gw), _ptr(gb) if gb is not None else C.c_void_p(0), Ci, Co,
+                                            parts.numel() // blk, 1 if accumulate else 0, _stream(parts))
+    _check(rc, "uno_channel_wgrad_finish")
+    return gw, gb
+
+
+def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False, out_w=None, out_b=None, accumulate: bool = False,
+                   partials_out=None):
     """gy (B, Co, P), x1 (B, C1, P), x2 (B, C2, P) or None -> gw (Co, C1 + C2), gb (Co) or None: the weight gradient of a
     (two-source) layer from one launch (act_x: x1 := gelu(x1) as it is read).  out_w / out_b: write (accumulate: add) into these
-    float32 tensors of Co * Ci / Co elements instead of fresh ones (out_b is required with need_bias when out_w is given)."""
+    float32 tensors of Co * Ci / Co elements instead of fresh ones (out_b is required with need_bias when out_w is given).
+    partials_out: a dense float32 tensor of channel_wgrad_partial_floats() elements - the first stage only, its partial sums left
+    there for channel_wgrad_finish (-> None, None)."""
     bf16 = _act_dtype(gy, "grad_output")
     _require(x1, gy.dtype, "x1")
     B, Co, P = gy.shape
@@ -542,6 +574,16 @@ def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False, out_
         raise RuntimeError("uno_amd: grad_output and the sources disagree in batch / pixel count")
     Ci = C1 + C2
     L = lib()
+    if partials_out is not None:
+        _require(partials_out, torch.float32, "partial-sum buffer")
+        if partials_out.numel() != channel_wgrad_partial_floats(B, Ci, Co, P):
+            raise RuntimeError("uno_amd: partial-sum buffer has the wrong size")
+        with torch.cuda.device(gy.device):
+            fn = L.uno_channel_wgrad2_bf16 if bf16 else L.uno_channel_wgrad2
+            rc = fn(_ptr(gy), _ptr(x1), _ptr(x2) if x2 is not None else C.c_void_p(0), C1, C.c_void_p(0), C.c_void_p(0),
+                    _ptr(partials_out), B, Ci, Co, P, 1 if act_x else 0, 3, _stream(gy))
+        _check(rc, "uno_channel_wgrad2")
+        return None, None
     if out_w is None:
         accumulate = False
         gw = torch.empty((Co, Ci), dtype=torch.float32, device=gy.device)

@@ -440,8 +440,14 @@ int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, 
 static int channel_wgrad2_impl(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
                                int Co, long long P, int act_x, int accumulate, int bf16, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
-    if (!gw) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
+    if (accumulate < 0 || accumulate > 3 || accumulate == 2) { set_error("uno_channel_wgrad2: accumulate is 0, 1 or 3 (got %d)", accumulate); return -1; }
+    if (!gw && accumulate != 3) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
     if (B == 0 || P == 0) {
+        if (accumulate == 3) {      // an empty call's partial sums are zeros
+            if (!ws) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
+            if (hipMemsetAsync(ws, 0, uno_channel_wgrad_ws_bytes(B, Ci, Co, P), (hipStream_t)stream) != hipSuccess) { set_error("uno_channel_wgrad2: memset failed"); return -5; }
+            return 0;
+        }
         if (accumulate) return 0;
         if (hipMemsetAsync(gw, 0, sizeof(float) * Co * Ci, (hipStream_t)stream) != hipSuccess ||
             (gb && hipMemsetAsync(gb, 0, sizeof(float) * Co, (hipStream_t)stream) != hipSuccess)) { set_error("uno_channel_wgrad2: memset failed"); return -5; }
@@ -459,6 +465,12 @@ int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1
 int uno_channel_wgrad2_bf16(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
                             long long P, int act_x, int accumulate, void* stream) {
     return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, accumulate, 1, stream);
+}
+
+int uno_channel_wgrad_finish(const void* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, void* stream) {
+    if (Ci < 1 || Co < 1 || nparts < 1) { set_error("uno_channel_wgrad_finish: bad sizes Ci=%d Co=%d blocks=%lld", Ci, Co, nparts); return -1; }
+    if (!parts || !gw) { set_error("uno_channel_wgrad_finish: null pointer"); return -1; }
+    return launch_channel_wgrad_finish((const float*)parts, gw, gb, Ci, Co, nparts, accumulate, (hipStream_t)stream);
 }
 
 int uno_adam_step(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,

@@ -955,8 +955,8 @@ __global__ __launch_bounds__(256) void channel_wgrad_reduce_kernel(const float* 
         for (int g = 1; g < 8; ++g) t += sh[g][el];
         const int o = e / (Ci + 1), i = e % (Ci + 1);
         // accumulate: the results are added to what gw / gb hold (a parameter's gradient buffer written in place)
-        if (i < Ci) gw[(size_t)o * Ci + i] = accumulate ? gw[(size_t)o * Ci + i] + t : t;
-        else if (gb) gb[o] = accumulate ? gb[o] + t : t;
+        if (i < Ci) gw[(size_t)o * Ci + i] = accumulate == 1 ? gw[(size_t)o * Ci + i] + t : t;
+        else if (gb) gb[o] = accumulate == 1 ? gb[o] + t : t;
     }
 }
 
@@ -1012,7 +1012,8 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
 #undef UNO_CWF
         }
         const int nf = Co * (Ci + 1);
-        hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((nf + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
+        if (accumulate != 3)
+            hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((nf + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
@@ -1033,9 +1034,21 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
         }
     }
     const int n = Co * (Ci + 1);
-    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
+    if (accumulate != 3)        // 3: the partial sums stay in ws; launch_channel_wgrad_finish sums any number of such blocks later
+        hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+// second stage alone: nparts consecutive (Co, Ci + 1) blocks of partial sums (the ws of one or more stage-1 calls with
+// accumulate = 3, laid out one after the other) -> gw, gb, in the fixed order of the blocks
+int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s) {
+    if (nparts < 1 || nparts > 0x7fffffffLL) { set_error("channel_wgrad_finish: %lld partial blocks", nparts); return -2; }
+    const int n = Co * (Ci + 1);
+    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, parts, gw, gb, Co, Ci, (int)nparts, accumulate ? 1 : 0);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("channel_wgrad_finish launch: %s", hipGetErrorString(e)); return -5; }
     return 0;
 }
 

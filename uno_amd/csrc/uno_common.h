@@ -259,5 +259,6 @@ int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, fl
                          int act_x, int bf16, hipStream_t s);
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
                           long long P, int act_x, int accumulate, int bf16, hipStream_t s);
+int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s);
 
 }  // namespace uno

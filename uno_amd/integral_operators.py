@@ -117,7 +117,7 @@ class _SpectralConv2dFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gy):
         xt, w1, w2 = ctx.saved_tensors
-        gx, gw1, gw2 = _spectral_backward(_plain(gy), xt, w1, w2, ctx.in_hw[0], ctx.in_hw[1], ctx.needs_input_grad[0],
+        gx, gw1, gw2, _ = _spectral_backward(_plain(gy), xt, w1, w2, ctx.in_hw[0], ctx.in_hw[1], ctx.needs_input_grad[0],
                                           ctx.needs_input_grad[1] or ctx.needs_input_grad[2],
                                           ctx.needs_input_grad[1] and ctx.needs_input_grad[2], ctx.params, ctx.stack)
         return gx, gw1, gw2, None, None, None
@@ -245,14 +245,21 @@ def _grad_targets(params):
     return out
 
 
-def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False):
+def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False, stack=None):
     """Weight / bias gradient of a channel-mix layer (K9), written in place where the layer's leaf parameters allow it.
-    leaves = (weight leaf, bias leaf or None) or None.  -> (gw or None shaped (Co, Ci), gb or None) to return to autograd."""
+    leaves = (weight leaf, bias leaf or None) or None.  -> (gw or None shaped (Co, Ci), gb or None) to return to autograd.
+    stack = (stack, slot) of the block's spectral layer when that is batching its weight gradient over the uses of the pass: the
+    second stage of this gradient is deferred to the last use as well (_stack_pointwise)."""
     if not (need_w or need_b):
         return None, None
     has_bias = need_b
     tg = None
     fused = x2 is None or (x1.shape[1] % 64 == 0 and gy.shape[2] >= 64)
+    if stack is not None and fused and leaves is not None and need_w and (leaves[1] is not None) == has_bias and gy.dtype == torch.float32 \
+            and all(isinstance(t, torch.Tensor) and t.is_leaf for t in leaves if t is not None):
+        out = _stack_pointwise(stack, leaves, gy, x1, x2, has_bias, act_x)
+        if out is not NotImplemented:
+            return out
     if fused and leaves is not None and need_w and (leaves[1] is not None) == has_bias:
         tg = _grad_targets([leaves[0]] + ([leaves[1]] if has_bias else []))        # committed: the call below writes them
     if tg is not None:
@@ -283,11 +290,13 @@ TIME_BATCHED_WGRAD = True
 
 
 class _SpectrumStack:
-    __slots__ = ("X", "G", "n", "sealed", "done", "version")
+    __slots__ = ("X", "G", "n", "sealed", "done", "version", "P", "Pinfo")
 
     def __init__(self, cap, shape, device, version):
         self.X = torch.empty((cap, *shape), dtype=torch.complex64, device=device)     # truncated input spectra, slot per use
         self.G = None               # truncated output-gradient spectra (allocated for the slots in use when the first one arrives)
+        self.P = None               # (n, floats) split-K partial sums of the block's 1x1 convolution weight gradient, row per use
+        self.Pinfo = None           # (Ci, Co, has_bias, (weight leaf, bias leaf)) of those
         self.n = 0                  # slots handed out
         self.sealed = False         # a backward pass has started on it: no new uses
         self.done = False           # its gradient has been produced: late backward calls (retain_graph) run on their own
@@ -350,6 +359,40 @@ def _stack_arrived(st, slot, leaves, wshape, in_place):
     return out
 
 
+def _stack_pointwise(stack, leaves, gy, x1, x2, has_bias, act_x):
+    """The 1x1 convolution's weight gradient of a block whose spectral layer is stacked: K9's first stage leaves this use's split-K
+    partial sums in row `slot` of the stack's (n, floats) buffer, and the use that completes the stack runs ONE second stage over
+    all rows (the roll-out ran 40 second stages of ~5 us per layer; their read-modify-write of the gradient goes with them).
+    -> (gw (Co, Ci), gb) for autograd ((None, None) until the last use), or NotImplemented: take the ordinary path for this call."""
+    st, slot = stack
+    B, Co, P = gy.shape
+    Ci = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    nf = _native.channel_wgrad_partial_floats(B, Ci, Co, P)
+    if st.P is None:
+        if st.Pinfo is not None:
+            return NotImplemented               # the stack's buffer has been consumed (late call on a retained graph)
+        st.P = torch.empty((st.n, nf), dtype=torch.float32, device=gy.device)
+        st.Pinfo = (Ci, Co, has_bias, leaves)
+    fits = st.P.shape[1] == nf and st.Pinfo[:3] == (Ci, Co, has_bias)
+    if fits:
+        _native.channel_wgrad2(gy, x1, x2, need_bias=has_bias, act_x=act_x, partials_out=st.P[slot])
+    else:
+        st.P[slot].zero_()                      # another grid than the stack's other uses: this use is computed on its own
+    if not st.done:
+        return (None, None) if fits else NotImplemented
+    # the spectral half of this backward call completed the stack: every row is written
+    Ci0, Co0, hb0, lv = st.Pinfo
+    tg = _grad_targets([lv[0]] + ([lv[1]] if hb0 else []))
+    gw, gb = _native.channel_wgrad_finish(st.P, Ci0, Co0, hb0, out_w=tg[0][0] if tg else None,
+                                          out_b=tg[1][0] if (tg and hb0) else None, accumulate=bool(tg and tg[0][1]))
+    st.P = None
+    if not fits:
+        _native.channel_wgrad2(gy, x1, x2, need_bias=hb0, act_x=act_x, out_w=gw, out_b=gb, accumulate=True)
+    if tg:
+        gw, gb = (None if tg[0][2] is None else tg[0][2].view(Co0, Ci0)), (tg[1][2] if hb0 else None)
+    return gw, gb
+
+
 def _stack_flush_partial(st, leaves, wshape, slots):
     """End of a pass that back-propagated only `slots` of the stack's uses: their weight gradient goes to .grad directly (the
     parameters' AccumulateGrad nodes have run), the remaining uses - if a later pass reaches them - run one by one."""
@@ -370,6 +413,25 @@ def _stack_flush_partial(st, leaves, wshape, slots):
                 p.grad = g
             else:
                 p.grad.add_(g)
+        if st.P is not None:                    # the block's 1x1 convolution: second stage over the rows that were written
+            Ci0, Co0, hb0, lv = st.Pinfo
+            ptot = None
+            k = 0
+            while k < len(slots):
+                e = k
+                while e + 1 < len(slots) and slots[e + 1] == slots[e] + 1:
+                    e += 1
+                g = _native.channel_wgrad_finish(st.P[slots[k]:slots[e] + 1], Ci0, Co0, hb0)
+                ptot = g if ptot is None else (ptot[0] + g[0], (ptot[1] + g[1]) if hb0 else None)
+                k = e + 1
+            for p, g in ((lv[0], ptot[0]), (lv[1] if hb0 else None, ptot[1])):
+                if p is not None:
+                    g = g.view(p.shape)
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        p.grad.add_(g)
+            st.P = None
     st.done, st.G = True, None
     leaves[0]._uno_uses, leaves[0]._uno_nostack = 0, True
     warnings.warn("uno_amd: a backward pass covered only some of the uses of a spectral layer whose weight gradient is batched "
@@ -389,7 +451,7 @@ def _stack_wanted(ctx, iw, x, half_weights):
 
 
 def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, stack, join=None):
-    """Backward of the spectral branch: -> (gx or None, gw1, gw2 as autograd should receive them).
+    """Backward of the spectral branch: -> (gx or None, gw1, gw2 as autograd should receive them, whether the layer's stack took the call).
     leaves = (weights1, weights2) as the caller passed them (in-place gradient targets); stack = (stack, slot) of the forward pass
     or None; join: GradJoin whose deferred spectra are merged into this layer's before the inverse transform."""
     B, Co = gs.shape[:2]
@@ -405,7 +467,7 @@ def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, 
                                                         accumulate_gw=bool(tg and tg[0][1]))
         if tg:
             gw1, gw2 = tg[0][2], tg[1][2]
-        return gx, gw1, gw2
+        return gx, gw1, gw2, False
     # stage by stage: the gradient spectrum goes to its slot of the layer's stack and / or the deferred gradient spectra of x's
     # other consumer are added to this layer's before ONE inverse transform
     gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True, out=gslot)
@@ -425,7 +487,7 @@ def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, 
         if merging:
             gX = join.merge(gX, (H, W))
         gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype)
-    return gx, gw1, gw2
+    return gx, gw1, gw2, gslot is not None
 
 
 class GradJoin:
@@ -844,8 +906,9 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         need_gc = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
         join = ctx.join
         lw1, lw2, lcw, lcb = ctx.leaves
-        gx, gw1, gw2 = _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, ctx.needs_input_grad[1] and ctx.needs_input_grad[2],
-                                          (lw1, lw2), ctx.stack, join)
+        gx, gw1, gw2, stacked = _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, ctx.needs_input_grad[1] and ctx.needs_input_grad[2],
+                                                   (lw1, lw2), ctx.stack, join)
+        pstack = ctx.stack if stacked else None         # the 1x1 convolution's weight gradient follows the spectral layer's stack
         gcw = gcb = None
         # x is the activation of a fused-GELU block (join.pre): the gradient this block returns must be multiplied by gelu'(pre).
         # The LAST kernel that accumulates into gx does it - a deferred closure if any is pending, else this block's own
@@ -866,7 +929,7 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                     resample_adjoint(g_act.view(B, Ci, Ho, Wo), H, W, out=gx)
             if need_gc:
                 gcw, gcb = _wgrad_into((lcw, lcb), gs.view(B, Co, -1), act.view(B, Ci, -1), None, ctx.needs_input_grad[3],
-                                       has_bias and ctx.needs_input_grad[4])
+                                       has_bias and ctx.needs_input_grad[4], stack=pstack)
         else:
             # forward: t = Wm x + b;  s += R t
             g_t = resample_adjoint(gs, H, W).view(B, Co, -1)
@@ -875,7 +938,7 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                 dg_done = own_last
             if need_gc:
                 gcw, gcb = _wgrad_into((lcw, lcb), g_t, act.view(B, Ci, -1), None, ctx.needs_input_grad[3],
-                                       has_bias and ctx.needs_input_grad[4])
+                                       has_bias and ctx.needs_input_grad[4], stack=pstack)
         if gcw is not None:
             gcw = gcw.view(cw_shape)
         if join is not None:
