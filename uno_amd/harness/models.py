@@ -139,9 +139,13 @@ class UNO(nn.Module):
         return _cached(self._grid_cache, (tuple(shape[:3]), str(device)), build)
 
     def forward(self, x):
-        S1, S2 = x.shape[1], x.shape[2]
         # channels-first input in ONE pass: the cat kernel reads the permuted view of x and the (cached, channels-first) grid features
-        x = torch.cat((x.permute(0, 3, 1, 2), self.get_grid(x.shape, x.device).permute(0, 3, 1, 2)), dim=1)
+        z = torch.cat((x.permute(0, 3, 1, 2), self.get_grid(x.shape, x.device).permute(0, 3, 1, 2)), dim=1)
+        return self.forward_cf(z).permute(0, 2, 3, 1).contiguous()         # one channel: the permuted view IS contiguous
+
+    def forward_cf(self, x):
+        """(B, T_in + 4, S, S) channels-first window + positional features -> (B, 1, S, S).  The roll-out keeps its window in this
+        layout (harness.ns2d_rollout_loss): one concatenation per step instead of one for the window and one for the layout."""
         lifted = F.gelu(gelu_channel_mix(channel_mix(x, self.fc.weight, self.fc.bias), self.fc0.weight, self.fc0.bias))
         p = self.padding
         if p != 0:              # (F.pad with zero widths still copies the tensor: 40 copies per roll-out)
@@ -168,8 +172,7 @@ class UNO(nn.Module):
         c6 = torch.cat([self.L6(c5, d1, d2), lifted], dim=1)
         if p != 0:      # the reference pads both sides but crops one (navier_stokes_uno2d.py:201,217-218); kept
             c6 = c6[..., :-p, :-p]
-        out = gelu_project(channel_mix(c6.contiguous(), self.fc1.weight, self.fc1.bias), self.fc2.weight, self.fc2.bias)
-        return out.permute(0, 2, 3, 1).contiguous()
+        return gelu_project(channel_mix(c6.contiguous(), self.fc1.weight, self.fc1.bias), self.fc2.weight, self.fc2.bias)
 
 
 class Uno3D_T20(nn.Module):

@@ -169,6 +169,17 @@ def ns2d_rollout_loss(model, xx, yy, T_f, step=1):
     L2 losses are summed; ONE backward runs through the whole unrolled chain."""
     loss = 0
     B = yy.shape[0]
+    if step == 1 and hasattr(model, "forward_cf") and hasattr(model, "get_grid"):
+        # the window lives channels-first next to the model's positional features: per step ONE concatenation
+        # [frames 1.., new frame, features] instead of the channels-last window, its layout change and the feature concatenation
+        T_in = xx.shape[-1]
+        z = torch.cat((xx.permute(0, 3, 1, 2), model.get_grid(xx.shape, xx.device).permute(0, 3, 1, 2)), dim=1)
+        for t in range(T_f):
+            im = model.forward_cf(z)                                # (B, 1, S, S)
+            loss = loss + lp_loss_rel_sum(im.reshape(B, -1), yy[..., t:t + 1].reshape(B, -1))
+            if t + 1 < T_f:
+                z = torch.cat((z[:, 1:T_in], im, z[:, T_in:]), dim=1)
+        return loss
     for t in range(0, T_f, step):
         im = model(xx)
         loss = loss + lp_loss_rel_sum(im.reshape(B, -1), yy[..., t:t + step].reshape(B, -1))
