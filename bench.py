@@ -384,7 +384,7 @@ def dp_selfcheck(dev, world, rank):
     """Before anything is timed with N > 1 ranks: two training steps of a small UNO_9 on a global batch of 2 x world samples,
     sharded over the ranks (bucketed RCCL all-reduce, several buckets) against the same two steps in ONE process on the whole
     batch (computed redundantly on every rank, no collectives).  Gradients are SUMMED over ranks, so the flat gradient buffers
-    must agree to float32 summation order - the check tests/test_hip_dist.py::test_two_ranks_rccl_equal_single_process makes, run where the
+    must agree to float32 summation order - the check tests/test_hip_zz_dist.py::test_two_ranks_rccl_equal_single_process makes, run where the
     devices are.  Raises on mismatch: a wrong exchange never produces a throughput number."""
     import torch
     import torch.distributed as dist

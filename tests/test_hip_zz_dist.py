@@ -1,7 +1,9 @@
 """RCCL smoke test of the data-parallel step on ONE GPU: a 1-rank "nccl" process group with the collectives
 forced on (broadcast of parameters, all-reduce of the flat gradient buffer incl. complex grads, barrier) must
 reproduce the plain single-process step bit for bit.  The multi-rank arithmetic is covered on CPU with gloo
-(tests/test_harness_cpu.py); the multi-GPU run itself is the driver's.  pytest -m gpu"""
+(tests/test_harness_cpu.py); the multi-GPU run itself is the driver's.  pytest -m gpu
+(The file sorts LAST on purpose: process-group set-up is the one part of the suite that depends on the box outside the GPU - a
+rendezvous that hangs there ends a `-x` run after every kernel test has reported, not before 450 of them.)"""
 import os
 import socket
 
