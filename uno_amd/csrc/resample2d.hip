@@ -97,6 +97,10 @@ __global__ __launch_bounds__(256) void resample_cols_generic_kernel(const TI* __
 //   phase 2 (columns): banded column operator from LDS, TR x Wo outputs written unit-stride.
 // The image is read once (plus the band overlap of neighbouring tiles, an L2 hit) and the result written once.
 constexpr int RS_TR = 16;
+// phase-1 prefetch depth (k-steps of four input rows in flight per lane).  Measured 1 .. 8 on one box (tools/rsbench.py, six Darcy
+// shapes + the accumulating calls): 2 is best, 3 (rounds 2-3) 2-4 % behind, 6 and 8 are 5-25 % SLOWER - more loads in flight per
+// wave hurt this kernel (Darcy step 13.95 -> 13.84 ms with 2)
+constexpr int RS_PD = 2;
 
 // MF: phase 1 on v_mfma_f32_16x16x4_f32.  The dense 16 x NP row operator of the tile is the A operand (one LDS read per k-step
 // from a table in operand layout), a lane's 16-byte piece of an input row is the B operand of FOUR column tiles (tile e = columns 4 n + e of the
@@ -140,16 +144,24 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = f32x4{0, 0, 0, 0};
             auto fetch = [&](int ks) { return io_ld4(colp + (size_t)min(p0 + 4 * ks + kk, H - 1) * W); };     // rows past the tile meet zero weights
-            float4 x0 = fetch(0), x1 = fetch(min(1, nks - 1)), x2 = fetch(min(2, nks - 1));
-            for (int ks = 0; ks < nks; ++ks) {
-                const float a = sWd[ks * 64 + lane];
-                const float4 x = x0;
-                x0 = x1; x1 = x2;
-                x2 = fetch(min(ks + 3, nks - 1));                                  // unconditional: the waits stay partial
-                acc[0] = mfma16(a, x.x, acc[0]);
-                acc[1] = mfma16(a, x.y, acc[1]);
-                acc[2] = mfma16(a, x.z, acc[2]);
-                acc[3] = mfma16(a, x.w, acc[3]);
+            // RS_PD k-steps of rows in flight per lane
+            float4 xb[RS_PD];
+#pragma unroll
+            for (int d = 0; d < RS_PD; ++d) xb[d] = fetch(min(d, nks - 1));
+            for (int ks0 = 0; ks0 < nks; ks0 += RS_PD) {
+#pragma unroll
+                for (int d = 0; d < RS_PD; ++d) {
+                    const int ks = ks0 + d;
+                    if (ks < nks) {                                                      // uniform
+                        const float a = sWd[ks * 64 + lane];
+                        const float4 x = xb[d];
+                        xb[d] = fetch(min(ks + RS_PD, nks - 1));                        // unconditional: the waits stay partial
+                        acc[0] = mfma16(a, x.x, acc[0]);
+                        acc[1] = mfma16(a, x.y, acc[1]);
+                        acc[2] = mfma16(a, x.z, acc[2]);
+                        acc[3] = mfma16(a, x.w, acc[3]);
+                    }
+                }
             }
             // accumulator register r of lane (g = kk, n16) of tile e: output row 4 g + r, column col + e
             if (c0 + 4 * n16 == col) {
