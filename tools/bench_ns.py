@@ -4,6 +4,10 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+for _a in sys.argv[1:]:
+    if _a.endswith(".so"):          # a library variant (tools/dev/mkvariant.py)
+        from uno_amd import _native
+        _native.LIB_PATH = os.path.abspath(_a)
 from uno_amd.harness import UNO, Uno3D_T20, ComplexAdam, GraphedStep, ns2d_rollout_loss, ns3d_loss
 dev = torch.device("cuda:0")
 
