@@ -258,6 +258,39 @@ def test_two_source_wgrad(B, C1, C2, Co, P, act_x):
     assert rel(gb, gy.double().sum(dim=(0, 2))) < 2e-5
 
 
+@pytest.mark.parametrize("B,Ci,C2,Co,P,act_x", [(2, 8, 0, 8, 576, False), (3, 64, 64, 64, 300, True), (2, 3, 0, 32, 2048, False), (1, 192, 0, 96, 77, False)])
+def test_wgrad_first_stage_then_one_second_stage(B, Ci, C2, Co, P, act_x):
+    """uno_channel_wgrad2 with accumulate = 3 leaves its split-K partial sums; uno_channel_wgrad_finish sums the partial sums of
+    SEVERAL calls (the uses of a layer in a roll-out, reference ns_train_2d.py:46-68) in one second stage: same result as the sum of
+    the separate weight gradients, written or accumulated."""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(B + Ci + Co + P)
+    T = 3
+    gys = [torch.randn(B, Co, P, generator=g).cuda() for _ in range(T)]
+    x1s = [torch.randn(B, Ci, P, generator=g).cuda() for _ in range(T)]
+    x2s = [torch.randn(B, C2, P, generator=g).cuda() if C2 else None for _ in range(T)]
+    nf = _native.channel_wgrad_partial_floats(B, Ci + C2, Co, P)
+    assert nf > 0 and nf % (Co * (Ci + C2 + 1)) == 0
+    parts = torch.full((T, nf), float("nan"), device="cuda")            # every float of a row must be written by its call
+    refw = torch.zeros(Co, Ci + C2, dtype=torch.float64, device="cuda")
+    refb = torch.zeros(Co, dtype=torch.float64, device="cuda")
+    for t in range(T):
+        assert _native.channel_wgrad2(gys[t], x1s[t], x2s[t], act_x=act_x, partials_out=parts[t]) == (None, None)
+        gw, gb = _native.channel_wgrad2(gys[t], x1s[t], x2s[t], act_x=act_x)
+        refw += gw.double(); refb += gb.double()
+    gw, gb = _native.channel_wgrad_finish(parts, Ci + C2, Co, True)
+    assert rel(gw, refw) < 2e-6 and rel(gb, refb) < 2e-6
+    bw, bb = torch.randn(Co, Ci + C2, generator=g).cuda(), torch.randn(Co, generator=g).cuda()
+    ow, ob = bw.clone(), bb.clone()
+    _native.channel_wgrad_finish(parts[1:], Ci + C2, Co, True, out_w=ow, out_b=ob, accumulate=True)
+    gw1, _ = _native.channel_wgrad_finish(parts[:1], Ci + C2, Co, False)
+    assert rel(ow + gw1, refw + bw.double()) < 2e-6
+    with pytest.raises(RuntimeError):
+        _native.channel_wgrad_finish(parts.flatten()[:-1], Ci + C2, Co, True)          # not a whole number of blocks
+    with pytest.raises(RuntimeError):
+        _native.channel_wgrad2(gys[0], x1s[0], x2s[0], partials_out=parts[0][:-4].contiguous())     # wrong size
+
+
 def test_two_source_argument_errors():
     from uno_amd import _native
     x1, x2 = torch.randn(1, 24, 200).cuda(), torch.randn(1, 8, 200).cuda()

@@ -1,0 +1,69 @@
+"""Bookkeeping of the per-layer spectrum stacks (integral_operators._stack_take and friends: the weight gradient of a layer that a
+roll-out uses several times per graph is batched over its uses, reference ns_train_2d.py:46-68) - host logic only, CPU tensors,
+no kernels: how many slots a layer gets, when a stack is closed, the 2 GiB bound of the per-mode GEMM's operand offsets."""
+import torch
+
+import uno_amd.integral_operators as io
+
+
+def _leaf(ci=4, co=6, m=3):
+    return torch.nn.Parameter(torch.zeros(ci, co, m, m, dtype=torch.cfloat))
+
+
+def test_no_stack_until_a_pass_used_the_layer_twice():
+    w = _leaf()
+    shape = (2, 4, 6, 3)
+    assert io._stack_take(w, shape, w.device, True) is None            # no hint yet
+    w._uno_uses = 1
+    assert io._stack_take(w, shape, w.device, True) is None            # one use per pass: nothing to batch
+    w._uno_uses = 3
+    assert io._stack_take(w, shape, w.device, False) is None           # gradient not wanted
+    st, slot = io._stack_take(w, shape, w.device, True)
+    assert slot == 0
+    assert tuple(st.X.shape) == (3, *shape) and st.X.dtype == torch.complex64
+    assert [io._stack_take(w, shape, w.device, True)[1] for _ in range(2)] == [1, 2]
+    st2, slot2 = io._stack_take(w, shape, w.device, True)              # a fourth use: the stack is full, a second one starts
+    assert st2 is not st and slot2 == 0 and st.n == 3
+
+
+def test_a_stack_closes_when_a_backward_touched_it_or_the_weights_changed():
+    w = _leaf()
+    w._uno_uses = 4
+    shape = (2, 4, 6, 3)
+    st, _ = io._stack_take(w, shape, w.device, True)
+    st.sealed = True                                                   # what the first backward call of a pass does
+    st2, slot = io._stack_take(w, shape, w.device, True)
+    assert st2 is not st and slot == 0
+    with torch.no_grad():
+        w.add_(1.0)                                                    # the optimiser step bumps the version counter
+    st3, slot = io._stack_take(w, shape, w.device, True)
+    assert st3 is not st2 and slot == 0
+    st4, slot = io._stack_take(w, (3, 4, 6, 3), w.device, True)        # another batch size: another stack
+    assert st4 is not st3 and slot == 0
+    w._uno_nostack = True
+    assert io._stack_take(w, shape, w.device, True) is None
+
+
+def test_stacks_stay_below_the_32_bit_operand_offsets_of_the_mode_gemm():
+    w = torch.nn.Parameter(torch.zeros(8, 256, 1, 1, dtype=torch.cfloat))         # Co = 256 output channels decide the bound
+    w._uno_uses = 1000
+    shape = (32, 8, 44, 22)                                            # per slot: 8 * 32 * max(8, 256) * 44 * 22 bytes = 63 MB
+    per_slot = 8 * 32 * 256 * 44 * 22
+    cap = (2 ** 31 - 4096) // per_slot
+    assert 2 <= cap < 1000
+    # (allocating cap slots of the INPUT spectra is 8 * 32 * 8 * 44 * 22 * cap = 65 MB: fine on the host)
+    st, _ = io._stack_take(w, shape, w.device, True)
+    assert st.X.shape[0] == cap
+
+
+def test_switches():
+    w = _leaf()
+    w._uno_uses = 3
+    shape = (2, 4, 6, 3)
+    for name in ("TIME_BATCHED_WGRAD", "INPLACE_PARAM_GRADS"):
+        setattr(io, name, False)
+        try:
+            assert io._stack_take(w, shape, w.device, True) is None
+        finally:
+            setattr(io, name, True)
+    assert io._stack_take(torch.zeros(4, 6, 3, 3, dtype=torch.cfloat), shape, w.device, True) is None     # not a leaf parameter with a hint
