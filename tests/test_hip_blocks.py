@@ -458,6 +458,48 @@ def test_weight_gradient_batched_over_the_uses_of_a_layer():
 
 
 @pytest.mark.gpu
+def test_weight_gradient_batched_over_the_uses_of_a_two_source_block():
+    """The same batching for a block that consumes a skip connection's two tensors (forward_cat): its spectral weight gradient
+    is computed once per pass over the stacked spectra; equal to the use-by-use gradients."""
+    import uno_amd.integral_operators as io
+    from uno_amd.integral_operators import OperatorBlock_2D
+    torch.manual_seed(4)
+    blk = OperatorBlock_2D(32, 16, 24, 24, 5, 4).to(dev())
+    params = list(blk.parameters())
+    a = torch.randn(2, 16, 24, 24, device=dev(), requires_grad=True)
+    b = torch.randn(2, 16, 24, 24, device=dev(), requires_grad=True)
+
+    def loss_fn():
+        h = a
+        for _ in range(4):
+            h = torch.tanh(blk.forward_cat([h, b], 24, 24))
+        return h.square().sum()
+
+    def grads(batched):
+        io.TIME_BATCHED_WGRAD = batched
+        try:
+            for p in params + [a, b]:
+                p.grad = None
+            loss_fn().backward()
+            return [p.grad.clone() for p in params + [a, b]]
+        finally:
+            io.TIME_BATCHED_WGRAD = True
+
+    w1 = blk.conv.weights1
+    for attr in ("_uno_uses", "_uno_stack", "_uno_nostack"):
+        if hasattr(w1, attr):
+            delattr(w1, attr)
+    ref = grads(False)
+    assert w1._uno_uses == 4
+    for rep in range(2):
+        got = grads(True)
+        assert w1._uno_stack.n == 4 and w1._uno_stack.done
+        for u, v in zip(got, ref):
+            ur, vr = (torch.view_as_real(t) if t.is_complex() else t for t in (u, v))
+            assert float((ur - vr).norm()) <= 3e-6 * float(vr.norm()) + 1e-12
+
+
+@pytest.mark.gpu
 def test_inplace_weight_gradients_never_lose_a_contribution_silently():
     """A weight that receives gradients from the library's kernels (in place) AND from a stock torch op in the same backward pass:
     autograd may add the stock gradient out of place and so replace the tensor the kernels keep accumulating into.  The library
