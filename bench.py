@@ -411,6 +411,7 @@ def dp_selfcheck(dev, world, rank):
         # one process on the whole batch, no collectives
         tr_one.grads.zero_()
         lp_loss_rel_sum(m_one(a).reshape(B, -1), u.reshape(B, -1)).backward()
+        tr_one.grads.finish()           # .flat is complete only after collect(): gradients autograd returned as ordinary tensors are copied in
         g_dp, g_one = tr_dp.grads.flat, tr_one.grads.flat
         worst = max(worst, float((g_dp - g_one).norm() / g_one.norm().clamp_min(1e-30)))
         tr_dp.opt.step()

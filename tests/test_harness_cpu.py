@@ -207,6 +207,24 @@ def test_flat_gradients_rebind_after_zero_grad_set_to_none():
     assert torch.allclose(fg.flat[:12].view(3, 4), torch.full((3, 4), 2.0)) and torch.allclose(fg.flat[12:], torch.full((3,), 2.0))
 
 
+def test_flat_gradients_zero_the_segment_of_a_parameter_without_gradient():
+    """zero_() releases the gradients without clearing the flat buffer; a parameter that takes part in one step but not in the
+    next must contribute ZERO to the next sum over ranks, not the previous step's values."""
+    from uno_amd.harness.train import FlatGradients
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(4, 3), torch.nn.Linear(3, 2)
+    fg = FlatGradients(list(a.parameters()) + list(b.parameters()))
+    fg.zero_()
+    b(a(torch.ones(2, 4))).sum().backward()
+    fg.finish()
+    assert fg.flat[15:].abs().sum() > 0                   # b's segment is live
+    fg.zero_()
+    a(torch.ones(2, 4)).sum().backward()                  # b takes no part in this step
+    fg.finish()
+    assert b.weight.grad is None and float(fg.flat[15:].abs().sum()) == 0.0
+    assert torch.allclose(fg.flat[:12].view(3, 4), torch.full((3, 4), 2.0))
+
+
 def test_flat_gradients_odd_real_prefix_before_complex_param():
     """A complex parameter behind an odd number of real entries still gets a valid complex view."""
     from uno_amd.harness.train import FlatGradients

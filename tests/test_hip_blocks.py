@@ -564,3 +564,136 @@ def test_gelu_backward_applied_by_the_consumers_last_kernel(consumer):
     for a, b in zip(res["plain"], res["fused"]):
         ar, br = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
         assert float((ar - br).norm()) <= 2e-5 * float(ar.norm()) + 1e-12
+
+
+def _grads_of(params):
+    return [None if p.grad is None else p.grad.clone() for p in params]
+
+
+def _assert_same_grads(ref, got, tol=2e-6):
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        ar, br = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
+        assert float((ar - br).norm()) <= tol * float(ar.norm()) + 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flat", [False, True])
+def test_inplace_gradients_under_reentrant_checkpoint(flat):
+    """A NESTED backward pass (re-entrant activation checkpointing re-runs the block's forward and back-propagates it inside the
+    outer pass, as its own autograd graph task) must not disturb the outer pass's in-place gradient bookkeeping: the block is used
+    twice in one graph - once under the checkpoint, once outside - so the outer pass holds a partial sum for its weights while the
+    inner pass runs.  Same gradients as the ordinary path (INPLACE_PARAM_GRADS = False), with and without a registered flat buffer."""
+    import torch.utils.checkpoint as cp
+    import uno_amd.integral_operators as io
+    from uno_amd.harness.train import FlatGradients
+    torch.manual_seed(3)
+    blk = io.OperatorBlock_2D(8, 8, 20, 20, 4, 4).to(dev())
+    lin = torch.nn.Linear(8, 8).to(dev())
+    params = list(blk.parameters()) + list(lin.parameters())
+    x = torch.randn(2, 8, 20, 20, device=dev(), requires_grad=True)
+
+    def loss_fn():
+        h = blk(x)                                                                  # outer use: its backward runs LAST
+        h = io.channel_mix(h, lin.weight, lin.bias)
+        h = cp.checkpoint(lambda t: io.channel_mix(blk(t), lin.weight, lin.bias), h, use_reentrant=True)   # nested pass
+        h = blk(h)                                                                  # outer use: its backward runs FIRST
+        return h.square().sum()
+
+    res = {}
+    for mode in (False, True):
+        io.INPLACE_PARAM_GRADS = mode
+        try:
+            for p in params:
+                p.grad = None
+                if hasattr(p, "_uno_grad_buffer"):
+                    del p._uno_grad_buffer
+            x.grad = None
+            fg = FlatGradients(params) if (flat and mode) else None
+            loss_fn().backward()
+            if fg is not None:
+                fg.finish()
+            res[mode] = _grads_of(params) + [x.grad.clone()]
+        finally:
+            io.INPLACE_PARAM_GRADS = True
+            for p in params:
+                if hasattr(p, "_uno_grad_buffer"):
+                    del p._uno_grad_buffer
+    assert not io._PASSES, "a finished backward pass left its state behind"
+    _assert_same_grads(res[False], res[True])
+
+
+@pytest.mark.gpu
+def test_inplace_gradients_with_autograd_grad_inside_a_hook():
+    """torch.autograd.grad called from a tensor hook DURING a backward pass is a second graph task on the same thread.  It uses the
+    same layers; its state must be its own, and the outer pass must go on summing into the tensors it started with."""
+    import uno_amd.integral_operators as io
+    torch.manual_seed(4)
+    blk = io.OperatorBlock_2D(8, 8, 20, 20, 4, 4).to(dev())
+    params = list(blk.parameters())
+    x = torch.randn(2, 8, 20, 20, device=dev(), requires_grad=True)
+    z = torch.randn(2, 8, 20, 20, device=dev(), requires_grad=True)
+    seen = []
+
+    def hook(g):
+        # an independent little graph through the same block, differentiated with respect to its input only
+        (gz,) = torch.autograd.grad(blk(z).sin().sum(), z)
+        seen.append(gz)
+        return g
+
+    def loss_fn():
+        h = blk(x)
+        h.register_hook(hook)
+        h = blk(blk(h))
+        return h.square().sum()
+
+    res = {}
+    for mode in (False, True):
+        io.INPLACE_PARAM_GRADS = mode
+        try:
+            for p in params:
+                p.grad = None
+            x.grad = None
+            seen.clear()
+            loss_fn().backward()
+            res[mode] = _grads_of(params) + [x.grad.clone(), seen[0].clone()]
+        finally:
+            io.INPLACE_PARAM_GRADS = True
+    assert not io._PASSES
+    _assert_same_grads(res[False], res[True])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fallback", ["three_sources", "three_source_projection"])
+def test_join_is_voided_when_a_consumer_cannot_defer(fallback):
+    """out_join / defer_grad with a second consumer that falls back to the stock-op path (three sources cannot be consumed in place;
+    a projection with two output channels has no fused form): that consumer's gradient reaches the producer through autograd
+    WITHOUT gelu'(pre), so the join's owner must not apply the factor to its own share either - the producer applies it to the
+    sum."""
+    from uno_amd.integral_operators import GradJoin, OperatorBlock_2D, channel_mix_cat
+    torch.manual_seed(10)
+    B, C, S = 2, 64, 24
+    prod = OperatorBlock_2D(C, C, S, S, 4, 4).to(dev())
+    cons = OperatorBlock_2D(C, 32, S, S, 3, 3, Normalize=True).to(dev())
+    other = OperatorBlock_2D(2 * C, 32, 36, 36, 4, 4).to(dev())
+    lin = torch.nn.Linear(2 * C, 16).to(dev())
+    x0 = torch.randn(B, C, S, S, device=dev())
+    z0 = torch.randn(B, C, S, S, device=dev())
+    res = {}
+    for mode in ("plain", "joined"):
+        x = x0.clone().requires_grad_(True)
+        for m in (prod, cons, other, lin):
+            m.zero_grad(set_to_none=True)
+        j = GradJoin() if mode == "joined" else None
+        a = prod(x, S, S, out_join=j)
+        y = cons(a, S, S, join=j)
+        if fallback == "three_sources":
+            second = other.forward_cat([z0[:, :32], z0[:, 32:], a], 36, 36, defer_grad=j)
+        else:
+            second = channel_mix_cat([z0, a, z0[:, :0]], lin.weight, lin.bias, defer_grad=j)       # three sources: stock cat + one-source kernel
+        (y.square().sum() + second.sin().sum()).backward()
+        res[mode] = [x.grad.clone()] + [p.grad.clone() for m in (prod, cons, other, lin) for p in m.parameters() if p.grad is not None]
+    _assert_same_grads(res["plain"], res["joined"], tol=2e-5)

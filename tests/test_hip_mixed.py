@@ -122,3 +122,30 @@ def test_mixed_precision_layer_with_default_modes_widens_instead_of_raising():
     assert out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
     out.float().sum().backward()
     assert blk.conv.weights1.grad is not None and torch.isfinite(torch.view_as_real(blk.conv.weights1.grad)).all()
+
+
+def test_half_weight_copy_is_recorded_in_a_captured_graph():
+    """The float16 (re, im) copy of the complex64 master weights is cached per parameter version - but while a HIP graph is being
+    captured the conversion must be part of the graph: the optimiser updates the master weights BETWEEN replays (eagerly), and a copy
+    found in the cache at capture time would be frozen into every replay."""
+    from uno_amd.integral_operators import SpectralConv2d_Uno, enable_mixed_precision
+    torch.manual_seed(0)
+    layer = enable_mixed_precision(SpectralConv2d_Uno(8, 8, 24, 24, 5, 5).to(dev()))
+    x = torch.randn(2, 8, 24, 24, device=dev()).bfloat16()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        layer(x)                                        # eager warm-up: fills the per-parameter cache
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        y = layer(x)
+    with torch.no_grad():
+        layer.weights1.mul_(-1.5)                       # what an optimiser step does: in-place update of the master weights
+        layer.weights2.add_(0.25)
+    graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = layer(x)
+    assert torch.equal(y, want), "the replay read a stale half-precision weight copy"

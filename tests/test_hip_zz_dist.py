@@ -139,3 +139,35 @@ def test_two_ranks_rccl_equal_single_process(tmp_path):
         if r.is_complex():
             r, g = torch.view_as_real(r), torch.view_as_real(g)
         assert float((r - g).norm()) <= 2e-4 * float(r.norm()) + 1e-12, k
+
+
+def _bench_selfcheck_worker(rank, world, port, out_path):
+    import sys
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec = bench.dp_selfcheck(dev, world, rank)      # raises SystemExit on a mismatch
+        if rank == 0:
+            torch.save(rec, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_data_parallel_selfcheck_passes_with_two_ranks(tmp_path):
+    """bench.py refuses to time anything with N > 1 ranks before its own sharded-vs-whole-batch gradient comparison passes; run that
+    comparison here with two ranks (gloo, sharing the one GPU) so that a broken check cannot wait for the first 8-GPU run to be
+    found (the one-process side read its flat buffer before collect())."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_path = str(tmp_path / "selfcheck.pt")
+    mp.spawn(_bench_selfcheck_worker, args=(2, port, out_path), nprocs=2, join=True)
+    rec = torch.load(out_path)
+    assert rec["ranks"] == 2 and rec["buckets"] > 3 and rec["max_rel_grad_diff_over_2_steps"] < 2e-4

@@ -90,7 +90,8 @@ class FlatGradients:
         self._t_arm = 0.0
 
     def zero_(self):
-        """Start of a step: every .grad is released (None).  The backward pass then writes each gradient ONCE into its view of the
+        """Start of a step: every .grad is released (None).  `.flat` is NOT cleared here: it is valid only after finish() / collect()
+        of the pass that follows (which also zero the segments of parameters that received no gradient).  The backward pass then writes each gradient ONCE into its view of the
         flat buffer - the library's weight-gradient kernels write there directly and autograd adopts an alias of the view as
         .grad (no zero fill, no `.grad +=` pass); gradients that arrive as ordinary tensors (a few small ones: normalisation
         affines, the final projection) are copied in by collect()."""
@@ -103,7 +104,10 @@ class FlatGradients:
         pairs = zip(self.params, self.views) if only is None else ((self.params[only], self.views[only]),)
         for p, view in pairs:
             g = p.grad
-            if g is not None and g.data_ptr() != view.data_ptr():
+            if g is None:
+                if only is None:            # end of a pass: a parameter that took no part in it contributes ZERO to the sum over ranks
+                    view.zero_()            # (zero_() does not clear the buffer, so its segment still holds an earlier step's values)
+            elif g.data_ptr() != view.data_ptr():
                 view.copy_(g)
                 p.grad = view.view(view.shape)
 

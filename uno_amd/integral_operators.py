@@ -23,6 +23,8 @@ layers (they are not part of the spectral path and the CPU-side harness tests us
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -63,15 +65,20 @@ def _half_weights(w1, w2):
     of a parameter is kept on it and re-made only when the parameter changed (its version counter moves with every in-place
     update - the optimiser step): repeated forward passes between updates (evaluation, roll-outs) convert nothing."""
     out = []
+    # while a HIP graph is being captured the conversion must be PART of the graph: the optimiser updates the master weights between
+    # replays (harness.GraphedStep runs it eagerly), and a copy made at warm-up and found in the cache would never be re-made - the
+    # replays would read frozen weights.  The captured conversion re-reads the parameter on every replay.
+    capturing = w1.is_cuda and torch.cuda.is_current_stream_capturing()
     with torch.no_grad():
         for w in (w1, w2):
-            cached = getattr(w, "_uno_half", None)
+            cached = None if capturing else getattr(w, "_uno_half", None)
             if cached is None or cached[0] != w._version or cached[1].device != w.device or cached[2] != w.data_ptr():
                 cached = (w._version, torch.view_as_real(w.detach()).half().contiguous(), w.data_ptr())
-                try:
-                    w._uno_half = cached
-                except (AttributeError, RuntimeError):
-                    pass
+                if not capturing:
+                    try:
+                        w._uno_half = cached
+                    except (AttributeError, RuntimeError):
+                        pass
             out.append(cached[1])
     return out[0], out[1]
 
@@ -172,10 +179,13 @@ def channel_mix(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
 #     node): the kernel adds (beta = 1) into that same tensor and the backward returns None for the parameter.
 # A parameter that already HAS a .grad when the pass starts (accumulation across passes) takes the ordinary path.
 INPLACE_PARAM_GRADS = True
-_PASS = {"id": None, "acc": {}, "stacks": {}, "uses": {}}
-# per backward pass (autograd graph task):  acc: id(parameter) -> (tensor its gradient is being summed in, parameter, [contributions]);
-# stacks: id(stack) -> (stack, weight leaves, weight shape, [slots whose gradient spectrum arrived in this pass]);
-# uses: id(weights1 leaf) -> [leaf, spectral-layer backward calls of this pass that did NOT go through a stack]
+# State of the backward passes in flight, keyed by autograd's graph-task id (a nested pass - re-entrant activation checkpointing,
+# torch.autograd.grad inside a hook - is its own task with its own state; the outer pass finds its state untouched when it resumes):
+#   acc:    id(parameter) -> [tensor its gradient is being summed in, parameter, contributions so far, touched by a nested pass]
+#   stacks: id(stack) -> (stack, weight leaves, weight shape, [slots whose gradient spectrum arrived in this pass])
+#   uses:   id(weights1 leaf) -> [leaf, [spectral-layer backward calls of this pass that did NOT go through a stack]]
+_PASSES = {}
+_PASSES_LOCK = threading.Lock()
 
 
 def _pass_state():
@@ -183,44 +193,65 @@ def _pass_state():
     tid = torch._C._current_graph_task_id()
     if tid < 0:
         return None
-    if _PASS["id"] != tid:
-        _PASS.update(id=tid, acc={}, stacks={}, uses={})
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass)     # drop the references when this pass completes
-    return _PASS
+    ps = _PASSES.get(tid)
+    if ps is None:
+        with _PASSES_LOCK:
+            ps = _PASSES.get(tid)
+            if ps is None:
+                ps = _PASSES[tid] = {"id": tid, "acc": {}, "stacks": {}, "uses": {}}
+                # final callbacks belong to the graph task that is current when they are queued: this one runs when THIS pass completes
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_pass(tid))
+    return ps
 
 
-def _end_of_pass():
+def _end_of_pass(tid):
     """End of a backward pass (engine callback: every node, AccumulateGrad included, has run).  A parameter that received SEVERAL
     contributions in place must now have a .grad that aliases the tensor they were summed in; if it does not, autograd replaced
     that tensor on the way (a gradient for the same parameter from a path outside this library was added out of place) and the
     later in-place contributions would be missing - fail loudly instead of training on a wrong gradient.
     Spectral layers: remember how often each was used in this pass (the next forward passes stack that many spectra, see
     _SpectrumStack), and finish the stacks of which only a part of the uses was back-propagated."""
-    acc, stacks, uses = _PASS["acc"], _PASS["stacks"], _PASS["uses"]
-    _PASS.update(id=None, acc={}, stacks={}, uses={})
+    with _PASSES_LOCK:
+        ps = _PASSES.pop(tid, None)
+    if ps is None:
+        return
+    acc, stacks, uses = ps["acc"], ps["stacks"], ps["uses"]
     for leaf, count in uses.values():
         if not getattr(leaf, "_uno_nostack", False):
             leaf._uno_uses = count[0]
     for st, leaves, wshape, slots in stacks.values():
         _stack_flush_partial(st, leaves, wshape, slots)
-    for t, param, count in acc.values():
-        if count[0] > 1 and param.grad is not None and param.grad.data_ptr() != t.data_ptr():
+    for t, param, count, nested in acc.values():
+        # nested: a pass that ran INSIDE this one gave the parameter a .grad of its own before this pass's AccumulateGrad ran; the
+        # tensor summed here was then added to that .grad as a whole (complete: AccumulateGrad runs after every contribution)
+        if count[0] > 1 and not nested[0] and param.grad is not None and param.grad.data_ptr() != t.data_ptr():
             raise RuntimeError("uno_amd: a parameter's gradient was accumulated in place by the library's kernels, but autograd also "
                                "received gradients for it from other operations and replaced the buffer; set "
                                "uno_amd.integral_operators.INPLACE_PARAM_GRADS = False for this model")
 
 
-def _grad_plan(p):
+def _grad_plan(p, ps):
     """('acc', tensor): later contribution of this pass | ('new', registered buffer or None): first contribution | None: ordinary path"""
     if not INPLACE_PARAM_GRADS or not isinstance(p, torch.Tensor) or not p.is_leaf or not p.requires_grad or not p.is_cuda:
         return None
-    if _pass_state() is None:
+    if ps is None:
         return None
-    acc = _PASS["acc"].get(id(p))
+    acc = ps["acc"].get(id(p))
     if acc is not None:
         return "acc", acc[0]
     if p.grad is not None:
         return None
+    if len(_PASSES) > 1:
+        # another pass is in flight (this one is nested in it, or the other way round): if it is summing this parameter's gradient
+        # in place, its tensor - possibly the registered buffer - must not be overwritten by a beta = 0 write from here
+        busy = False
+        for other in list(_PASSES.values()):
+            rec = other["acc"].get(id(p)) if other is not ps else None
+            if rec is not None:
+                rec[3][0] = True
+                busy = True
+        if busy:
+            return None
     buf = getattr(p, "_uno_grad_buffer", None)
     if buf is not None and (buf.shape != p.shape or buf.dtype != p.dtype or buf.device != p.device or not buf.is_contiguous()):
         buf = None
@@ -230,17 +261,18 @@ def _grad_plan(p):
 def _grad_targets(params):
     """Targets of the parameters ONE kernel call writes together: all or nothing, one accumulate flag.
     -> list of (destination tensor, accumulate flag, value to return to autograd) or None"""
-    plans = [_grad_plan(p) for p in params]
+    ps = _pass_state()
+    plans = [_grad_plan(p, ps) for p in params]
     if any(pl is None for pl in plans) or len({pl[0] for pl in plans}) != 1:
         return None
     if plans[0][0] == "acc":
         for p in params:
-            _PASS["acc"][id(p)][2][0] += 1
+            ps["acc"][id(p)][2][0] += 1
         return [(pl[1], True, None) for pl in plans]
     out = []
     for p, pl in zip(params, plans):
         buf = pl[1] if pl[1] is not None else torch.empty(p.shape, dtype=p.dtype, device=p.device)
-        _PASS["acc"][id(p)] = (buf, p, [1])        # (tensor the gradient is summed in, parameter, contributions so far)
+        ps["acc"][id(p)] = (buf, p, [1], [False])       # (tensor the gradient is summed in, parameter, contributions so far, nested)
         out.append((buf, False, buf.view(buf.shape)))
     return out
 
@@ -516,6 +548,21 @@ class GradJoin:
         self.owner = False
         self.spectra, self.pending = [], []
 
+    def void(self):
+        """A consumer or producer that was handed this join cannot honour it (it runs a stock-op path): the fused GELU derivative is
+        off for this pass - the producer block applies gelu'(pre) itself to the SUM of the gradients autograd delivers, which is
+        correct whatever path each consumer took."""
+        self.pre = None
+        self.dgelu_applied = False
+
+    def late(self, g):
+        """Gradient contribution of a consumer whose backward runs AFTER the owner's (graph order did not put it first, so it could
+        not defer): when the owner has already multiplied its result by gelu'(pre) - the producer will then skip its own GELU
+        backward - this contribution needs the factor as well."""
+        if g is not None and self.dgelu_applied and self.pre is not None:
+            g = torch.ops.aten.gelu_backward(g.contiguous(), self.pre.view(g.shape))
+        return g
+
     def merge(self, gX, grid):
         """own gradient spectrum (B, C, 2 m1, m2) + the deferred ones, embedded by frequency into the largest mode box"""
         if not self.spectra:
@@ -638,6 +685,8 @@ class _ChannelMixCatFn(torch.autograd.Function):
             g1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=x1 if ctx.gelu_first else None)
         elif ctx.needs_input_grad[1]:
             g2 = _native.channel_mix(gy, w[:, C1:].contiguous(), None, transpose_w=True)
+        if ctx.defer is not None and g2 is not None:        # the owner's backward came first after all
+            g2 = ctx.defer.late(g2)
         gw, gb = _wgrad_into(ctx.leaves, gy, x1, x2, ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3], act_x=ctx.gelu_first)
         return g1, g2, gw, gb
 
@@ -698,6 +747,8 @@ def channel_mix_cat(xs, weight: torch.Tensor, bias: torch.Tensor | None, gelu_fi
                                    defer_grad, tuple(x2.shape[2:]), (weight, bias))
         return y.view(B, w.shape[0], *x1.shape[2:])
     xs = list(xs)
+    if defer_grad is not None:
+        defer_grad.void()
     if gelu_first:
         xs[0] = F.gelu(xs[0])
     return channel_mix(torch.cat(xs, dim=1), weight, bias)
@@ -1093,6 +1144,8 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
             gcw, gcb = _wgrad_into((lcw, lcb), g_src, a1.view(B, C1, -1), a2.view(B, C2, -1), ctx.needs_input_grad[4],
                                    has_bias and ctx.needs_input_grad[5])
             gcw = None if gcw is None else gcw.view(cw_shape)
+        if ctx.defer is not None and gx2 is not None:       # the owner's backward came first after all
+            gx2 = ctx.defer.late(gx2)
         return gx1, gx2, gw1, gw2, gcw, gcb, None, None, None, None
 
 
@@ -1232,6 +1285,8 @@ class OperatorBlock_2D(nn.Module):
         GradJoin and _OperatorBlock2dFn."""
         if self.non_lin and not self.normalize:
             return self._branches(x, dim1, dim2, gelu=True, join=join, out_join=out_join)
+        if out_join is not None:            # no GELU straight after the sum: this block leaves no pre-activation tensor to a join
+            out_join.void()
         out = self._branches(x, dim1, dim2, join=join)
         if self.normalize:
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
@@ -1252,6 +1307,8 @@ class OperatorBlock_2D(nn.Module):
                  and xs[0].shape[1] + xs[1].shape[1] == conv.in_channels and cdims == (d1, d2)
                  and w.conv.weight.dtype == torch.float32)
         if not fused:
+            if defer_grad is not None:      # xs[1]'s gradient reaches its producer through autograd, without the join's gelu' factor
+                defer_grad.void()
             if defer_gelu:
                 return self._branches(torch.cat(xs, dim=1), dim1, dim2)
             return self.forward(torch.cat(xs, dim=1), dim1, dim2)
@@ -1276,6 +1333,9 @@ class OperatorBlock_2D(nn.Module):
         fused = (self._takes(x) and (conv.dim1, conv.dim2) == (d1, d2)
                  and x.shape[1] == conv.in_channels and w.conv.weight.dtype == torch.float32)
         if not fused:               # CPU tensors raise inside the spectral layer; mismatched grids raise at the sum
+            for j in (join, out_join):      # stock-op path: nothing here completes a joined gradient or leaves a pre-activation sum
+                if j is not None:
+                    j.void()
             out = conv(x) + w(x, d1, d2)
             return F.gelu(out) if gelu else out
         return _OperatorBlock2dFn.apply(x, conv.weights1, conv.weights2, w.conv.weight, w.conv.bias, int(d1), int(d2),
