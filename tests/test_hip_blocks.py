@@ -640,7 +640,8 @@ def test_inplace_gradients_with_autograd_grad_inside_a_hook():
 
     def hook(g):
         # an independent little graph through the same block, differentiated with respect to its input only
-        (gz,) = torch.autograd.grad(blk(z).sin().sum(), z)
+        with torch.enable_grad():                       # hooks run with grad mode off
+            (gz,) = torch.autograd.grad(blk(z).sin().sum(), z)
         seen.append(gz)
         return g
 

@@ -113,7 +113,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     if (n_img == 0) return 0;
     Dft2dParams p;
     p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
-    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0; p.rowfreq = nullptr; p.nw = 1;
+    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0; p.rowfreq = nullptr; p.nw = 1; p.exp = 0;
     if (sp_group <= 0) { sp_group = n_img; sp_stride = 0; sp_offset = 0; }          // plain layout: spectrum i of image i
     if (sp_offset < 0 || sp_stride < sp_offset + sp_group || n_img % sp_group) {
         if (!(sp_stride == 0 && sp_offset == 0 && sp_group == n_img)) {
@@ -130,6 +130,8 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     // many small images (3-D planes, coarse 2-D levels): plane-batched kernels (dft2d_plane.hip)
     if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
         return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);
+    // bfloat16 images: row stage on the bf16 MFMA (dft2d_b16.hip)
+    if (dft2d_b16_applies(p)) return inverse ? launch_dft2d_inv_b16(p, s) : launch_dft2d_fwd_b16(p, s);
     return inverse ? launch_dft2d_inv(p, s) : launch_dft2d_fwd(p, s);
 }
 
@@ -641,7 +643,7 @@ int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, in
     float* Z2 = Z1 + 2LL * n_vol * D1 * C;                        // (n_vol * M1, J2, m3) c64
     float* S = Z2 + 2LL * n_vol * M1 * C;                         // (n_vol, 4, J1/2, J2/2, m3) c64
     Dft2dParams p;
-    p.n_img = n_vol * D1; p.H = D2; p.W = D3; p.m1 = J2 / 2; p.m2 = m3; p.scale = 1.0f; p.herm = herm_in ? 1 : 0; p.mask = 0; p.bf16 = 0; p.nw = 1;
+    p.n_img = n_vol * D1; p.H = D2; p.W = D3; p.m1 = J2 / 2; p.m2 = m3; p.scale = 1.0f; p.herm = herm_in ? 1 : 0; p.mask = 0; p.bf16 = 0; p.nw = 1; p.exp = 0;
     p.sp_group = p.n_img; p.sp_stride = 0; p.sp_offset = 0;
     p.in = x; p.out = Z1; p.rowfreq = f2_in;
     p.twH = twiddle_table(D2); p.twW = twiddle_table(D3);

@@ -143,6 +143,7 @@ struct Dft2dParams {
     int bf16;               // 1: the images (forward input / inverse output) are bfloat16; spectra stay complex64
     const int* rowfreq;     // optional (plane-batched kernels only): frequency of spectrum row j, j < 2*m1, instead of the corner rule
     int nw;                 // set by the K1 / K3 launchers: waves per image (a workgroup holds blockDim / (64 nw) images)
+    int exp;                // development: knock-out switches of the bf16-MFMA kernels (dft2d_b16.hip), 0 in production
 };
 
 __device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {
@@ -218,6 +219,9 @@ int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
 bool dft2d_fwd_plane_applies(const Dft2dParams& p);      // dft2d_plane.hip: many small images
 bool dft2d_inv_plane_applies(const Dft2dParams& p);
+bool dft2d_b16_applies(const Dft2dParams& p);           // dft2d_b16.hip: bfloat16 images, row stage on the bf16 MFMA
+int launch_dft2d_fwd_b16(const Dft2dParams& p, hipStream_t s);
+int launch_dft2d_inv_b16(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_fwd_plane(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv_plane(const Dft2dParams& p, hipStream_t s);
 bool vol3d_fwd_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3);      // dft3d_volume.hip
