@@ -44,6 +44,30 @@ if "model" in what:
     from uno_amd.harness.mixed import c5_mixed_model_bench
     r = c5_mixed_model_bench(dev)
     print("C5 mixed model:", round(r["ms_per_step"], 2), "ms/step", round(r["peak_mem_GiB"], 2), "GiB")
+    if "prof" in what:
+        from uno_amd.harness import UNO_9, synthetic_darcy_batch
+        from uno_amd.harness.mixed import MixedDarcyTrainer
+        for cls_name in ("mixed", "f32"):
+            torch.manual_seed(0)
+            model = UNO_9(3, 64, pad=5).to(dev)
+            from uno_amd.harness import DarcyTrainer
+            tr = (MixedDarcyTrainer if cls_name == "mixed" else DarcyTrainer)(model, lr=1e-3, weight_decay=1e-3)
+            a, u = synthetic_darcy_batch(4, 1024, 1234, dev)
+            for _ in range(2):
+                tr.step(a, u)
+            torch.cuda.synchronize()
+            _native.profile_begin(4096)
+            tr.step(a, u)
+            torch.cuda.synchronize()
+            rec = _native.profile_end()
+            agg = {}
+            for k, ms, by in rec:
+                e = agg.setdefault(k, [0, 0.0, 0.0]); e[0] += 1; e[1] += ms; e[2] += by
+            tot = sum(v[1] for v in agg.values())
+            print(f"--- {cls_name}: {len(rec)} launches, sum of kernel times {tot:.2f} ms")
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:18]:
+                print(f"   {k:58s} n={v[0]:3d} {v[1]:7.3f} ms  {v[2] / max(v[1], 1e-9) / 1e9:7.2f} TB/s")
+            del tr, model
     if "f32" in what:
         from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
         torch.manual_seed(0)
