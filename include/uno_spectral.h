@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 6
+#define UNO_SPECTRAL_ABI_VERSION 7
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -254,6 +254,14 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
                         const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int step, void* stream);
 
+/* The same with the step count kept ON THE DEVICE (ABI 7), so that the update can be captured in a HIP graph and replayed:
+ * `step_counter` (one int32, zero before the first step) is advanced by one and the bias corrections lr / (1 - beta1^t),
+ * 1 / sqrt(1 - beta2^t) are evaluated in double by a one-thread kernel into `scalars` (two floats of device scratch owned by the
+ * caller), which the update kernel reads instead of kernel arguments.  Same arithmetic as uno_adam_step_multi with step = t. */
+int uno_adam_step_multi_dev(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                            const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, int* step_counter, float* scalars, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Mixed precision (BASELINE.json configs[4]: bf16 activations, half-precision weight storage, f32 accumulation).
  * The reference has no behaviour here (integral_operators.py:187 raises on bfloat16 input); the contract is "the float32
@@ -298,6 +306,17 @@ int uno_instnorm_forward_bf16(const void* x, const float* gamma, const float* be
 int uno_instnorm_backward_bf16(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, void* gx, float* s1, float* s2, long long rows, int C, long long N,
                                int gelu, void* stream);
+
+/* Scratch for the any-mode transforms (ABI 7).  Mode counts beyond the MFMA kernels' compiled range (modes1 > 40 or modes2 > 48 - the
+ * reference's DEFAULT modes dim1//2 - 1, dim2//2, integral_operators.py:153-158) run two-pass plain-FMA transforms that need
+ *   uno_dft2d_any_ws_bytes(n_img, H, W, m1, m2) = 8 n_img H m2 bytes of device scratch (0 inside the MFMA range)
+ * per transform.  The library allocates nothing itself: the caller registers a device buffer for the calling THREAD with
+ * uno_scratch_provide(ptr, bytes) before a call that may take that form (every uno_dft2d_* / uno_spectral_conv2d_* entry point; the
+ * composite ones run their two transforms one after the other on the caller's stream, so max over the two sizes is enough), and clears it
+ * with uno_scratch_provide(NULL, 0) afterwards.  The buffer must stay valid until the enqueued work has run (stream-ordered allocators:
+ * free it on the same stream).  A call that needs more than was provided fails with -6 and a message naming the size. */
+long long uno_dft2d_any_ws_bytes(int n_img, int H, int W, int m1, int m2);
+int uno_scratch_provide(void* ptr, long long bytes);
 
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.

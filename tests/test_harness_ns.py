@@ -80,19 +80,22 @@ def test_ns3d_gpu_product():
 
 
 @pytest.mark.gpu
-def test_graphed_step_equals_eager_step():
+@pytest.mark.parametrize("capturable", [False, True])
+def test_graphed_step_equals_eager_step(capturable):
     """harness.GraphedStep: forward + loss + backward replayed from a HIP graph give the eager step's loss, gradients and
-    updated parameters bit for bit (every kernel is deterministic), for two different batches through one capture."""
+    updated parameters bit for bit (every kernel is deterministic), for several batches through one capture.  capturable: the
+    optimiser update is INSIDE the graph (step count and bias corrections on the device, reference Adam.py:27-52) - three replays
+    equal three eager steps of the host-counted optimiser bit for bit, and the device counter reads 3."""
     from uno_amd.harness import ComplexAdam, GraphedStep
     dev = torch.device("cuda:0")
-    def make():
+    def make(cap=False):
         torch.manual_seed(5)
         m = UNO(14, 4).to(dev)
-        return m, ComplexAdam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        return m, ComplexAdam(m.parameters(), lr=1e-3, weight_decay=1e-4, capturable=cap)
     g = torch.Generator().manual_seed(9)
-    batches = [(torch.randn(2, 64, 64, 10, generator=g).to(dev), torch.randn(2, 64, 64, 3, generator=g).to(dev)) for _ in range(2)]
+    batches = [(torch.randn(2, 64, 64, 10, generator=g).to(dev), torch.randn(2, 64, 64, 3, generator=g).to(dev)) for _ in range(3)]
     me, oe = make()
-    mg, og = make()
+    mg, og = make(capturable)
     gs = GraphedStep(mg, og, lambda a, b: ns2d_rollout_loss(mg, a, b, T_f=3, step=1), batches[0])
     # the eager model's first backward pass runs the spectral weight gradients use by use and only the later ones batch them over
     # the roll-out (integral_operators.TIME_BATCHED_WGRAD) - the capture's warm-up passes have put the graphed model in that mode
@@ -108,3 +111,7 @@ def test_graphed_step_equals_eager_step():
         for (k, pe), (_, pg) in zip(me.named_parameters(), mg.named_parameters()):
             assert torch.equal(ge[k], pg.grad), k
             assert torch.equal(pe, pg), k
+    assert gs.opt_in_graph == capturable
+    if capturable:
+        p0 = next(iter(mg.parameters()))
+        assert int(og.state[p0]["step"]) == len(batches)

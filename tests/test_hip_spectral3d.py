@@ -257,3 +257,34 @@ def test_3d_any_mode_count_vs_dense_oracle():
         assert rel_err(xd.grad.cpu().numpy(), gx_ref) < 2e-5
         for got, ref in zip(wd, gws_ref):
             assert rel_err(got.grad.cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [((15, 15, 9), (7, 7, 6)), ((8, 64, 40), (8, 48, 30)), ((9, 9, 7), (12, 12, 9))])
+def test_pointwise_op_3d_outside_the_pruned_dft_range_matches_the_reference_sequence(cfg):
+    """pointwise_op_3D for grids the pruned-DFT resampling kernels do not take (odd kept-row counts, (W, T) planes over 1792 elements):
+    `_resample3d_plan` is None and the layer runs the stock rocFFT sequence with the corner copies as one mask multiplication -
+    compared here with the reference's own op sequence (integral_operators.py:439-467) on the host, forward and every gradient
+    (these shapes were skipped by the bench-shape test and compared nowhere)."""
+    from uno_amd.integral_operators import _resample3d_plan, pointwise_op_3D
+    din, dout = cfg
+    dev = torch.device("cuda:0")
+    assert _resample3d_plan(din, dout, dev) is None
+    torch.manual_seed(0)
+    ref = so.OraclePointwise3d(4, 3, *dout)
+    mod = pointwise_op_3D(4, 3, *dout)
+    mod.load_state_dict(ref.state_dict(), strict=True)
+    mod = mod.to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, *din, generator=g)
+    gy = torch.randn(2, 3, *dout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr, *dout)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    y = mod(xd, *dout)
+    y.backward(gy.to(dev))
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 2e-5
+    assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
+    assert rel_err(mod.conv.weight.grad.cpu().numpy(), ref.conv.weight.grad.numpy()) < 2e-5
+    assert rel_err(mod.conv.bias.grad.cpu().numpy(), ref.conv.bias.grad.numpy()) < 2e-5

@@ -19,7 +19,7 @@ if "--no-time-batch" in sys.argv:   # A/B: the spectral weight gradient of the r
 
 
 def run(name, model, closure, samples, steps=5, warmup=2, inputs=()):
-    opt = ComplexAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt = ComplexAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=GRAPH and "--eager-adam" not in sys.argv)
     if GRAPH:
         gs = GraphedStep(model, opt, closure, inputs)
         name += " [HIP graph]"

@@ -1,11 +1,11 @@
-# everything profiles/ holds for round 3, on one box: blocks + step profiles (tools/profile_round.sh), NS-2D / NS-3D kernel
+# everything profiles/ holds for a round, on one box: blocks + step profiles (tools/profile_round.sh), NS-2D / NS-3D kernel
 # statistics, the bench line with the CPU baseline
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tag=${1:-r03}
+tag=${1:-r04}
 bash tools/profile_round.sh $tag > gpurun_out/profile_round_$tag.log 2>&1
-bash tools/prof_ns2d_kernels.sh > gpurun_out/ns2d_stats.txt 2>&1
+bash tools/prof_ns_kernels.sh 2d > gpurun_out/ns2d_stats.txt 2>&1
 cp $(ls gpurun_out/ns2d_prof/*/*kernel_stats.csv | head -1) profiles/${tag}_ns2d_kernel_stats.csv
-bash tools/prof_ns3d_kernels.sh 32 > gpurun_out/ns3d_stats.txt 2>&1
+bash tools/prof_ns_kernels.sh 3d 32 > gpurun_out/ns3d_stats.txt 2>&1
 cp $(ls gpurun_out/ns3d_prof/*/*kernel_stats.csv | head -1) profiles/${tag}_ns3d_w32_kernel_stats.csv
 rm -rf gpurun_out/ns2d_prof gpurun_out/ns3d_prof
 python bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err

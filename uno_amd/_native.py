@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 _lock = threading.Lock()
@@ -24,6 +24,8 @@ _i = C.c_int
 _SIGNATURES = {
     "uno_abi_version": (C.c_int, []),
     "uno_last_error": (C.c_char_p, []),
+    "uno_dft2d_any_ws_bytes": (C.c_longlong, [_i] * 5),
+    "uno_scratch_provide": (C.c_int, [_fp, C.c_longlong]),
     "uno_spectral_conv2d_fwd_ws_bytes": (C.c_longlong, [_i] * 5),
     "uno_spectral_conv2d_bwd_ws_bytes": (C.c_longlong, [_i] * 5),
     "uno_spectral_conv2d_forward": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
@@ -63,6 +65,8 @@ _SIGNATURES = {
     "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
     "uno_adam_step_multi": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
                                       C.POINTER(_i)] + [C.c_double] * 5 + [_i, _fp]),
+    "uno_adam_step_multi_dev": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
+                                          C.POINTER(_i)] + [C.c_double] * 5 + [_fp, _fp, _fp]),
     "uno_spectral_conv2d_forward_mixed": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
     "uno_spectral_conv2d_backward_mixed": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
     "uno_mode_mix_f16w": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
@@ -120,6 +124,30 @@ def _stream(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+class _any_mode_scratch:
+    """Scratch of the any-mode transforms (mode counts beyond the MFMA kernels' range: the reference's DEFAULT modes).  The library
+    allocates nothing: `needs` = (n_img, H, W, m1, m2) of every transform the call may run; the largest requirement is taken from
+    torch's caching allocator (stream-ordered: the block is reused only by later work on this stream), registered for this thread
+    for the duration of the call and cleared afterwards."""
+
+    def __init__(self, device, *needs):
+        L = lib()
+        self.bytes = max((int(L.uno_dft2d_any_ws_bytes(*[int(v) for v in n])) for n in needs), default=0)
+        self.device = device
+        self.buf = None
+
+    def __enter__(self):
+        if self.bytes > 0:
+            self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=self.device)
+            _check(lib().uno_scratch_provide(_ptr(self.buf), self.bytes), "uno_scratch_provide")
+        return self
+
+    def __exit__(self, *exc):
+        if self.bytes > 0:
+            lib().uno_scratch_provide(None, 0)
+        return False
+
+
 def _require(t: torch.Tensor, dtype, name: str):
     if not t.is_cuda:
         raise RuntimeError(f"uno_amd: {name} must live on a HIP device (got {t.device}); the spectral "
@@ -173,8 +201,8 @@ def spectral_conv2d_forward(x, w1, w2, Ho: int, Wo: int, xt_out=None):
                 raise RuntimeError("uno_amd: xtrunc buffer has the wrong shape")
         ws = torch.empty(max(1, L.uno_spectral_conv2d_fwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=x.device)
         fn = L.uno_spectral_conv2d_forward_mixed if wh else (L.uno_spectral_conv2d_forward_bf16 if bf16 else L.uno_spectral_conv2d_forward)
-        rc = fn(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws),
-                                           B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(x))
+        with _any_mode_scratch(x.device, (B * Ci, H, W, m1, m2), (B * Co, Ho, Wo, m1, m2)):
+            rc = fn(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y), _ptr(xt), _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, _stream(x))
     _check(rc, "uno_spectral_conv2d_forward")
     return y, xt
 
@@ -204,10 +232,11 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
             gw2 = torch.empty((Ci, Co, m1, m2), dtype=torch.complex64, device=gy.device) if need_gw else None
         ws = torch.empty(max(1, L.uno_spectral_conv2d_bwd_ws_bytes(B, Ci, Co, m1, m2)), dtype=torch.uint8, device=gy.device)
         null = C.c_void_p(0)
-        rc = L.uno_spectral_conv2d_backward_acc(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2), _ptr(gx) if need_gx else null,
-                                                _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
-                                                _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, 2 if wh else (1 if bf16 else 0),
-                                                1 if accumulate_gw else 0, _stream(gy))
+        with _any_mode_scratch(gy.device, (B * Co, Ho, Wo, m1, m2), (B * Ci, H, W, m1, m2)):
+            rc = L.uno_spectral_conv2d_backward_acc(_ptr(gy), _ptr(xt), _ptr(w1), _ptr(w2), _ptr(gx) if need_gx else null,
+                                                    _ptr(gw1) if need_gw else null, _ptr(gw2) if need_gw else null,
+                                                    _ptr(ws), B, Ci, Co, H, W, Ho, Wo, m1, m2, 2 if wh else (1 if bf16 else 0),
+                                                    1 if accumulate_gw else 0, _stream(gy))
     _check(rc, "uno_spectral_conv2d_backward")
     return gx, gw1, gw2
 
@@ -248,7 +277,8 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
         spec = torch.empty((*lead, 2 * m1, m2), dtype=torch.complex64, device=images.device)
         with torch.cuda.device(images.device):
             fn = lib().uno_dft2d_forward_bf16 if bf16 else lib().uno_dft2d_forward
-            rc = fn(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(images))
+            with _any_mode_scratch(images.device, (n, H, W, m1, m2)):
+                rc = fn(_ptr(images), _ptr(spec), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(images))
         _check(rc, "uno_dft2d_forward")
         return spec
     _require(out, torch.complex64, "out")
@@ -257,8 +287,9 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
         raise RuntimeError("uno_amd: out must be (B, Ctot, 2*m1, m2) with room for the image channels at channel_offset")
     with torch.cuda.device(images.device):
         fn = lib().uno_dft2d_forward_grouped_bf16 if bf16 else lib().uno_dft2d_forward_grouped
-        rc = fn(_ptr(images), _ptr(out), n, H, W, m1, m2, float(scale), int(hermitian_cols),
-                int(mask_overlap), images.shape[1], out.shape[1], int(channel_offset), _stream(images))
+        with _any_mode_scratch(images.device, (n, H, W, m1, m2)):
+            rc = fn(_ptr(images), _ptr(out), n, H, W, m1, m2, float(scale), int(hermitian_cols),
+                    int(mask_overlap), images.shape[1], out.shape[1], int(channel_offset), _stream(images))
     _check(rc, "uno_dft2d_forward_grouped")
     return out
 
@@ -279,7 +310,8 @@ def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True,
         img = torch.empty((*lead, H, W), dtype=dtype, device=spec.device)
         with torch.cuda.device(spec.device):
             fn = lib().uno_dft2d_inverse_bf16 if dtype == torch.bfloat16 else lib().uno_dft2d_inverse
-            rc = fn(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(spec))
+            with _any_mode_scratch(spec.device, (n, H, W, m1, m2)):
+                rc = fn(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap), _stream(spec))
         _check(rc, "uno_dft2d_inverse")
         return img
     if dtype not in (torch.float32, torch.bfloat16):
@@ -290,8 +322,9 @@ def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True,
     img = torch.empty((B, channels, H, W), dtype=dtype, device=spec.device)
     with torch.cuda.device(spec.device):
         fn = lib().uno_dft2d_inverse_grouped_bf16 if dtype == torch.bfloat16 else lib().uno_dft2d_inverse_grouped
-        rc = fn(_ptr(spec), _ptr(img), B * channels, H, W, m1, m2, float(scale), int(hermitian_cols),
-                int(mask_overlap), int(channels), spec.shape[1], int(channel_offset), _stream(spec))
+        with _any_mode_scratch(spec.device, (B * channels, H, W, m1, m2)):
+            rc = fn(_ptr(spec), _ptr(img), B * channels, H, W, m1, m2, float(scale), int(hermitian_cols),
+                    int(mask_overlap), int(channels), spec.shape[1], int(channel_offset), _stream(spec))
     _check(rc, "uno_dft2d_inverse_grouped")
     return img
 
@@ -360,8 +393,10 @@ def spectral_conv3d_forward(x, ws_, Ho: int, Wo: int, To: int):
         xt = torch.empty((B, Ci, 4, m1, m2, m3), dtype=torch.complex64, device=x.device)
         scratch = torch.empty(max(1, L.uno_spectral_conv3d_fwd_ws_bytes(B, Ci, Co, H, Ho, m1, m2, m3)), dtype=torch.uint8,
                               device=x.device)
-        rc = L.uno_spectral_conv3d_forward(_ptr(x), _ptr_array(ws_), _ptr(y), _ptr(xt), _ptr(scratch), B, Ci, Co,
-                                           H, W, T, Ho, Wo, To, m1, m2, m3, _stream(x))
+        # (the (W, T) planes go through the 2-D transforms with modes (m2, m3): beyond the MFMA range they take the any-mode form)
+        with _any_mode_scratch(x.device, (B * Ci * H, W, T, m2, m3), (B * Co * Ho, Wo, To, m2, m3)):
+            rc = L.uno_spectral_conv3d_forward(_ptr(x), _ptr_array(ws_), _ptr(y), _ptr(xt), _ptr(scratch), B, Ci, Co,
+                                               H, W, T, Ho, Wo, To, m1, m2, m3, _stream(x))
     _check(rc, "uno_spectral_conv3d_forward")
     return y, xt
 
@@ -381,9 +416,10 @@ def spectral_conv3d_backward(gy, xt, ws_, H: int, W: int, T: int, need_gx=True, 
         gws = [torch.empty_like(w) for w in ws_] if need_gw else None
         scratch = torch.empty(max(1, L.uno_spectral_conv3d_bwd_ws_bytes(B, Ci, Co, H, Ho, m1, m2, m3)), dtype=torch.uint8,
                               device=gy.device)
-        rc = L.uno_spectral_conv3d_backward(_ptr(gy), _ptr(xt), _ptr_array(ws_), _ptr(gx) if need_gx else C.c_void_p(0),
-                                            _ptr_array(gws) if need_gw else None, _ptr(scratch), B, Ci, Co,
-                                            H, W, T, Ho, Wo, To, m1, m2, m3, _stream(gy))
+        with _any_mode_scratch(gy.device, (B * Co * Ho, Wo, To, m2, m3), (B * Ci * H, W, T, m2, m3)):
+            rc = L.uno_spectral_conv3d_backward(_ptr(gy), _ptr(xt), _ptr_array(ws_), _ptr(gx) if need_gx else C.c_void_p(0),
+                                                _ptr_array(gws) if need_gw else None, _ptr(scratch), B, Ci, Co,
+                                                H, W, T, Ho, Wo, To, m1, m2, m3, _stream(gy))
     _check(rc, "uno_spectral_conv3d_backward")
     return gx, gws
 
@@ -778,6 +814,15 @@ class AdamPlan:
             rc = lib().uno_adam_step_multi(self.n, self.p, self.g, self.m, self.v, self.sizes, self.cplx, lr, beta1, beta2, eps,
                                            weight_decay, int(step), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         _check(rc, "uno_adam_step_multi")
+
+    def step_dev(self, counter, scalars, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
+        """the update with the step count on the device (`counter`: int32 tensor of one element, advanced here; `scalars`: two floats
+        of scratch): capturable in a HIP graph"""
+        with torch.cuda.device(self.device):
+            rc = lib().uno_adam_step_multi_dev(self.n, self.p, self.g, self.m, self.v, self.sizes, self.cplx, lr, beta1, beta2, eps,
+                                               weight_decay, _ptr(counter), _ptr(scalars),
+                                               C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        _check(rc, "uno_adam_step_multi_dev")
 
 
 def profile_begin(max_records: int = 100000):

@@ -86,9 +86,21 @@ struct AdamMultiParams {
     unsigned cplx_mask;
     int n_tensors;
     AdamScalars a;
+    const float* dev_scalars;       // optional: {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} on the device (step count kept on the device)
 };
 
+// Step count on the DEVICE (so that the update can be part of a captured HIP graph: the bias corrections then cannot be kernel
+// arguments, reference Adam.py:27-52 computes them from state['step'] on the host): one thread advances the counter and evaluates
+// the two step-dependent scalars in double, as the host path does.
+__global__ void adam_advance_kernel(int* step, float* scalars, double lr, double beta1, double beta2) {
+    const int t = *step + 1;
+    *step = t;
+    scalars[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
+    scalars[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+}
+
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiParams q) {
+    if (q.dev_scalars) { q.a.step_size = q.dev_scalars[0]; q.a.inv_sqrt_bc2 = q.dev_scalars[1]; }
     int t = 0;
 #pragma unroll 1
     for (int i = 1; i < q.n_tensors; ++i)
@@ -108,13 +120,21 @@ static AdamScalars adam_scalars(double lr, double beta1, double beta2, double ep
     return a;
 }
 
+int launch_adam_advance(int* step, float* scalars, double lr, double beta1, double beta2, hipStream_t s) {
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step, scalars, lr, beta1, beta2);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("adam advance launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
 int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
-                      const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s) {
+                      const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s,
+                      const float* dev_scalars) {
     const AdamScalars a = adam_scalars(lr, beta1, beta2, eps, wd, step);
     int t0 = 0;
     while (t0 < n_tensors) {
         AdamMultiParams q;
-        q.a = a; q.cplx_mask = 0; q.n_tensors = 0;
+        q.a = a; q.cplx_mask = 0; q.n_tensors = 0; q.dev_scalars = dev_scalars;
         unsigned long long blocks = 0;
         double bytes = 0;
         while (t0 < n_tensors && q.n_tensors < ADAM_MAX_TENSORS) {
@@ -148,7 +168,7 @@ int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, flo
 
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s) {
-    return launch_adam_multi(1, &p, &g, &m, &v, &n, &is_complex, lr, beta1, beta2, eps, wd, step, s);
+    return launch_adam_multi(1, &p, &g, &m, &v, &n, &is_complex, lr, beta1, beta2, eps, wd, step, s, nullptr);
 }
 
 }  // namespace uno

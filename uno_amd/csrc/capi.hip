@@ -104,6 +104,10 @@ static int check_modes2d(const char* who, int H, int W, int Ho, int Wo, int m1, 
     return 0;
 }
 
+// caller-provided scratch of the calling thread (uno_scratch_provide): the any-mode transforms' intermediate spectrum
+struct Scratch { void* ptr; size_t bytes; };
+static thread_local Scratch t_scratch = {nullptr, 0};
+
 static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, int W, int m1, int m2, float scale,
                  int herm, int mask, hipStream_t s, int sp_group = 0, int sp_stride = 0, int sp_offset = 0, int bf16 = 0) {
     const char* who = inverse ? "uno_dft2d_inverse" : "uno_dft2d_forward";
@@ -126,7 +130,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
     // mode counts beyond the compiled MFMA range (the reference's default modes, integral_operators.py:153-158): any-mode form
-    if (m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, s);
+    if (m1 > 40 || m2 > 48) return launch_dft2d_generic(p, inverse, t_scratch.ptr, t_scratch.bytes, s);
     // many small images (3-D planes, coarse 2-D levels): plane-batched kernels (dft2d_plane.hip)
     if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
         return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);
@@ -245,6 +249,19 @@ int uno_profile_get(int index, char* name, int name_len, double* ms, double* byt
 }
 
 const char* uno_last_error(void) { return g_err; }
+
+long long uno_dft2d_any_ws_bytes(int n_img, int H, int W, int m1, int m2) {
+    (void)W;
+    if (n_img <= 0 || H <= 0 || m2 <= 0) return 0;
+    return (m1 > 40 || m2 > 48) ? 8LL * n_img * H * m2 : 0;
+}
+
+int uno_scratch_provide(void* ptr, long long bytes) {
+    if (bytes < 0 || (bytes > 0 && !ptr)) { set_error("uno_scratch_provide: bad buffer"); return -1; }
+    t_scratch.ptr = bytes > 0 ? ptr : nullptr;
+    t_scratch.bytes = bytes > 0 ? (size_t)bytes : 0;
+    return 0;
+}
 
 long long uno_spectral_conv2d_fwd_ws_bytes(int B, int Ci, int Co, int m1, int m2) {
     (void)Ci;
@@ -503,6 +520,22 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
     }
     // one launch per 24 tensors (csrc/adam.hip): the tensors' descriptors travel in the kernel arguments
     return launch_adam_multi(n_tensors, p, g, m, v, n, is_complex, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+
+int uno_adam_step_multi_dev(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                            const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, int* step_counter, float* scalars, void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!p || !g || !m || !v || !n || !is_complex)) || !step_counter || !scalars) {
+        set_error("uno_adam_step_multi_dev: bad arguments");
+        return -1;
+    }
+    if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) { set_error("uno_adam_step_multi_dev: bad betas (%g, %g)", beta1, beta2); return -1; }
+    for (int t = 0; t < n_tensors; ++t) {
+        if (n[t] < 0) { set_error("uno_adam_step_multi_dev: tensor %d has n=%lld", t, n[t]); return -1; }
+        if (n[t] > 0 && (!p[t] || !g[t] || !m[t] || !v[t])) { set_error("uno_adam_step_multi_dev: null pointer (tensor %d)", t); return -1; }
+    }
+    if (int rc = launch_adam_advance(step_counter, scalars, lr, beta1, beta2, (hipStream_t)stream)) return rc;
+    return launch_adam_multi(n_tensors, p, g, m, v, n, is_complex, lr, beta1, beta2, eps, weight_decay, 1, (hipStream_t)stream, scalars);
 }
 
 static int gelu_project_forward_impl(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, void* stream) {

@@ -110,13 +110,18 @@ static int check_launch(const char* who) {
     return 0;
 }
 
-int launch_dft2d_generic(const Dft2dParams& p, bool inverse, hipStream_t s) {
+int launch_dft2d_generic(const Dft2dParams& p, bool inverse, void* ws_, size_t ws_bytes, hipStream_t s) {
     if (p.bf16) { set_error("dft2d (any-mode form): bfloat16 images need modes1 <= 40 and modes2 <= 48"); return -2; }
     const size_t lds_rows = (size_t)((p.W + 1) & ~1) * 4 + (size_t)p.W * 8 + (size_t)p.m2 * 8, lds_cols = (size_t)p.H * 8;
     if (lds_rows > 64 * 1024 || lds_cols > 64 * 1024) { set_error("dft2d (any-mode form): grid %dx%d too large", p.H, p.W); return -3; }
-    float2* ws = nullptr;
+    // the intermediate (n_img, H, m2) spectrum lives in the CALLER's scratch (uno_scratch_provide): the library allocates nothing
     const size_t bytes = (size_t)p.n_img * p.H * p.m2 * sizeof(float2);
-    if (hipMallocAsync(reinterpret_cast<void**>(&ws), bytes, s) != hipSuccess) { set_error("dft2d (any-mode form): workspace of %zu bytes", bytes); return -6; }
+    if (!ws_ || ws_bytes < bytes) {
+        set_error("dft2d (any-mode form, modes %d x %d beyond the MFMA kernels' range): needs %zu bytes of scratch, %zu provided - register a "
+                  "device buffer with uno_scratch_provide (uno_dft2d_any_ws_bytes)", p.m1, p.m2, bytes, ws_ ? ws_bytes : (size_t)0);
+        return -6;
+    }
+    float2* ws = static_cast<float2*>(ws_);
     int rc = 0;
     {
         ProfScope prof(inverse ? "uno::dft2d_inv_generic" : "uno::dft2d_fwd_generic",
@@ -130,7 +135,6 @@ int launch_dft2d_generic(const Dft2dParams& p, bool inverse, hipStream_t s) {
         }
         rc = check_launch("dft2d (any-mode form)");
     }
-    (void)hipFreeAsync(ws, s);
     return rc;
 }
 

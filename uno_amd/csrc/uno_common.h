@@ -230,7 +230,7 @@ int launch_dft3d_fwd_volume(const Vol3dParams& p, hipStream_t s);
 int launch_dft3d_inv_volume(const Vol3dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
-int launch_dft2d_generic(const Dft2dParams& p, bool inverse, hipStream_t s);      // dft_generic.hip: any mode count
+int launch_dft2d_generic(const Dft2dParams& p, bool inverse, void* ws, size_t ws_bytes, hipStream_t s);      // dft_generic.hip: any mode count; ws: 8 n_img H m2 bytes
 int launch_cdft_generic(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_resample2d(const void* in, void* out, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
@@ -246,7 +246,9 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s);
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s);
 int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
-                      const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s);
+                      const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s,
+                      const float* dev_scalars = nullptr);
+int launch_adam_advance(int* step, float* scalars, double lr, double beta1, double beta2, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s);
 int launch_gelu_project_fwd(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, hipStream_t s);

@@ -13,11 +13,17 @@ from torch.optim.optimizer import Optimizer
 
 
 class ComplexAdam(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        """capturable: keep the step count of the device parameters ON THE DEVICE (one counter per parameter group, advanced by the
+        update itself), so that step() can be recorded in a HIP graph (harness.GraphedStep) - the bias corrections of the reference
+        (Adam.py:27-52: from state['step']) are then evaluated on the device in double.  All device parameters of a group must take
+        part in every step (they share the counter); state[p]['step'] is that counter tensor."""
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._plans = {}            # per param group: pointer tables of the device tensors (not part of state_dict)
+        self.capturable = bool(capturable)
+        self._dev_counters = {}     # id(group) -> (int32 step counter, float32[2] scalars) on the group's device
 
     def _device_step(self, group, params, step, lr, beta1, beta2, eps, wd):
         """K10 over all device tensors of the group in one native call; the pointer tables are rebuilt only when a
@@ -34,7 +40,11 @@ class ComplexAdam(Optimizer):
             plan = _native.AdamPlan([p.data for p in params], [p.grad for p in params],
                                     [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params])
             self._plans[key] = plan
-        plan.step(step, lr, beta1, beta2, eps, wd)
+        if step is None:            # capturable: the group's device counter
+            ctr, scal = self._dev_counters[id(group)]
+            plan.step_dev(ctr, scal, lr, beta1, beta2, eps, wd)
+        else:
+            plan.step(step, lr, beta1, beta2, eps, wd)
         # the kernel writes the parameters through raw pointers: tell autograd they changed (version counters guard saved tensors
         # and key the half-precision weight copies of the mixed-precision layers)
         torch.autograd.graph.increment_version(params)
@@ -42,6 +52,30 @@ class ComplexAdam(Optimizer):
     @staticmethod
     def _real(t):
         return torch.view_as_real(t) if t.is_complex() else t
+
+    def _init_param_state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(self._real(p))
+            # one real second-moment entry per (possibly complex) parameter entry
+            st["exp_avg_sq"] = torch.zeros(p.shape, dtype=st["exp_avg"].dtype, device=p.device)
+        return st
+
+    def init_state(self):
+        """Allocate every parameter's moments (and, when capturable, the device step counters) NOW instead of at the first step():
+        an allocation + zero fill recorded inside a HIP graph would be replayed with it."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if not p.requires_grad:
+                    continue
+                st = self._init_param_state(p)
+                if self.capturable and p.is_cuda and p.dtype in (torch.float32, torch.complex64):
+                    if id(group) not in self._dev_counters:
+                        self._dev_counters[id(group)] = (torch.zeros(1, dtype=torch.int32, device=p.device),
+                                                         torch.zeros(2, dtype=torch.float32, device=p.device))
+                    if not torch.is_tensor(st["step"]):
+                        st["step"] = self._dev_counters[id(group)][0]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -58,14 +92,17 @@ class ComplexAdam(Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(self._real(p))
-                    # one real second-moment entry per (possibly complex) parameter entry
-                    st["exp_avg_sq"] = torch.zeros(p.shape, dtype=st["exp_avg"].dtype, device=p.device)
+                st = self._init_param_state(p)
+                on_dev = p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous() and p.grad.is_contiguous()
+                if self.capturable and on_dev:
+                    if id(group) not in self._dev_counters:
+                        self._dev_counters[id(group)] = (torch.zeros(1, dtype=torch.int32, device=p.device),
+                                                         torch.zeros(2, dtype=torch.float32, device=p.device))
+                    st["step"] = self._dev_counters[id(group)][0]
+                    devb.setdefault(None, []).append(p)
+                    continue
                 st["step"] += 1
-                if p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous() and p.grad.is_contiguous():
+                if on_dev:
                     devb.setdefault(st["step"], []).append(p)
                 else:
                     host.setdefault(st["step"], []).append(p)

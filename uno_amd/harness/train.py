@@ -200,7 +200,9 @@ def ns3d_loss(model, x, y):
 
 class GraphedStep:
     """Forward + loss + backward of one training step captured ONCE into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm)
-    and replayed per step; the optimiser update stays eager (its bias correction takes the step count as a kernel argument).
+    and replayed per step.  With a capturable optimiser (ComplexAdam(capturable=True): step count on the device, bias corrections
+    evaluated there - reference Adam.py:27-52 takes them from state['step'] on the host) the update is part of the graph too; with
+    any other optimiser it runs eagerly after the replay.
     Single rank only: no gradient all-reduce is issued between the replay and the update (DarcyTrainer is the data-parallel step).
 
     For launch-bound steps: the NS-2D roll-out (reference ns_train_2d.py:46-68) issues ~7400 kernels of 5-40 us per step and
@@ -217,6 +219,9 @@ class GraphedStep:
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs the GPU (HIP graph capture)")
         self.model, self.opt, self.loss_fn = model, opt, loss_fn
+        self.opt_in_graph = bool(getattr(opt, "capturable", False))
+        if self.opt_in_graph:
+            opt.init_state()                            # moments and step counters exist before the capture (nothing to re-zero on replay)
         self.static_in = tuple(t.clone() for t in example_inputs)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -231,12 +236,18 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.static_loss = loss_fn(*self.static_in)
             self.static_loss.backward()
+            if self.opt_in_graph:
+                self.opt.step()
+        self._params = [p for g in opt.param_groups for p in g["params"] if p.requires_grad]
 
     def step(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()                             # gradients are overwritten by the captured backward
-        self.opt.step()
+        if self.opt_in_graph:
+            torch.autograd.graph.increment_version(self._params)       # the replayed update wrote the parameters through raw pointers
+        else:
+            self.opt.step()
         return self.static_loss.detach().clone()        # the graph-owned scalar is overwritten by the next replay
 
 
