@@ -82,6 +82,13 @@ int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, in
                        int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
                        float scale, int herm_in, int herm_out, void* stream);
 
+/* The same, ACCUMULATING into y (y += resampled x) and, with y_act != NULL, writing y_act = gelu(y) in the same pass (ABI 7): the
+ * point-wise branch of OperatorBlock_3D (reference integral_operators.py:506-512: x1_out + x2_out, then F.gelu) lands in the buffer
+ * the spectral branch wrote - neither the sum nor the activation is a separate pass. */
+int uno_fft_resample3d_acc(const float* x, float* y, float* y_act, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
+                           int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
+                           float scale, int herm_in, int herm_out, void* stream);
+
 /* SpectralConv3d_Uno.forward - reference integral_operators.py:385-427
  *   x (B, Ci, H, W, T) f32;  w[0..3] = weights1..4 (Ci, Co, m1, m2, m3) c64 in the reference's corner
  *   order (lo,lo), (hi,lo), (lo,hi), (hi,hi);  y (B, Co, Ho, Wo, To) f32 [out]

@@ -288,3 +288,42 @@ def test_pointwise_op_3d_outside_the_pruned_dft_range_matches_the_reference_sequ
     assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
     assert rel_err(mod.conv.weight.grad.cpu().numpy(), ref.conv.weight.grad.numpy()) < 2e-5
     assert rel_err(mod.conv.bias.grad.cpu().numpy(), ref.conv.bias.grad.numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normalize,non_lin", [(False, True), (True, True), (False, False)])
+@pytest.mark.parametrize("geom", [((16, 16, 10), (12, 12, 16)), ((32, 32, 13), (16, 16, 15)), ((16, 16, 12), (16, 16, 12)), ((24, 24, 9), (36, 36, 14))])
+def test_operator_block_3d_one_buffer_equals_branch_sum(geom, normalize, non_lin):
+    """OperatorBlock_3D in one buffer (_OperatorBlock3dFn: the point-wise branch's last transform accumulates into the spectral branch's
+    output and writes the GELU; the transposed 1x1x1 convolution accumulates into the spectral branch's input gradient) against the
+    same module's two branches run separately and summed by stock ops (reference integral_operators.py:506-512)."""
+    import torch.nn.functional as F
+    from uno_amd import _native
+    from uno_amd.integral_operators import OperatorBlock_3D, _resample3d_plan, instance_norm_gelu
+    din, dout = geom
+    dev = torch.device("cuda:0")
+    assert _resample3d_plan(din, dout, dev) is not None
+    torch.manual_seed(7)
+    blk = OperatorBlock_3D(4, 3, *dout, 4, 4, 3, Normalize=normalize, Non_Lin=non_lin).to(dev)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 4, *din, generator=g).to(dev)
+    gy = torch.randn(2, 3, *dout, generator=g).to(dev)
+    # separate branches
+    xr = x.clone().requires_grad_(True)
+    out = blk.conv(xr, *dout) + blk.w(xr, *dout)
+    out = instance_norm_gelu(out, blk.normalize_layer, non_lin) if normalize else (F.gelu(out) if non_lin else out)
+    out.backward(gy)
+    ref = [xr.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    blk.zero_grad(set_to_none=True)
+    # one buffer
+    xd = x.clone().requires_grad_(True)
+    _native.profile_begin(256)
+    y = blk(xd, *dout)
+    y.backward(gy)
+    names = [r[0] for r in _native.profile_end()]
+    assert any("dft2d_inv_plane_kernel<acc>" in n for n in names), names
+    got = [xd.grad] + [p.grad for p in blk.parameters()]
+    assert rel_err(y.detach().cpu().numpy(), out.detach().cpu().numpy()) < 1e-5
+    for a, b in zip(got, ref):
+        a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7, (a.shape,)

@@ -6,6 +6,9 @@ from uno_amd import _native
 if len(sys.argv) > 1 and sys.argv[1] != "-":
     _native.LIB_PATH = os.path.abspath(sys.argv[1])
 from uno_amd.harness import Uno3D_T20, ComplexAdam, ns3d_loss
+import uno_amd.integral_operators as _io
+if os.environ.get("ONE_BUFFER_3D") == "0":
+    _io.ONE_BUFFER_3D = False
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

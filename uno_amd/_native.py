@@ -34,6 +34,7 @@ _SIGNATURES = {
     "uno_spectral_conv2d_backward_bf16": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
     "uno_fft_resample3d_ws_bytes": (C.c_longlong, [_i] * 6),
     "uno_fft_resample3d": (C.c_int, [_fp] * 3 + [_i] * 8 + [_fp, _fp, _i, _fp, _fp, _i, C.c_float, _i, _i, _fp]),
+    "uno_fft_resample3d_acc": (C.c_int, [_fp] * 4 + [_i] * 8 + [_fp, _fp, _i, _fp, _fp, _i, C.c_float, _i, _i, _fp]),
     "uno_dft2d_forward": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_forward_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
@@ -241,10 +242,11 @@ def spectral_conv2d_backward(gy, xt, w1, w2, H: int, W: int, need_gx=True, need_
     return gx, gw1, gw2
 
 
-def fft_resample3d(x, out_size, f1, f2, m3: int, scale: float, adjoint: bool):
+def fft_resample3d(x, out_size, f1, f2, m3: int, scale: float, adjoint: bool, out=None, act=False):
     """x (..., D1, D2, D3) f32 -> (..., M1, M2, M3): pruned DFT with row frequencies f1[0] / f2[0] (int32 device tensors) along
     axes 1 / 2 and m3 half-spectrum bins, pruned inverse DFT with f1[1] / f2[1]; adjoint=True: Hermitian weights on the
-    forward side instead of the inverse side (the transpose of the operator with sizes and tables swapped)."""
+    forward side instead of the inverse side (the transpose of the operator with sizes and tables swapped).
+    out: ACCUMULATE into this (..., M1, M2, M3) tensor (returned); act: also return gelu(out) written in the same pass -> (out, act)."""
     _require(x, torch.float32, "x")
     *lead, D1, D2, D3 = x.shape
     M1, M2, M3 = (int(v) for v in out_size)
@@ -257,8 +259,18 @@ def fft_resample3d(x, out_size, f1, f2, m3: int, scale: float, adjoint: bool):
     J1, J2 = f1[0].numel(), f2[0].numel()
     L = lib()
     with torch.cuda.device(x.device):
-        y = torch.empty((*lead, M1, M2, M3), dtype=torch.float32, device=x.device)
         ws = torch.empty(max(1, L.uno_fft_resample3d_ws_bytes(n, D1, M1, J1, J2, int(m3))), dtype=torch.uint8, device=x.device)
+        if out is not None:
+            _require(out, torch.float32, "out")
+            if tuple(out.shape) != (*lead, M1, M2, M3) or not out.is_contiguous():
+                raise RuntimeError(f"uno_amd: out must be a contiguous {(*lead, M1, M2, M3)} tensor")
+            ya = torch.empty_like(out) if act else None
+            rc = L.uno_fft_resample3d_acc(_ptr(x), _ptr(out), _ptr(ya) if act else C.c_void_p(0), _ptr(ws), n, D1, D2, D3, M1, M2, M3,
+                                          J1, _ptr(f1[0]), _ptr(f1[1]), J2, _ptr(f2[0]), _ptr(f2[1]), int(m3), float(scale),
+                                          int(adjoint), int(not adjoint), _stream(x))
+            _check(rc, "uno_fft_resample3d_acc")
+            return (out, ya) if act else out
+        y = torch.empty((*lead, M1, M2, M3), dtype=torch.float32, device=x.device)
         rc = L.uno_fft_resample3d(_ptr(x), _ptr(y), _ptr(ws), n, D1, D2, D3, M1, M2, M3, J1, _ptr(f1[0]), _ptr(f1[1]), J2,
                                   _ptr(f2[0]), _ptr(f2[1]), int(m3), float(scale), int(adjoint), int(not adjoint), _stream(x))
     _check(rc, "uno_fft_resample3d")

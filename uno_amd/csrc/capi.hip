@@ -117,7 +117,7 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     if (n_img == 0) return 0;
     Dft2dParams p;
     p.in = in; p.out = out; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
-    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0; p.rowfreq = nullptr; p.nw = 1; p.exp = 0;
+    p.scale = scale; p.herm = herm ? 1 : 0; p.mask = mask ? 1 : 0; p.bf16 = bf16 ? 1 : 0; p.rowfreq = nullptr; p.nw = 1; p.exp = 0; p.accumulate = 0; p.act_out = nullptr;
     if (sp_group <= 0) { sp_group = n_img; sp_stride = 0; sp_offset = 0; }          // plain layout: spectrum i of image i
     if (sp_offset < 0 || sp_stride < sp_offset + sp_group || n_img % sp_group) {
         if (!(sp_stride == 0 && sp_offset == 0 && sp_group == n_img)) {
@@ -659,9 +659,9 @@ long long uno_fft_resample3d_ws_bytes(int n_vol, int D1, int M1, int J1, int J2,
     return 8LL * n_vol * ((long long)D1 * C + (long long)M1 * C + (long long)J1 * C);
 }
 
-int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
-                       int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
-                       float scale, int herm_in, int herm_out, void* stream) {
+static int fft_resample3d_impl(const float* x, float* y, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
+                               int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
+                               float scale, int herm_in, int herm_out, int accumulate, float* act_out, void* stream) {
     const char* who = "uno_fft_resample3d";
     if (n_vol < 0 || D1 < 1 || D2 < 1 || D3 < 1 || M1 < 1 || M2 < 1 || M3 < 1) { set_error("%s: bad sizes", who); return -1; }
     if (J1 < 2 || (J1 & 1) || J2 < 2 || (J2 & 1) || J1 > 80 || J2 > 48 || m3 < 1 || m3 > D3 / 2 + 1 || m3 > M3 / 2 + 1) {
@@ -676,7 +676,7 @@ int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, in
     float* Z2 = Z1 + 2LL * n_vol * D1 * C;                        // (n_vol * M1, J2, m3) c64
     float* S = Z2 + 2LL * n_vol * M1 * C;                         // (n_vol, 4, J1/2, J2/2, m3) c64
     Dft2dParams p;
-    p.n_img = n_vol * D1; p.H = D2; p.W = D3; p.m1 = J2 / 2; p.m2 = m3; p.scale = 1.0f; p.herm = herm_in ? 1 : 0; p.mask = 0; p.bf16 = 0; p.nw = 1; p.exp = 0;
+    p.n_img = n_vol * D1; p.H = D2; p.W = D3; p.m1 = J2 / 2; p.m2 = m3; p.scale = 1.0f; p.herm = herm_in ? 1 : 0; p.mask = 0; p.bf16 = 0; p.nw = 1; p.exp = 0; p.accumulate = 0; p.act_out = nullptr;
     p.sp_group = p.n_img; p.sp_stride = 0; p.sp_offset = 0;
     p.in = x; p.out = Z1; p.rowfreq = f2_in;
     p.twH = twiddle_table(D2); p.twW = twiddle_table(D3);
@@ -697,7 +697,22 @@ int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, in
     p.twH = twiddle_table(M2); p.twW = twiddle_table(M3);
     if (!p.twH || !p.twW) return -6;
     if (!dft2d_inv_plane_applies(p)) { set_error("%s: output planes %d x %d (%d of them) are outside the plane-batched kernels' range", who, M2, M3, p.n_img); return -2; }
+    p.accumulate = accumulate ? 1 : 0; p.act_out = act_out;
     return launch_dft2d_inv_plane(p, s);
+}
+
+int uno_fft_resample3d(const float* x, float* y, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
+                       int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
+                       float scale, int herm_in, int herm_out, void* stream) {
+    return fft_resample3d_impl(x, y, ws, n_vol, D1, D2, D3, M1, M2, M3, J1, f1_in, f1_out, J2, f2_in, f2_out, m3, scale, herm_in, herm_out,
+                               0, nullptr, stream);
+}
+
+int uno_fft_resample3d_acc(const float* x, float* y, float* y_act, void* ws, int n_vol, int D1, int D2, int D3, int M1, int M2, int M3,
+                           int J1, const int* f1_in, const int* f1_out, int J2, const int* f2_in, const int* f2_out, int m3,
+                           float scale, int herm_in, int herm_out, void* stream) {
+    return fft_resample3d_impl(x, y, ws, n_vol, D1, D2, D3, M1, M2, M3, J1, f1_in, f1_out, J2, f2_in, f2_out, m3, scale, herm_in, herm_out,
+                               1, y_act, stream);
 }
 
 static int check_modes3d(const char* who, int H, int W, int T, int Ho, int Wo, int To, int m1, int m2, int m3) {

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_fwd_plane_kernel(Dft2d
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K3p
-template <int MT, int NTN>
+// ACC: out += result, and act_out = gelu(out) where the caller asked for it (a separate instantiation: the plain stores stay as they are)
+template <int MT, int NTN, bool ACC>
 __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2dParams p) {
     constexpr int KSJ = 4 * MT;                                          // k-steps over the corner rows (compiled bound)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -318,7 +319,23 @@ __global__ __launch_bounds__(64 * PL_WAVES, 2) void dft2d_inv_plane_kernel(Dft2d
                 const int w0 = 16 * wt + 4 * kk;
                 if (h < H) {
                     float* row = dst + (size_t)h * W;
-                    if (w0 + 3 < W) {
+                    if constexpr (ACC) {
+                        float* arow = p.act_out ? p.act_out + (size_t)img * H * W + (size_t)h * W : nullptr;
+                        if (w0 + 3 < W) {
+                            const f4u o = *reinterpret_cast<const f4u*>(row + w0);
+                            const f4u v = f4u{{o.v[0] + Y[0], o.v[1] + Y[1], o.v[2] + Y[2], o.v[3] + Y[3]}};
+                            *reinterpret_cast<f4u*>(row + w0) = v;
+                            if (arow) *reinterpret_cast<f4u*>(arow + w0) = f4u{{uno_gelu(v.v[0]), uno_gelu(v.v[1]), uno_gelu(v.v[2]), uno_gelu(v.v[3])}};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (w0 + e < W) {
+                                    const float v = row[w0 + e] + Y[e];
+                                    row[w0 + e] = v;
+                                    if (arow) arow[w0 + e] = uno_gelu(v);
+                                }
+                        }
+                    } else if (w0 + 3 < W) {
                         *reinterpret_cast<f4u*>(row + w0) = f4u{{Y[0], Y[1], Y[2], Y[3]}};
                     } else {
 #pragma unroll
@@ -397,10 +414,15 @@ static int launch_fwd_plane_t(const Dft2dParams& p, hipStream_t s) {
 template <int MT, int NTN>
 static int launch_inv_plane_t(const Dft2dParams& p, hipStream_t s) {
     const size_t lds = inv_plane_lds(p);
-    const int grid = plane_grid(reinterpret_cast<const void*>(dft2d_inv_plane_kernel<MT, NTN>), lds, p.n_img);
+    const void* kern = p.accumulate ? reinterpret_cast<const void*>(dft2d_inv_plane_kernel<MT, NTN, true>)
+                                    : reinterpret_cast<const void*>(dft2d_inv_plane_kernel<MT, NTN, false>);
+    const int grid = plane_grid(kern, lds, p.n_img);
     {
-        ProfScope prof("uno::dft2d_inv_plane_kernel", (double)p.n_img * ((double)p.H * p.W * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
-        hipLaunchKernelGGL((dft2d_inv_plane_kernel<MT, NTN>), dim3(grid), dim3(64 * PL_WAVES), lds, s, p);
+        const double img = (double)p.n_img * (double)p.H * p.W * 4.0;
+        ProfScope prof(p.accumulate ? "uno::dft2d_inv_plane_kernel<acc>" : "uno::dft2d_inv_plane_kernel",
+                       img * (p.accumulate ? (p.act_out ? 3.0 : 2.0) : 1.0) + (double)p.n_img * 2.0 * p.m1 * p.m2 * 8.0, s);
+        if (p.accumulate) hipLaunchKernelGGL((dft2d_inv_plane_kernel<MT, NTN, true>), dim3(grid), dim3(64 * PL_WAVES), lds, s, p);
+        else hipLaunchKernelGGL((dft2d_inv_plane_kernel<MT, NTN, false>), dim3(grid), dim3(64 * PL_WAVES), lds, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dft2d_inv_plane launch: %s", hipGetErrorString(e)); return -5; }

@@ -144,6 +144,8 @@ struct Dft2dParams {
     const int* rowfreq;     // optional (plane-batched kernels only): frequency of spectrum row j, j < 2*m1, instead of the corner rule
     int nw;                 // set by the K1 / K3 launchers: waves per image (a workgroup holds blockDim / (64 nw) images)
     int exp;                // development: knock-out switches of the bf16-MFMA kernels (dft2d_b16.hip), 0 in production
+    int accumulate;         // plane-batched inverse only: out += result (the point-wise branch of OperatorBlock_3D lands in the spectral branch's buffer)
+    float* act_out;         // ... and, if set, act_out = gelu(out) is written in the same pass (blocks without normalisation)
 };
 
 __device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {

@@ -1483,6 +1483,69 @@ class pointwise_op_3D(nn.Module):
         return F.interpolate(out, size=(dim1, dim2, dim3), mode="trilinear", align_corners=True)
 
 
+ONE_BUFFER_3D = True        # OperatorBlock_3D in one buffer (_OperatorBlock3dFn); False: the two branches and stock sum / GELU (A/B switch)
+
+
+class _OperatorBlock3dFn(torch.autograd.Function):
+    """s = SpectralConv3d_Uno(x) + pointwise_op_3D(x) in ONE buffer (reference integral_operators.py:506-512: `x1_out = self.conv(...);
+    x2_out = self.w(...); x_out = x1_out + x2_out`, then F.gelu for blocks without normalisation).
+
+    The spectral branch's inverse transform writes s; the point-wise branch - 1x1x1 convolution (K8), then the reference's FFT crop /
+    resample on the pruned-DFT kernels - ends in a plane-batched inverse transform that ACCUMULATES into s and, for a block whose sum is
+    followed directly by the GELU, writes the activation in the same pass (uno_fft_resample3d_acc).  Backward: the spectral branch
+    writes grad_x, the transposed 1x1x1 convolution accumulates into it.  The element-wise sum (three passes over the output), the
+    GELU (two) and autograd's sum of the two input gradients (three over the input) are gone."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, w4, cw, cb, dims, plan, fuse_gelu):
+        ctx.leaves = (cw, cb)
+        x = _plain(x)
+        ws = [_plain(w) for w in (w1, w2, w3, w4)]
+        B, Ci = x.shape[0], x.shape[1]
+        din = tuple(x.shape[2:])
+        Co = cw.shape[0]
+        cwm = _plain(cw).reshape(Co, Ci)
+        cbp = None if cb is None else _plain(cb)
+        s, xt = _native.spectral_conv3d_forward(x, ws, *dims)
+        t = _native.channel_mix(x.view(B, Ci, -1), cwm, cbp).view(B, Co, *din)
+        t1, t2, m3 = plan
+        scale = 1.0 / (dims[0] * dims[1] * dims[2])
+        if fuse_gelu:
+            s, out = _native.fft_resample3d(t, dims, (t1, t1), (t2, t2), m3, scale, adjoint=False, out=s, act=True)
+        else:
+            out = _native.fft_resample3d(t, dims, (t1, t1), (t2, t2), m3, scale, adjoint=False, out=s)
+        ctx.save_for_backward(xt, *ws, cwm, x, s if fuse_gelu else None)
+        ctx.geom = (din, tuple(dims), plan, cb is not None, tuple(cw.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xt, w1, w2, w3, w4, cwm, x, pre = ctx.saved_tensors
+        din, dims, plan, has_bias, cw_shape = ctx.geom
+        g = _plain(g)
+        if pre is not None:
+            g = torch.ops.aten.gelu_backward(g, pre)
+        B, Co = g.shape[0], g.shape[1]
+        Ci = cwm.shape[1]
+        need_gx = ctx.needs_input_grad[0]
+        need_gw = any(ctx.needs_input_grad[1:5])
+        need_gc = ctx.needs_input_grad[5] or (has_bias and ctx.needs_input_grad[6])
+        gx, gws = _native.spectral_conv3d_backward(g, xt, [w1, w2, w3, w4], *din, need_gx=need_gx, need_gw=need_gw)
+        gws = gws or [None] * 4
+        gcw = gcb = None
+        if need_gx or need_gc:
+            t1, t2, m3 = plan
+            scale = 1.0 / (dims[0] * dims[1] * dims[2])
+            g_t = _native.fft_resample3d(g, din, (t1, t1), (t2, t2), m3, scale, adjoint=True).view(B, Co, -1)
+            if need_gx:
+                _native.channel_mix(g_t, cwm, None, transpose_w=True, out=gx.view(B, Ci, -1))        # accumulates into the spectral branch's gx
+            if need_gc:
+                gcw, gcb = _wgrad_into(ctx.leaves, g_t, x.view(B, Ci, -1), None, ctx.needs_input_grad[5], has_bias and ctx.needs_input_grad[6])
+                gcw = None if gcw is None else gcw.view(cw_shape)
+        return (gx, *gws, gcw, gcb, None, None, None)
+
+
 class OperatorBlock_3D(nn.Module):
     """gelu( [InstanceNorm3d]( SpectralConv3d(x) + pointwise(x) ) )  (reference integral_operators.py:471-513)."""
 
@@ -1496,12 +1559,41 @@ class OperatorBlock_3D(nn.Module):
             self.normalize_layer = nn.InstanceNorm3d(int(out_codim), affine=True)
 
     def forward(self, x, dim1=None, dim2=None, dim3=None):
+        fused = self._fused(x, dim1, dim2, dim3)
+        if fused is not None:
+            out, activated = fused
+            if self.normalize:
+                return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
+            return out if (activated or not self.non_lin) else F.gelu(out)
         out = self.conv(x, dim1, dim2, dim3) + self.w(x, dim1, dim2, dim3)
         if self.normalize:
             return instance_norm_gelu(out, self.normalize_layer, self.non_lin)
         if self.non_lin:
             out = F.gelu(out)
         return out
+
+    def _fused(self, x, dim1, dim2, dim3):
+        """(conv(x) + w(x) [activated], whether the GELU has been applied) through the one-buffer form, or None when the layer has to take
+        the two branches separately (CPU tensors, other dtypes, grids outside the pruned-DFT resampling kernels' range, mismatched grids)."""
+        conv, w = self.conv, self.w
+        if not (ONE_BUFFER_3D and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == conv.in_channels
+                and w.conv.weight.dtype == torch.float32):
+            return None
+        if dim1 is not None:        # the spectral layer keeps a call-time override, the point-wise one does not (:391-394, :444-446)
+            dims = (int(dim1), int(dim2), int(dim3))
+        else:
+            dims = (int(w.dim1), int(w.dim2), int(w.dim3))
+            if (conv.dim1, conv.dim2, conv.dim3) != dims:
+                return None
+        plan = _resample3d_plan(tuple(x.shape[-3:]), dims, x.device)
+        if plan is None:
+            return None
+        if dim1 is not None:
+            conv.dim1, conv.dim2, conv.dim3 = dim1, dim2, dim3
+        gelu = self.non_lin and not self.normalize
+        out = _OperatorBlock3dFn.apply(x, conv.weights1, conv.weights2, conv.weights3, conv.weights4, w.conv.weight, w.conv.bias,
+                                       dims, plan, gelu)
+        return out, gelu
 
 
 # --------------------------------------------------------------------------------------------- 1-D
