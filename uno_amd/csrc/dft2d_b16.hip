@@ -526,7 +526,7 @@ static int launch_fwd_b16_t(const Dft2dParams& p, hipStream_t s) {
 // NC = 16 NCT output columns per chunk (one twiddle table; NCT is a template parameter); a wave owns 32-row tiles (two 16-row operand tiles); staging: 32 rows x
 // NC bf16 per wave.  The +-k pair operands of the column stage (72 registers at 32 x 32 modes) live in LDS per image, not in
 // registers: they are read once per tile.
-template <int NT, int NCT, int XP>
+template <int NT, int NCT, int SCT, int XP>
 __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dParams p, const u32x4* __restrict__ gtab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = p.H, W = p.W, m1 = p.m1, m2 = p.m2;
@@ -538,7 +538,8 @@ __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dPara
     const unsigned H8 = 8u * H;
     constexpr int NC = 16 * NCT;                                // columns per chunk: compile-time, so that the group and flush loops unroll
     const int nch = (W + NC - 1) / NC;
-    constexpr int srow = NC / 2 + 4;                            // staging row pitch in dwords: NC bf16 + 16 bytes (bank skew)
+    constexpr int SC = 16 * SCT;                                // columns staged and flushed at a time (NCT / SCT flushes per chunk)
+    constexpr int srow = SC / 2 + 4;                            // staging row pitch in dwords: SC bf16 + 16 bytes (bank skew)
     const int ksk = (m1 + 4) >> 2;                              // k-steps of the paired column stage: k = 0 .. m1 in fours (<= 2 JT + 1)
     u32x4* sTab = reinterpret_cast<u32x4*>(smem);                                              // [NCT][NT][2][64]
     unsigned* sStage = reinterpret_cast<unsigned*>(smem + (size_t)NCT * NT * 2 * 1024);       // [waves][32][srow]
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dPara
     const u32x4* tabL = sTab + lane;
     const float* pmL = sPM + (size_t)slot * NT * ksk * 256 + lane;
     const bool w8 = (W & 7) == 0;               // rows 16-byte aligned: one 16-byte store per lane
-    constexpr int lpr = NC >> 3;                // flush: lanes per row segment (a lane owns 8 columns = 16 bytes) ...
+    constexpr int lpr = SC >> 3;                // flush: lanes per row segment (a lane owns 8 columns = 16 bytes) ...
     constexpr int RP = 64 / lpr;                // ... rows per pass
     const int frow = lane / lpr, fcol = lane - frow * lpr;
 
@@ -664,7 +665,10 @@ __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dPara
             const int col0 = c * NC;
             const int nmt = min(NCT, (W - col0 + 15) >> 4);
 #pragma unroll
-            for (int m0 = 0; m0 < NCT; m0 += 2) {
+            for (int sub = 0; sub < NCT / SCT; ++sub) {
+            if (sub * SCT >= nmt) break;
+#pragma unroll
+            for (int m0 = sub * SCT; m0 < (sub + 1) * SCT; m0 += 2) {
                 if (m0 >= nmt) break;
                 f32x4 D[2][2];
 #pragma unroll
@@ -695,15 +699,15 @@ __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dPara
                     if (m0 + u < nmt && !(xp & 4)) {
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh) {
-                            unsigned* dst = stg + (16 * hh + r16) * srow + 8 * (m0 + u) + 2 * kk;      // columns 16 mt + 4 kk .. + 3 of row 16 hh + r16
+                            unsigned* dst = stg + (16 * hh + r16) * srow + 8 * (m0 + u - sub * SCT) + 2 * kk;      // columns 16 mt + 4 kk .. + 3 of row 16 hh + r16
                             *reinterpret_cast<uint2*>(dst) = make_uint2(bf16_pack2(D[u][hh][0], D[u][hh][1]), bf16_pack2(D[u][hh][2], D[u][hh][3]));
                         }
                     }
                 }
             }
             B16_STAMP(t_row);
-            // ---- the chunk leaves as row segments: pass q covers rows q * RP .. + RP - 1, a lane owns 8 columns (16 bytes)
-            const int col = col0 + 8 * fcol;
+            // ---- the staged columns leave as row segments: pass q covers rows q * RP .. + RP - 1, a lane owns 8 columns (16 bytes)
+            const int col = col0 + sub * SC + 8 * fcol;
             u32x4 fv[32 / RP];
 #pragma unroll
             for (int q = 0; q < 32 / RP; ++q) fv[q] = *reinterpret_cast<const u32x4*>(stg + (q * RP + frow) * srow + 4 * fcol);
@@ -728,6 +732,7 @@ __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dPara
                 }
             }
             B16_STAMP(t_flush);
+            }
         }
     }
     if ((xp & 16) && p.rowfreq && lane == 0) {
@@ -736,18 +741,18 @@ __global__ __launch_bounds__(64 * B16_WAVES) void dft2d_inv_b16_kernel(Dft2dPara
     }
 }
 
-static size_t inv_b16_lds(const Dft2dParams& p, int NT, int NCT, int G) {
+static size_t inv_b16_lds(const Dft2dParams& p, int NT, int NCT, int SCT, int G) {
     const int NC = 16 * NCT, nch = (p.W + NC - 1) / NC, ksk = (p.m1 + 4) >> 2;
-    return (size_t)NCT * NT * 2 * 1024 + (size_t)B16_WAVES * 32 * (NC / 2 + 4) * 4 + (size_t)nch * 16 * NT * 8 + (size_t)((p.H + 1) & ~1) * 8 +
+    return (size_t)NCT * NT * 2 * 1024 + (size_t)B16_WAVES * 32 * (16 * SCT / 2 + 4) * 4 + (size_t)nch * 16 * NT * 8 + (size_t)((p.H + 1) & ~1) * 8 +
            (size_t)G * NT * ksk * 1024;
 }
 
-template <int NT, int NCT, int XP>
+template <int NT, int NCT, int SCT, int XP>
 static int launch_inv_b16_v(Dft2dParams p, hipStream_t s) {
     int nw, g;
     b16_geometry(p.n_img, (p.H + 31) / 32, B16_WAVES, &nw, &g);
     p.nw = nw;
-    const size_t lds = inv_b16_lds(p, NT, NCT, g);
+    const size_t lds = inv_b16_lds(p, NT, NCT, SCT, g);
     if (lds > 160 * 1024) { set_error("dft2d_inv_b16: %zu bytes of LDS", lds); return -3; }
     const int W = p.W, m2 = p.m2;
     // entry e = (column tile mt, k-step ks): lane (i = ln & 15 -> column wc = 16 mt + i of the chunk, g = ln >> 4), element j: value
@@ -764,12 +769,12 @@ static int launch_inv_b16_v(Dft2dParams p, hipStream_t s) {
         return im ? -sn : c;
     });
     if (!tab) return -6;
-    auto k = dft2d_inv_b16_kernel<NT, NCT, XP>;
+    auto k = dft2d_inv_b16_kernel<NT, NCT, SCT, XP>;
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_slot)) { set_error("dft2d_inv_b16: cannot raise dynamic LDS to %zu", lds); return -4; }
     if (XP & 16) p.rowfreq = reinterpret_cast<const int*>((uintptr_t)strtoull(getenv("UNO_B16_STAMPS") ? getenv("UNO_B16_STAMPS") : "0", nullptr, 0));
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_inv_b16_kernel<%d, %d>", NT, NCT);
+    snprintf(name, sizeof(name), "uno::dft2d_inv_b16_kernel<%d, %d, %d>", NT, NCT, SCT);
     {
         ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 2.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3((p.n_img + g - 1) / g), dim3(64 * B16_WAVES), lds, s, p, reinterpret_cast<const u32x4*>(tab));
@@ -779,27 +784,31 @@ static int launch_inv_b16_v(Dft2dParams p, hipStream_t s) {
     return 0;
 }
 
-// 128 columns per chunk where a row is long enough and the staging fits next to the table and the column-stage operands, else 64
+// chunk = 256 columns (one rotation + split of U per 256 columns), staged and flushed 128 at a time, where the 64 KB table, the
+// staging and the column-stage operands fit the LDS together; else 128 / 128; short rows 64 / 64
 template <int NT>
 static int launch_inv_b16_t(const Dft2dParams& p, hipStream_t s) {
     int nw, g;
     b16_geometry(p.n_img, (p.H + 31) / 32, B16_WAVES, &nw, &g);
-    const bool wide = p.W > 128 && inv_b16_lds(p, NT, 8, g) <= 150 * 1024;
+    const size_t limit = 160 * 1024;
+    const bool c256 = p.W > 256 && inv_b16_lds(p, NT, 16, 8, g) <= limit;
+    const bool c128 = p.W > 128 && inv_b16_lds(p, NT, 8, 8, g) <= limit;
 #ifdef UNO_B16_DEV
-    if (NT == 2 && wide) {
+    if (NT == 2 && c128) {
         static const int xp = b16_exp("UNO_B16_INV_EXP", 0);
         switch (xp) {
-            case 1: return launch_inv_b16_v<NT, 8, 1>(p, s);
-            case 2: return launch_inv_b16_v<NT, 8, 2>(p, s);
-            case 4: return launch_inv_b16_v<NT, 8, 4>(p, s);
-            case 6: return launch_inv_b16_v<NT, 8, 6>(p, s);
-            case 8: return launch_inv_b16_v<NT, 8, 8>(p, s);
-            case 16: return launch_inv_b16_v<NT, 8, 16>(p, s);
+            case 1: return launch_inv_b16_v<NT, 8, 8, 1>(p, s);
+            case 2: return launch_inv_b16_v<NT, 8, 8, 2>(p, s);
+            case 4: return launch_inv_b16_v<NT, 8, 8, 4>(p, s);
+            case 8: return launch_inv_b16_v<NT, 8, 8, 8>(p, s);
+            case 16: return c256 ? launch_inv_b16_v<NT, 16, 8, 16>(p, s) : launch_inv_b16_v<NT, 8, 8, 16>(p, s);
+            case 32: return launch_inv_b16_v<NT, 8, 8, 0>(p, s);          // A/B: 128-column chunks where 256 would fit
             default: break;
         }
     }
 #endif
-    return wide ? launch_inv_b16_v<NT, 8, 0>(p, s) : launch_inv_b16_v<NT, 4, 0>(p, s);
+    if (c256) return launch_inv_b16_v<NT, 16, 8, 0>(p, s);
+    return c128 ? launch_inv_b16_v<NT, 8, 8, 0>(p, s) : launch_inv_b16_v<NT, 4, 4, 0>(p, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dispatch
