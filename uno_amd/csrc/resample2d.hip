@@ -13,6 +13,7 @@
 #include "uno_common.h"
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 
 namespace uno {
 
@@ -121,11 +122,31 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
     if (n >= n_img) return;
     const int i0 = tile * RS_TR;
     const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
     const int p0 = tile_p0[tile];
     const int WP = (W + 3) & ~3;                                       // row pitch of V: 16-byte aligned rows
     float* sWd = V + RS_TR * WP;
-    const int nthreads = blockDim.x;
     const T* src = in + (size_t)n * H * W;
+    // phase-2 mapping (needed here already: the accumulating form requests the old values of its first column sweep before phase 1)
+    T* dst = out + ((size_t)n * Ho + i0) * Wo;
+    const int nr = min(RS_TR, Ho - i0);
+    const int WoP = (Wo + 63) & ~63;
+    const int G = max(1, nthreads / WoP);
+    const int g = tid / WoP;
+    const int jstride = G == 1 ? nthreads : WoP;
+    const int j0 = tid - g * WoP;
+    float old[ACCUM ? RS_TR : 1];
+    // straight-line phase 2 (below) where the output rows are at least as long as the input rows (measured, tools/rsbench.py, old -> new:
+    // accumulating 223 -> 446 490 -> 400 us, 111 -> 223 272 -> 206, 334 -> 446 595 -> 499, 223 -> 334 629 -> 508; plain 223 -> 446
+    // 302 -> 277; the down-sampling shapes - half of the threads idle in phase 2 - LOSE 10-20 % with it and keep the rolled loop)
+    const bool straight = G == 1 && Wo >= W;
+    if constexpr (ACCUM) {
+        if (straight) {
+            const int jc = min(j0, Wo - 1);
+#pragma unroll
+            for (int i = 0; i < RS_TR; ++i) old[i] = io_widen(dst[(size_t)min(i, nr - 1) * Wo + jc]);
+        }
+    }
     if constexpr (MF) {
         const int lane = tid & 63, n16 = lane & 15, kk = lane >> 4;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
@@ -229,40 +250,64 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
     }
     }
     __syncthreads();
-    T* dst = out + ((size_t)n * Ho + i0) * Wo;
-    const int nr = min(RS_TR, Ho - i0);
-    // phase 2: thread -> (row group g, column j): when the workgroup is wider than a row, groups take rows round-robin
-    const int WoP = (Wo + 63) & ~63;
-    const int G = max(1, nthreads / WoP);
-    const int g = tid / WoP;
-    const int jstride = G == 1 ? nthreads : WoP;
-    if (g < G) {
-        for (int j = tid - g * WoP; j < Wo; j += jstride) {
-            const int s = startW[j];
-            // straight-line taps: KW is a run-time value, and `if (t < KW)` per tap compiled to a chain of branches with a
-            // load (then an LDS read) under each
-            float w[KT];
+    // phase 2: thread -> (row group g, column j): when the workgroup is wider than a row, groups take rows round-robin.  The rows of a
+    // thread are straight-line code (RS_TR / G of them at most; row index clamped for the reads, guarded for the stores): the LDS
+    // reads of all rows are in flight together and the stores leave back to back.  ACCUM: the OLD values of a column's rows are
+    // requested one column sweep ahead - the first sweep's before phase 1 (above) - so that no load round trip sits between
+    // two stores (the rolled loop of rounds 1-3 paid one per row: load - wait - add - store, 16 times per thread and sweep)
+    // one column sweep: NR = compile-time row count of a thread (16 when the workgroup is one row group, else the generic loop bound)
+    auto sweep = [&](int j, auto g1) {
+        constexpr bool G1 = decltype(g1)::value;
+        const int s = startW[j];
+        // straight-line taps: KW is a run-time value, and `if (t < KW)` per tap compiled to a chain of branches with a
+        // load (then an LDS read) under each
+        float w[KT];
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                float wv = wtW[(size_t)j * KW + min(t, KW - 1)];
-                asm volatile("" : "+v"(wv));
-                w[t] = t < KW ? wv : 0.f;
+        for (int t = 0; t < KT; ++t) {
+            float wv = wtW[(size_t)j * KW + min(t, KW - 1)];
+            asm volatile("" : "+v"(wv));
+            w[t] = t < KW ? wv : 0.f;
+        }
+        if constexpr (G1) {
+            float cur[ACCUM ? RS_TR : 1];
+            if constexpr (ACCUM) {
+#pragma unroll
+                for (int i = 0; i < RS_TR; ++i) cur[i] = old[i];
+                const int jn = min(j + jstride, Wo - 1);           // next sweep's column (clamped: a valid address, unused past the end)
+#pragma unroll
+                for (int i = 0; i < RS_TR; ++i) old[i] = io_widen(dst[(size_t)min(i, nr - 1) * Wo + jn]);
             }
-            for (int r = g; r < nr; r += G) {
-                const float* v = V + r * WP;
+#pragma unroll
+            for (int i = 0; i < RS_TR; ++i) {
+                const float* v = V + i * WP;                        // (rows past nr hold finite values: phase 1 writes all 16)
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
                 // ACCUM is a template parameter: a run-time flag here put a conditional load into the store loop and
                 // cost the plain path 60 % (227 -> 362 us at 1024 x 446^2 -> 223^2)
+                if (i < nr) io_store1(dst + (size_t)i * Wo + j, ACCUM ? cur[i] + acc : acc);
+            }
+        } else {
+            for (int r = g; r < nr; r += G) {
+                const float* v = V + r * WP;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
                 io_store1(dst + (size_t)r * Wo + j, ACCUM ? io_widen(dst[(size_t)r * Wo + j]) + acc : acc);
             }
         }
+    };
+    if (straight) {
+        for (int j = j0; j < Wo; j += jstride) sweep(j, std::true_type{});
+    } else if (g < G) {
+        for (int j = j0; j < Wo; j += jstride) sweep(j, std::false_type{});
     }
 }
 
 // one instantiation of the fused kernel: raises its dynamic-LDS limit when a long row needs more than the 64 KB a launch gets by
 // default (rows of 1000 .. 2400 floats: the 1024^2 / 1089^2 levels of config C5), then launches
+// (round 4, measured and not kept: PERSISTENT workgroups walking the (image, tile) slots of their XCD - as many workgroups as the
+// device holds at once - are 5-45 % slower on every shape of tools/rsbench.py than one workgroup per tile)
 template <bool A, int K, typename T, bool MF>
 static bool launch_fused_one(dim3 grid, int nthreads, size_t lds, hipStream_t s, const T* in, T* out, const int* tile_p0, const float* tile_w,
                              int NP, const int* startW, const float* wtW, int KW, int H, int W, int Ho, int Wo, int n_img, int ntiles) {
