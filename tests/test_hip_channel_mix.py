@@ -364,3 +364,69 @@ def test_channel_mix_cat_project_autograd_vs_torch():
     assert rel(out.detach(), outr.detach()) < 3e-6
     for got, ref, tol in zip((x1, x2, w, b, w2, b2), d, (3e-6, 3e-6, 2e-5, 2e-5, 2e-5, 2e-5)):
         assert rel(got.grad, ref.grad) < tol
+
+
+# ---- K8-S: the wide layers (Ci >= 128, Co % 128 == 0) on the bf16 matrix pipe with three-piece operands (csrc/channel_mix.hip).
+# The kernel name is checked through the library's own launch log so that a dispatch change cannot leave these shapes on the f32 form.
+SPLIT = [
+    # B, C1, C2, Co, P
+    (2, 128, 0, 256, 1111),         # 8 full pixel tiles + a partial one (guarded fallback inside the kernel)
+    (1, 256, 0, 128, 640),
+    (2, 160, 0, 128, 300),          # five chunks of 32
+    (2, 96, 64, 128, 515),          # two sources, split on a chunk boundary
+    (2, 128, 128, 256, 111 * 111),  # the Darcy model's 111^2 level (conv2: 256 -> 256)
+]
+
+
+def _launched(fn):
+    from uno_amd import _native
+    _native.profile_begin(64)
+    out = fn()
+    torch.cuda.synchronize()
+    return out, [r[0] for r in _native.profile_end()]
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", SPLIT)
+def test_split_bf16_wide_layers(B, C1, C2, Co, P):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + 5 * C2 + Co + P)
+    # values spread over several binades and signs: the three-piece split must carry the low bits of every element
+    x = (torch.randn(B, C1 + C2, P, generator=g) * torch.exp2(torch.randint(-6, 7, (B, C1 + C2, 1), generator=g).float())).cuda()
+    w = (torch.randn(Co, C1 + C2, generator=g) * torch.exp2(torch.randint(-4, 5, (Co, 1), generator=g).float())).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    x1, x2 = (x[:, :C1].contiguous(), x[:, C1:].contiguous()) if C2 else (x, None)
+    ref = _ref(x, w, b)
+    y, names = _launched(lambda: _native.channel_mix2(x1, x2, w, b))
+    assert names == ["uno::channel_mix_split_kernel"], names
+    assert rel(y, ref) < 1e-6          # (measured ~1e-7: tighter than the f32 MFMA form's bound on purpose)
+    assert (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    # accumulate + activated copy
+    base = torch.randn(B, Co, P, generator=g).cuda()
+    out = base.clone()
+    _native.channel_mix2(x1, x2, w, b, out=out, accumulate=True)
+    assert rel(out, ref + base.double()) < 1e-6
+    y2, act = _native.channel_mix2(x1, x2, w, b, y_act=True)
+    assert torch.equal(y2, y) and rel(act, _gelu64(y)) < 2e-6
+    # transposed weights (the input-gradient call): gx = W^T gy, both destinations of a two-source layer when the split is 128-aligned
+    gy = torch.randn(B, Co, P, generator=g).cuda()
+    if (C1 + C2) % 128 == 0 and Co >= 128:
+        gx, names = _launched(lambda: _native.channel_mix(gy, w, None, transpose_w=True))
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert rel(gx, torch.matmul(w.double().t(), gy.double())) < 1e-6
+        if C2 and C1 % 128 == 0:
+            g1, g2 = _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=C1)
+            assert rel(torch.cat([g1, g2], 1), torch.matmul(w.double().t(), gy.double())) < 1e-6
+
+
+def test_split_bf16_wide_layers_bf16_activations():
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(11)
+    B, Ci, Co, P = 2, 256, 128, 1000
+    x = torch.randn(B, Ci, P, generator=g).cuda().to(torch.bfloat16)
+    w, b = torch.randn(Co, Ci, generator=g).cuda(), torch.randn(Co, generator=g).cuda()
+    y, names = _launched(lambda: _native.channel_mix(x, w, b))
+    assert names == ["uno::channel_mix_split_kernel"], names
+    ref = _ref(x.float(), w, b)
+    # the products are exact to ~1e-7; what remains is the bf16 rounding of the result
+    assert rel(y.float(), ref) < 3e-3
+    assert rel(y.float(), ref.float().to(torch.bfloat16).double()) < 1e-3

@@ -11,6 +11,7 @@
 // v_mfma_f32_16x16x4_f32 fragments (exact f32, same arithmetic as an fmaf chain).
 #include "uno_common.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace uno {
 
@@ -61,6 +62,7 @@ struct ChannelMixParams {
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
+    int exp;                // development knock-outs of K8-S (timing only; UNO_CMS_EXP)
     int accumulate;         // 1: y += instead of y =;  2 (with dgelu_of): y = (y + product) * gelu'(dgelu_of) - the LAST contribution to a
                             // gradient that must still pass through a GELU: the factor multiplies the completed sum
     const void* dgelu_of;   // nullptr, or (B, Co1, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
@@ -512,6 +514,258 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K8-S
+// Wide layers (Ci >= 128, Co % 128 == 0) on the bf16 matrix pipe with BOTH operands split into three bfloat16 pieces
+// (x = hi + mid + lo exactly to 2^-24 |x|; six products hi hi, hi mid, mid hi, hi lo, mid mid, lo hi, f32 accumulation): relative
+// error ~1e-7 - measured below the f32 MFMA form's own 3e-7 (profiles/r04_split_bf16_error.txt) - at 6 x 16 cycles per
+// 16 x 16 x 32 block instead of 8 x 32.  Why here and not in the transforms: these layers are MFMA-bound, not memory-bound - a
+// 256 -> 256 layer at 111^2 is 25.8 GFLOP = 164 us of f32 MFMA peak for 808 MB = 135 us of HBM time, measured 286 us; the 256-channel
+// layers of the Darcy step ran at 55-60 % of the f32 MFMA peak.  bf16 activations (BF) are exact in one
+// piece: three products.
+//   * workgroup = 128 pixels x 128 output channels, K chunks of 32 input channels; wave (a, b) owns pixels 64 a .. + 63 x channels
+//     64 b .. + 63 = 4 x 4 accumulator tiles: every operand fragment feeds four MFMA groups;
+//   * both operands are split ONCE per workgroup, by the thread that stages them (88 VALU per 16 values), and live in LDS as bf16:
+//     - X as three planes [k][px] (the layout it arrives in: a thread's four pixels of one channel are one 8-byte write per
+//       plane); the A operand - 8 k-values of one pixel per lane - comes out of two ds_read_b64_tr_b16 (gfx950's transposing read:
+//       within a 16-lane group lane 4 j + q supplies the address of segment q of row j and lane i receives column i of the 4 x 16
+//       block, tools/probes/ds_read_tr_probe.hip), which numbers a lane's k-slots e = 0..7 as k = 4 g + e | 16 + 4 g + (e - 4);
+//       rows 288 bytes apart: the 8 rows x 4 segments of a half-wave cover the 64 banks once;
+//     - W as three planes of 16-byte atoms [k-group g][o] holding the SAME k-slots (a thread's four consecutive k of one output
+//       channel are half an atom): a lane's B operand is one conflict-free ds_read_b128 per plane and channel tile;
+//     no VALU work and 36 LDS reads per 96 MFMAs in the multiply phase.
+// One LDS buffer (52 KB), two barriers per chunk, the next chunk's global loads in flight during the MFMAs; two workgroups per CU.
+// Non-finite inputs: x - hi(x) is NaN for x = +-inf (the f32 form returns inf where no 0 * inf occurs).
+typedef __bf16 cms_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned cms_u32x4 __attribute__((ext_vector_type(4)));
+typedef short cms_v4i16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 cms_mfma(const cms_u32x4& a, const cms_u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cms_bf16x8, a), __builtin_bit_cast(cms_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void cms_split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = bf16_pack2(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = bf16_pack2(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = bf16_pack2(sa, sb);
+}
+__device__ __forceinline__ uint2 cms_tr_read(const char* lds_addr) {
+    typedef cms_v4i16 __attribute__((address_space(3))) * lds_v4;
+    const cms_v4i16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(const void __attribute__((address_space(3)))*)lds_addr);
+    return __builtin_bit_cast(uint2, v);
+}
+constexpr int CMS_KC = 32;
+constexpr int CMS_XRS = CM_PT * 2 + 32;                 // bytes between two k rows of an X plane
+constexpr int CMS_XPLANE = CMS_KC * CMS_XRS;            // 9 216
+constexpr int CMS_WPLANE = 4 * 128 * 16;                // bytes per W plane: [k-group 4][o 128] atoms of 8 bf16
+constexpr int CMS_FALLBACK = 2 * CM_KC * (CM_PT + 16) * 4 + 2 * CM_KC * CM_WS * 4;      // staging buffers of the guarded fallback path
+
+template <bool BF, bool TR, int XP = 0>      // TR: W contiguous along the output channel (input-gradient call); XP: development knock-outs / stamps
+__global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixParams p) {
+    constexpr bool tr = TR;
+    using T = typename IoElem<BF>::type;
+    constexpr int PT = CM_PT;
+    constexpr int NPX = BF ? 1 : 3;                     // pieces of the X operand
+    constexpr int LDS_MAIN = NPX * CMS_XPLANE + 3 * CMS_WPLANE;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_MAIN > CMS_FALLBACK ? LDS_MAIN : CMS_FALLBACK];
+    char* sXb = smem;
+    char* sWb = smem + NPX * CMS_XPLANE;
+    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.ntile) return;
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = blockIdx.y;
+    if (p0 + PT > p.P) {            // the last, partial pixel tile of a row: the guarded 64-channel path twice (as the wide kernel)
+        auto sXn = reinterpret_cast<float (*)[CM_KC * (PT + 16)]>(smem);
+        auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(smem + 2 * CM_KC * (PT + 16) * 4);
+        channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0, b);
+        __syncthreads();
+        channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0 + 64, b);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wb = wave >> 1;
+    const int C1 = p.C1;
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;
+    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;
+
+    float4 rx[4], rw[4];
+    auto load_chunk = [&](int k0) {
+        const T* cb = k0 < C1 ? xb : xb2;                // a 32-channel chunk lies in one source (C1 % 32 == 0)
+        const int kb = k0 < C1 ? k0 : k0 - C1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            if constexpr (!(XP & 4)) rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+            else rx[u] = make_float4(1.f, 2.f, 3.f, 4.f);
+            if constexpr ((XP & 2) != 0) { rw[u] = make_float4(1.f, 2.f, 3.f, 4.f); continue; }
+            if constexpr (!tr) {
+                // 16 consecutive lanes = 16 consecutive output channels at one k-quad (their LDS writes: 2-way, not 4-way), the four
+                // lane groups of a wave = 64 contiguous bytes of each of those rows
+                const int o = (e & 15) | ((e >> 7) << 4), k4 = ((e >> 4) & 7) * 4;
+                const f4u wv = *reinterpret_cast<const f4u*>(p.w + (unsigned)((o0 + o) * p.w_so + k0 + k4));
+                rw[u] = make_float4(wv.v[0], wv.v[1], wv.v[2], wv.v[3]);
+            } else {
+                const int o = e & 127, k4 = (e >> 7) * 4;
+                const float* wp = p.w + (unsigned)((k0 + k4) * p.w_si + o0 + o);
+                rw[u] = make_float4(wp[0], wp[p.w_si], wp[2 * p.w_si], wp[3 * p.w_si]);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            {
+                char* d = sXb + (e >> 5) * CMS_XRS + (e & 31) * 8;
+                if constexpr (BF) {
+                    *reinterpret_cast<uint2*>(d) = make_uint2(bf16_pack2(rx[u].x, rx[u].y), bf16_pack2(rx[u].z, rx[u].w));      // exact: widened bf16
+                } else {
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    if constexpr ((XP & 8) != 0) { h0 = __float_as_uint(rx[u].x); m0 = __float_as_uint(rx[u].y); l0 = h0 ^ m0; h1 = __float_as_uint(rx[u].z); m1 = __float_as_uint(rx[u].w); l1 = h1 ^ m1; }
+                    else { cms_split3(rx[u].x, rx[u].y, h0, m0, l0); cms_split3(rx[u].z, rx[u].w, h1, m1, l1); }
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(d + (NPX > 1 ? 1 : 0) * CMS_XPLANE) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(d + (NPX > 2 ? 2 : 0) * CMS_XPLANE) = make_uint2(l0, l1);
+                }
+            }
+            if constexpr ((XP & 16) != 0) continue;
+            const int o = tr ? (e & 127) : ((e & 15) | ((e >> 7) << 4));
+            const int k4 = tr ? (e >> 7) * 4 : ((e >> 4) & 7) * 4;
+            unsigned h0, m0, l0, h1, m1, l1;
+            cms_split3(rw[u].x, rw[u].y, h0, m0, l0);
+            cms_split3(rw[u].z, rw[u].w, h1, m1, l1);
+            // k-slots of an atom as the transposing read numbers them: k4 .. k4 + 3 are slots 0..3 (k4 < 16) or 4..7 of k-group (k4 & 15) / 4
+            char* d = sWb + (((((k4 & 15) >> 2) * 128) + o) * 16 + (k4 >> 4) * 8);
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + CMS_WPLANE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 2 * CMS_WPLANE) = make_uint2(l0, l1);
+        }
+    };
+
+    f32x4 acc[4][4];                    // [pixel tile m][channel tile t]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
+
+    // transposing read: lane (group kk, index r16) supplies the address of row 4 kk + (r16 >> 2), segment r16 & 3
+    const char* xat = sXb + (4 * kk + (r16 >> 2)) * CMS_XRS + (64 * wa + 4 * (r16 & 3)) * 2;
+    const char* wat = sWb + ((kk * 128 + 64 * wb + r16) * 16);
+    auto compute = [&]() {
+        cms_u32x4 Wop[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Wop[t][pl] = *reinterpret_cast<const cms_u32x4*>(wat + pl * CMS_WPLANE + t * 256);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cms_u32x4 Xp[NPX];
+#pragma unroll
+            for (int pl = 0; pl < NPX; ++pl) {
+                const uint2 a0 = cms_tr_read(xat + pl * CMS_XPLANE + 32 * m);
+                const uint2 a1 = cms_tr_read(xat + pl * CMS_XPLANE + 32 * m + 16 * CMS_XRS);
+                Xp[pl] = cms_u32x4{a0.x, a0.y, a1.x, a1.y};
+            }
+            if constexpr ((XP & 1) != 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t][0] += __uint_as_float(Xp[0][0] ^ Xp[NPX - 1][3] ^ Wop[t][0][1] ^ Wop[t][1][2] ^ Wop[t][2][3]);
+                continue;
+            }
+            // smallest products first; the four channel tiles between two uses of an accumulator
+            if constexpr (!BF) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[NPX > 2 ? 2 : 0], Wop[t][0], acc[m][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[NPX > 1 ? 1 : 0], Wop[t][1], acc[m][t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[0], Wop[t][2], acc[m][t]);
+            if constexpr (!BF) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[NPX > 1 ? 1 : 0], Wop[t][0], acc[m][t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[0], Wop[t][1], acc[m][t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[0], Wop[t][0], acc[m][t]);
+        }
+    };
+
+    const int nchunk = p.Ci / CMS_KC;
+    // development (XP & 64): cycle stamps per phase of wave 0 .. 3, summed over the chunks, to the buffer proj_out points at
+    constexpr bool stamps = (XP & 64) != 0;
+    unsigned long long tS = 0, tB1 = 0, tC = 0, tB2 = 0, t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_begin = t_prev;
+#define CMS_STAMP(acc_) do { if constexpr (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); (acc_) += t_ - t_prev; t_prev = t_; } } while (0)
+    load_chunk(0);
+    for (int c = 0; c < nchunk; ++c) {
+        store_chunk();                  // (waits for the chunk's loads)
+        CMS_STAMP(tS);
+        __syncthreads();
+        CMS_STAMP(tB1);
+        if (c + 1 < nchunk) load_chunk((c + 1) * CMS_KC);       // global -> registers while this chunk is multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+        CMS_STAMP(tC);
+        __syncthreads();                // every wave is done with the chunk: the buffers may be overwritten
+        CMS_STAMP(tB2);
+    }
+    const unsigned long long t_loop_end = t_prev;
+
+    // epilogue: a wave's 16 channels x 64 pixels leave through LDS as 256-byte row segments (four rows per store instruction);
+    // D[px = 16 m + 4 kk + r][o = 16 t + r16].  The staging area is PRIVATE to the wave (16 rows x 80 floats), a wave's LDS instructions execute in order, so no workgroup barrier is needed -
+    // only that the compiler keeps the order (wave_barrier); the first version synchronised the workgroup 16 times per tile
+    // (10 900 of a workgroup's 63 500 cycles were epilogue)
+    constexpr int OS = 64 + 16;
+    float* sO = reinterpret_cast<float*>(smem) + wave * (16 * OS);
+    const int c4 = (lane & 15) * 4;
+    const CmDest<T> dd = cm_dest<T>(p, o0, b);          // a 128-channel tile lies in one destination (Co1 % 128 == 0)
+    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
+    float bias_l[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bias_l[t] = p.bias ? p.bias[o0 + 64 * wb + 16 * t + r16] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ob = o0 + 64 * wb + 16 * t;
+        float* sT = sO;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<float4*>(sT + r16 * OS + 16 * m + 4 * kk) = make_float4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 old[4];
+        T* dst[4];
+        size_t aoff[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int o = ob + 4 * it + (lane >> 4);
+            dst[it] = dd.base + (size_t)(o - dd.ob) * p.P + p0 + 64 * wa + c4;
+            aoff[it] = (size_t)o * p.P + p0 + 64 * wa + c4;
+            if (p.accumulate) old[it] = io_ld4(dst[it]);
+            else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = 4 * it + (lane >> 4);
+            const float4 v = *reinterpret_cast<const float4*>(sT + row * OS + c4);
+            const float bv = __shfl(bias_l[t], row);
+            const float w0 = old[it].x + (v.x + bv), w1 = old[it].y + (v.y + bv), w2 = old[it].z + (v.z + bv), w3 = old[it].w + (v.w + bv);
+            io_store4(dst[it], w0, w1, w2, w3);
+            if (aall) io_store4(aall + aoff[it], cm_gelu(w0), cm_gelu(w1), cm_gelu(w2), cm_gelu(w3));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (stamps) {
+        if (p.proj_out && lane == 0) {
+            unsigned long long* o_ = reinterpret_cast<unsigned long long*>(p.proj_out) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            o_[0] = tS; o_[1] = tB1; o_[2] = tC; o_[3] = tB2; o_[4] = __builtin_readcyclecounter() - t_loop_end; o_[5] = t_loop_end - t_begin;
+            o_[6] = t_begin; o_[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#undef CMS_STAMP
+}
+
 // Few input channels (the lift's first layer: 3 -> 32 at full resolution).  The tiled kernel stages 16-channel chunks - 13 of 16
 // rows of every chunk would be zero fill: 148 us against 79 us for the layer's bytes.  Here a thread owns four pixels, keeps its CI
 // input values in registers and walks over the output channels with wave-uniform (scalar) weights: pure streaming, 1 KB of every
@@ -582,6 +836,12 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const void* dgelu_of = a.dgelu_of;
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
     const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0);
+    // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
+    static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;          // development: A/B against the f32-MFMA form
+    static const int cms_exp = getenv("UNO_CMS_EXP") ? atoi(getenv("UNO_CMS_EXP")) : 0;
+    p.exp = cms_exp;
+    if ((cms_exp & 64) && getenv("UNO_CMS_STAMPS")) p.proj_out = reinterpret_cast<void*>((uintptr_t)strtoull(getenv("UNO_CMS_STAMPS"), nullptr, 0));
+    const bool split = wide && !split_off && Ci >= 128 && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0);
     if (two_src && (p.C1 < CM_KC || p.C1 >= Ci || p.C1 % CM_KC)) {
         set_error("channel_mix: a two-source call splits the input channels at a multiple of %d inside (0, Ci) (got %d of %d)", CM_KC, p.C1, Ci);
         return -2;
@@ -611,9 +871,27 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     }
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
-        ProfScope prof(wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
+        ProfScope prof(split ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
-        if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        if (split) {
+            const dim3 grid((unsigned)(8 * p.per_xcd), B);
+            const bool trw = p.w_so == 1 && p.w_si != 1;
+#define UNO_CMS(BF_, TR_, XP_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, XP_>), grid, dim3(256), 0, s, p)
+#ifdef UNO_CMS_DEV          // development build: knock-out / stamp instantiations (f32 activations) selected by UNO_CMS_EXP
+#define UNO_CMS_X(XP_) case XP_: if (trw) UNO_CMS(false, true, XP_); else UNO_CMS(false, false, XP_); break;
+            if (!bf16 && cms_exp) {
+                switch (cms_exp) {
+                    UNO_CMS_X(1) UNO_CMS_X(2) UNO_CMS_X(4) UNO_CMS_X(6) UNO_CMS_X(8) UNO_CMS_X(16) UNO_CMS_X(31) UNO_CMS_X(64) UNO_CMS_X(70)
+                    default: if (trw) UNO_CMS(false, true, 0); else UNO_CMS(false, false, 0);
+                }
+            } else
+#undef UNO_CMS_X
+#endif
+            if (bf16) { if (trw) UNO_CMS(true, true, 0); else UNO_CMS(true, false, 0); }
+            else { if (trw) UNO_CMS(false, true, 0); else UNO_CMS(false, false, 0); }
+#undef UNO_CMS
+        }
+        else if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
