@@ -288,10 +288,11 @@ def extra_workloads(dev):
         tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
         a, u = synthetic_darcy_batch(BATCH, S, 1234, dev)
         ms = _train_ms(lambda: tr.step(a, u), dev)
-        return {"spectral_kernels": spectral_names(lambda: tr.step(a, u)),
-                "config": "UNO_9(3,64,pad=5) 421^2 batch 16 driven as darcy_flow_uno2d.py:94-133 drives it (channels-last nn.Linear, "
-                          "F.gelu, permute, F.pad, torch.cat, host-built grid) on the product operator blocks",
-                "ms_per_step": ms, "samples_per_s": BATCH / ms * 1e3}
+        res = {"spectral_kernels": spectral_names(lambda: tr.step(a, u)),
+               "config": "UNO_9(3,64,pad=5) 421^2 batch 16 driven as darcy_flow_uno2d.py:94-133 drives it (channels-last nn.Linear, "
+                         "F.gelu, permute, F.pad, torch.cat, host-built grid) on the product operator blocks",
+               "ms_per_step": ms, "samples_per_s": BATCH / ms * 1e3}
+        return res
 
     def ns2d():
         torch.manual_seed(0)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 7
+#define UNO_SPECTRAL_ABI_VERSION 8
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -324,6 +324,18 @@ int uno_instnorm_backward_bf16(const void* x, const void* gy, const float* gamma
  * free it on the same stream).  A call that needs more than was provided fails with -6 and a message naming the size. */
 long long uno_dft2d_any_ws_bytes(int n_img, int H, int W, int m1, int m2);
 int uno_scratch_provide(void* ptr, long long bytes);
+
+/* Batched transposing copy between the channels-last and the channels-first layout of an activation (ABI 8):
+ *   out[b][c][r] = in[b][r][c],   b < B, r < R, c < C
+ * in: R rows of C contiguous floats at pitch ld_in >= C, batch stride sb_in; out: C rows of R contiguous floats at pitch
+ * ld_out >= R, batch stride sb_out (pitches and strides in floats).  The reference's blocks accept any strides because they go
+ * through torch.fft / F.conv (integral_operators.py:187, 233); its model files hand the first block a channels-last tensor
+ * (darcy_flow_uno2d.py:104-107: `permute` of the nn.Linear lift + F.pad; navier_stokes_uno3d.py:316-318) and their autograd
+ * graph hands channels-last gradients back.  The kernels of this library read channels-first images, so the host side converts
+ * with this entry point (R = pixels, C = channels: NHWC -> NCHW; R = channels, C = pixels: NCHW -> NHWC) instead of a generic
+ * strided copy. */
+int uno_transpose_batched(const float* in, float* out, int B, long long R, int C, long long ld_in, long long sb_in,
+                          long long ld_out, long long sb_out, void* stream);
 
 /* Optional in-library kernel timing (HIP events recorded on the launch stream around every kernel
  * this library enqueues), used by bench.py for the live roofline figure.

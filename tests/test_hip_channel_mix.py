@@ -430,3 +430,50 @@ def test_split_bf16_wide_layers_bf16_activations():
     # the products are exact to ~1e-7; what remains is the bf16 rounding of the result
     assert rel(y.float(), ref) < 3e-3
     assert rel(y.float(), ref.float().to(torch.bfloat16).double()) < 1e-3
+
+
+# K9-S (channel_wgrad_split_kernel): both channel counts >= 96 - three-piece bf16 operands on the bf16 MFMA, 128 x 128 weight tiles.
+# Shapes: full tiles, partial tiles in both directions, rows ending inside a 32-pixel half chunk, inside a 4-pixel group, pixel counts
+# that leave the second half of the last 64-pixel chunk empty, the model's layers (fc1: 64 + 32 -> 128 with GELU-on-read; 256 x 256).
+WIDE_WGRAD = [  # B, C1, C2, Co, P, act_x
+    (2, 128, 0, 128, 640, False), (3, 256, 0, 256, 12321 // 9, False), (2, 96, 0, 130, 77, False), (1, 130, 0, 96, 64 + 31, True),
+    (2, 64, 32, 128, 446 * 3 + 1, True), (2, 64, 32, 128, 1000, False), (1, 128, 128, 128, 96, False), (2, 64, 64, 100, 200, True),
+    (1, 257, 0, 129, 130, False),
+]
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P,act_x", WIDE_WGRAD)
+def test_wide_wgrad_split_bf16(B, C1, C2, Co, P, act_x):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + C2 + Co + P)
+    gy = torch.randn(B, Co, P, generator=g).cuda()
+    x1 = torch.randn(B, C1, P, generator=g).cuda()
+    x2 = torch.randn(B, C2, P, generator=g).cuda() if C2 else None
+    _native.profile_begin(64)
+    gw, gb = _native.channel_wgrad2(gy, x1, x2, act_x=act_x)
+    torch.cuda.synchronize()
+    names = {n for n, _, _ in _native.profile_end()}
+    assert "uno::channel_wgrad_split_kernel" in names, names
+    xs = [_gelu64(x1) if act_x else x1.double()] + ([x2.double()] if C2 else [])
+    xc = torch.cat(xs, 1)
+    assert gw.shape == (Co, C1 + C2)
+    # the six-product split is MORE accurate than the f32 MFMA form (profiles/r04_split_bf16_error.txt): same bound as the narrow layers
+    assert rel(gw, torch.einsum("bop,bip->oi", gy.double(), xc)) < 2e-6
+    assert rel(gb, gy.double().sum(dim=(0, 2))) < 2e-6
+    gw2, _ = _native.channel_wgrad2(gy, x1, x2, act_x=act_x)
+    assert torch.equal(gw, gw2)                                     # fixed-order reduction: bit-reproducible
+
+
+def test_wide_wgrad_red_zone():
+    """the partial-sum workspace of the split form is sized by the same plan the kernel follows: nothing is written past it"""
+    from uno_amd import _native
+    B, Ci, Co, P = 2, 96, 130, 333
+    gy, x = torch.randn(B, Co, P, device="cuda"), torch.randn(B, Ci, P, device="cuda")
+    nf = _native.channel_wgrad_partial_floats(B, Ci, Co, P)
+    raw = torch.full((nf + 2048,), 3.25, device="cuda")
+    parts = raw[1024:1024 + nf]
+    assert _native.channel_wgrad2(gy, x, None, partials_out=parts) == (None, None)
+    torch.cuda.synchronize()
+    assert bool((raw[:1024] == 3.25).all()) and bool((raw[1024 + nf:] == 3.25).all())
+    gw, gb = _native.channel_wgrad_finish(parts.view(1, -1), Ci, Co, True)
+    assert rel(gw, torch.einsum("bop,bip->oi", gy.double(), x.double())) < 2e-6 and rel(gb, gy.double().sum(dim=(0, 2))) < 2e-6

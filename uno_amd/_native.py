@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 _lock = threading.Lock()
@@ -61,6 +61,7 @@ _SIGNATURES = {
     "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
     "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
     "uno_gelu_pad": (C.c_int, [_fp, _fp, _fp] + [_i] * 6 + [_fp]),
+    "uno_transpose_batched": (C.c_int, [_fp, _fp, _i, C.c_longlong, _i] + [C.c_longlong] * 4 + [_fp]),
     "uno_instnorm_forward": (C.c_int, [_fp] * 6 + [C.c_longlong, _i, C.c_longlong, C.c_float, _i, _fp]),
     "uno_instnorm_backward": (C.c_int, [_fp] * 9 + [C.c_longlong, _i, C.c_longlong, _i, _fp]),
     "uno_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, _i] + [C.c_double] * 5 + [_i, _fp]),
@@ -157,6 +158,13 @@ def _require(t: torch.Tensor, dtype, name: str):
         raise RuntimeError(f"uno_amd: {name} must be {dtype} (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError(f"uno_amd: {name} must be contiguous")
+
+
+def _require_dev(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"uno_amd: {name} must live on a HIP device (got {t.device})")
+    if t.dtype != dtype:
+        raise RuntimeError(f"uno_amd: {name} must be {dtype} (got {t.dtype})")
 
 
 def _act_dtype(t, name):
@@ -751,6 +759,39 @@ def gelu_pad_backward(s, gy):
     with torch.cuda.device(s.device):
         rc = (lib().uno_gelu_pad_bf16 if bf16 else lib().uno_gelu_pad)(_ptr(s), _ptr(gy), _ptr(out), n, H, W, Hp, Wp, 1, _stream(s))
     _check(rc, "uno_gelu_pad")
+    return out
+
+
+def channels_last_pitch(t):
+    """(pitch, batch stride) in elements if `t` (B, C, *grid) is stored channels-LAST - unit stride over the channels, the grid
+    points dense at one common pitch >= C (a channel slice of a wider channels-last tensor qualifies), any batch stride - else None."""
+    if t.dim() < 3 or t.shape[1] < 2 or t.stride(1) != 1:
+        return None
+    ld = t.stride(-1)
+    if ld < t.shape[1]:
+        return None
+    run = ld
+    for d in range(t.dim() - 1, 1, -1):
+        if t.shape[d] != 1 and t.stride(d) != run:
+            return None
+        run *= t.shape[d]
+    if t.shape[0] > 1 and t.stride(0) < (run // ld - 1) * ld + t.shape[1]:
+        return None
+    return ld, t.stride(0)
+
+
+def to_channels_first(t):
+    """A channels-last f32 activation (see channels_last_pitch) as a contiguous (B, C, *grid) tensor, by the tiled transposing copy."""
+    _require_dev(t, torch.float32, "activation")
+    ld, sb = channels_last_pitch(t)
+    B, Cc = t.shape[:2]
+    P = 1
+    for d in t.shape[2:]:
+        P *= d
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    with torch.cuda.device(t.device):
+        rc = lib().uno_transpose_batched(_ptr(t), _ptr(out), B, P, Cc, ld, sb if B > 1 else 0, P, Cc * P, _stream(t))
+    _check(rc, "uno_transpose_batched")
     return out
 
 

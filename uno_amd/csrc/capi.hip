@@ -596,6 +596,17 @@ int uno_gelu_pad_bf16(const void* s, const void* gy, void* out, int n_img, int H
     return gelu_pad_impl(s, gy, out, n_img, H, W, Hp, Wp, backward, 1, stream);
 }
 
+int uno_transpose_batched(const float* in, float* out, int B, long long R, int C, long long ld_in, long long sb_in, long long ld_out,
+                          long long sb_out, void* stream) {
+    if (B < 0 || R < 0 || C < 0 || ld_in < C || ld_out < R || sb_in < 0 || sb_out < 0) {
+        set_error("uno_transpose_batched: bad sizes (B %d, R %lld, C %d, pitches %lld / %lld)", B, R, C, ld_in, ld_out);
+        return -1;
+    }
+    if (B == 0 || R == 0 || C == 0) return 0;
+    if (!in || !out) { set_error("uno_transpose_batched: null pointer"); return -1; }
+    return launch_transpose_batched(in, out, B, R, C, ld_in, sb_in, ld_out, sb_out, (hipStream_t)stream);
+}
+
 static int instnorm_forward_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
                                  long long N, float eps, int gelu, int bf16, void* stream) {
     if (rows < 0 || C < 1 || N < 1 || (rows % C) != 0) { set_error("uno_instnorm_forward: bad sizes rows=%lld C=%d N=%lld", rows, C, N); return -1; }

@@ -1142,6 +1142,200 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K9-S
+// The weight gradient of the wide layers (both channel counts >= 96) on the bf16 matrix pipe with both operands split into three
+// bfloat16 pieces - the arrangement of K8-S (six products, f32 accumulation, ~1e-7 relative: profiles/r04_split_bf16_error.txt).
+// Why: gW = sum over 16 x P pixels of gY X^T has Co x Ci outputs for 4 (Co + Ci) bytes per pixel - 2 Co Ci / (4 (Co + Ci)) flop/B =
+// 64 at 256 x 256, 27 at 96 x 128 (fc1) - against the f32 ridge of 20: the vector kernel above ran these layers at 1.5-3.6 TB/s,
+// i.e. at the f32 MFMA peak (256 x 256 at 111^2: 25.8 GFLOP, 258 us; fc1 at 446^2: 78 GFLOP, 673 us for 2.44 GB).
+//   * workgroup = (32 MR) x 128 weight tile x one split of the pixels, MR = 4 (Co >= 96) or 2 (Co <= 64 .. 95: fc1 128 -> 64, conv5's
+//     256 -> 64); wave (a, b) owns output channels 16 MR a .. x input channels 64 b .. + 63 = MR x 4 accumulator tiles; K = pixels,
+//     staged 32 at a time;
+//   * BOTH operands have their k axis (pixels) contiguous in memory, so the MFMA operand of a lane - 8 consecutive k of one row - is
+//     16 contiguous bytes of an LDS row: planes [piece][row: 128 gY + 128 X][32 px] of bf16, rows 80 bytes apart (the 16 rows of a
+//     fragment read cover the 64 banks once), one ds_read_b128 per fragment and piece, no transposing reads;
+//   * the split happens once per element, in the thread that stages it (as K8-S); the next 32 pixels are in flight in registers
+//     while the current ones are multiplied; 60 KB of LDS, two workgroups per CU.
+// Partial sums leave in the (split, Co, Ci + 1) layout of the other first-stage kernels; the second stage is shared.
+constexpr int CWS_T = 128;
+constexpr int CWS_PK = 32;
+constexpr int CWS_RS = CWS_PK * 2 + 16;             // bytes per row of a plane
+constexpr int CWS_PLANE = 2 * CWS_T * CWS_RS;       // 20 480
+
+static bool wgrad_split_shape(int Ci, int Co, long long P) {
+    static const bool off = getenv("UNO_CW_SPLIT_OFF") != nullptr;         // development: A/B against the f32-MFMA form
+    return !off && Ci >= 96 && Co >= 48 && P >= 64;
+}
+static int wgrad_split_rows(int Co) { return Co >= 96 ? CWS_T : 64; }      // output channels per weight tile
+
+// BF: bfloat16 activations (exact in ONE piece: gY x X is one product; with the GELU applied on read, gelu(x) is an f32 value again: three
+// pieces of X against the one of gY)
+template <bool ACTX, int MR, bool BF>
+__global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * CWS_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wb = wave >> 1;
+    const int ntile_i = (p.Ci + CWS_T - 1) / CWS_T;
+    constexpr int TO = 32 * MR;                                     // output channels per tile
+    using T = typename IoElem<BF>::type;
+    constexpr int ES = BF ? 2 : 4;
+    constexpr int NPG = BF ? 1 : 3, NPX = (BF && !ACTX) ? 1 : 3;    // bf16 pieces of the two operands
+    const int ntile = ((p.Co + TO - 1) / TO) * ntile_i;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;            // all weight tiles of one pixel split on one XCD (as the vector kernel)
+    const int split = (j / ntile) * 8 + xcd, tile = j % ntile;
+    if (split >= p.nsplit) return;
+    const int o0 = (tile / ntile_i) * TO, i0 = (tile % ntile_i) * CWS_T;
+    const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, p.B * npc);
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int c4 = (tid & 7) * 4, row0 = tid >> 3;                  // a thread stages four pixels of rows row0 + 32 u of both operands
+    // the 32 input channels of band u lie in one source (C1 % 32 == 0 in two-source calls)
+    const T* xsrc[4];
+    int xcs[4], xrow[4];
+    bool xact[4], xok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ci = i0 + 32 * u;
+        const bool s2 = ci >= p.C1;
+        xsrc[u] = reinterpret_cast<const T*>(s2 ? p.x2 : p.x);
+        xcs[u] = s2 ? p.Ci - p.C1 : p.C1;
+        const int il = (s2 ? ci - p.C1 : ci) + row0;
+        xok[u] = ci + row0 < p.Ci;
+        xrow[u] = min(il, xcs[u] - 1);
+        xact[u] = ACTX && !s2;
+        if (ci >= p.Ci) { xsrc[u] = reinterpret_cast<const T*>(p.x); xcs[u] = p.C1; xrow[u] = 0; }
+    }
+    float4 rg[4], rxv[4];
+    int sh_cur = 0;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_half = [&](int it) {                                  // half chunk it: 32 pixels of chunk it >> 1
+        const int idx = it >> 1;
+        const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto widen = [](const u32x2& t) {
+            return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+        };
+        const int px = pp + c4, pc = min(px, p.P - 4);
+        sh_cur = px - pc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * p.P), 0, xcs[u] * p.P * ES, 0x00020000);
+            if constexpr (BF) {
+                if (u < MR) rg[u] = widen(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 2, 0, 0));
+                rxv[u] = widen(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * p.P + pc) * 2, 0, 0));
+            } else {
+                if (u < MR) {
+                    const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 4, 0, 0);
+                    rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
+                }
+                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * p.P + pc) * 4, 0, 0);
+                rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
+            }
+        }
+    };
+    auto shifted = [&](const float4& v, bool valid) {               // zero fill past the row end / past the channel count (see the vector kernel)
+        float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
+        if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
+        if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
+        if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
+        return make_float4(t0, t1, t2, t3);
+    };
+    auto put1 = [&](char* d, const float4& v) {                    // widened bf16 values: exact in one piece
+        *reinterpret_cast<uint2*>(d) = make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w));
+    };
+    auto put3 = [&](char* d, const float4& v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        cms_split3(v.x, v.y, h0, m0, l0);
+        cms_split3(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + CWS_PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 2 * CWS_PLANE) = make_uint2(l0, l1);
+    };
+    auto store_half = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 32 * u;
+            if (u < MR) {
+                const float4 g = shifted(rg[u], o0 + row < p.Co);
+                if constexpr (NPG == 1) put1(smem + row * CWS_RS + c4 * 2, g); else put3(smem + row * CWS_RS + c4 * 2, g);
+                bs[u] += (g.x + g.y) + (g.z + g.w);
+            }
+            float4 v = shifted(rxv[u], xok[u]);
+            if constexpr (ACTX) { if (xact[u]) v = cm_gelu4(v); }   // gelu(0) = 0: the zero fill survives
+            if constexpr (NPX == 1) put1(smem + (CWS_T + row) * CWS_RS + c4 * 2, v); else put3(smem + (CWS_T + row) * CWS_RS + c4 * 2, v);
+        }
+    };
+
+    f32x4 acc[MR][4];                   // [output-channel tile m][input-channel tile t]
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
+    const char* abase = smem + (16 * MR * wa + r16) * CWS_RS + 16 * kk;
+    const char* bbase = smem + (CWS_T + 64 * wb + r16) * CWS_RS + 16 * kk;
+    auto compute = [&]() {
+        cms_u32x4 A[MR][NPG];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int pl = 0; pl < NPG; ++pl) A[m][pl] = *reinterpret_cast<const cms_u32x4*>(abase + pl * CWS_PLANE + m * 16 * CWS_RS);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            cms_u32x4 Bp[NPX];
+#pragma unroll
+            for (int pl = 0; pl < NPX; ++pl) Bp[pl] = *reinterpret_cast<const cms_u32x4*>(bbase + pl * CWS_PLANE + t * 16 * CWS_RS);
+            // products (i, j) with i + j <= 2, smallest first; the MR row tiles between two uses of an accumulator
+#pragma unroll
+            for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+                for (int i = NPG - 1; i >= 0; --i) {
+                    const int jx = sum - i;
+                    if (jx < 0 || jx >= NPX) continue;
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) acc[m][t] = cms_mfma(A[m][i], Bp[jx], acc[m][t]);
+                }
+        }
+    };
+
+    const int it_begin = 2 * c_begin, it_end = 2 * c_end;
+    if (it_begin < it_end) load_half(it_begin);
+    for (int it = it_begin; it < it_end; ++it) {
+        store_half();                   // (waits for the half chunk's loads)
+        __syncthreads();
+        load_half(min(it + 1, it_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+
+    float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 16 * MR * wa + 16 * m + 4 * kk + r;
+            if (o < p.Co) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = i0 + 64 * wb + 16 * t + r16;
+                    if (i < p.Ci) part[(size_t)o * (p.Ci + 1) + i] = acc[m][t][r];
+                }
+            }
+        }
+    if (i0 == 0) {          // bias gradient: the 8 threads that share a row hold its partial sums
+#pragma unroll
+        for (int u = 0; u < MR; ++u) {
+            float v = bs[u];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            const int o = o0 + row0 + 32 * u;
+            if ((tid & 7) == 0 && o < p.Co) part[(size_t)o * (p.Ci + 1) + p.Ci] = v;
+        }
+    }
+}
+
 // Weight gradient with few input channels (CI <= 4): a thread owns four pixels at a time and accumulates its 16 output channels x
 // (CI + 1) sums in registers over the pixels of its split (the + 1: the bias gradient); fixed-order reduction inside the workgroup
 // (butterfly within a wave, the four waves through LDS in order), then the usual partials (split, Co, Ci + 1) for the reduce kernel.
@@ -1245,6 +1439,11 @@ static void wgrad_plan(int B, int Ci, int Co, long long P, int* nsplit, int* npc
     *npc = (int)((P + *pk - 1) / *pk);
     const long long nchunks = (long long)B * *npc;
     long long want = (1024 + tiles - 1) / tiles;
+    if (wgrad_split_shape(Ci, Co, P)) {             // K9-S: 128 x 128 weight tiles, two resident workgroups per CU = 512
+        const int to = wgrad_split_rows(Co);
+        const int tiles_s = ((Co + to - 1) / to) * ((Ci + CWS_T - 1) / CWS_T);
+        want = (512 + tiles_s - 1) / tiles_s;
+    }
     long long per = (nchunks + want - 1) / want;
     if (per < 4) per = 4;
     *cps = (int)per;
@@ -1296,10 +1495,22 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
         if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
     }
+    static const bool split_bf = getenv("UNO_CW_SPLIT_BF") != nullptr;      // bf16 activations: opt-in until measured
+    const bool split_form = wgrad_split_shape(Ci, Co, P) && (!bf16 || split_bf) && pk == CWV_PK && (!x2 || C1 % 32 == 0);
     {
-        ProfScope prof(pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
+        ProfScope prof(split_form ? "uno::channel_wgrad_split_kernel" : pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel",
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
         const dim3 gv(8 * tiles * ((p.nsplit + 7) / 8));
-        if (pk == CWV_PK && act_x) {
+        if (split_form) {
+            const int to = wgrad_split_rows(Co);
+            const int tiles_s = ((Co + to - 1) / to) * ((Ci + CWS_T - 1) / CWS_T);
+            const dim3 gs(8 * tiles_s * ((p.nsplit + 7) / 8));
+#define UNO_CWS(A_, M_) do { if (bf16) hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, true>), gs, dim3(256), 0, s, p, npc, cps); \
+                             else hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, false>), gs, dim3(256), 0, s, p, npc, cps); } while (0)
+            if (to == CWS_T) { if (act_x) UNO_CWS(true, 4); else UNO_CWS(false, 4); }
+            else { if (act_x) UNO_CWS(true, 2); else UNO_CWS(false, 2); }
+#undef UNO_CWS
+        } else if (pk == CWV_PK && act_x) {
             if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, true>), gv, dim3(256), 0, s, p, npc, cps);
             else hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false>), gv, dim3(256), 0, s, p, npc, cps);
         } else if (pk == CWV_PK) {

@@ -293,4 +293,84 @@ int launch_gelu_pad(const void* s, const void* gy, void* out, int n_img, int H, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ K14
+// Batched transposing copy  out[b][c][r] = in[b][r][c]  between the two layouts an activation reaches an operator block in:
+// channels-first (what every kernel of this library reads and writes) and channels-last - what the reference's model files
+// hand over when they `permute` the output of a channels-last nn.Linear (darcy_flow_uno2d.py:104-107: permute + F.pad gives
+// conv0 an NHWC tensor) and what their autograd graph hands back.  torch's own strided copy moves the 407 MB lift output of
+// the 421^2 Darcy model in 3.9 ms (0.2 TB/s: one 4-byte element per lane, 128-byte strides between lanes); this kernel
+// stages 64 x 64 tiles in LDS so that both sides move whole 256-byte row segments.
+// in: R rows of C contiguous floats at pitch ld_in;  out: C rows of R contiguous floats at pitch ld_out.
+template <bool VIN, bool VOUT>
+__global__ __launch_bounds__(256) void transpose_tile_kernel(const float* __restrict__ in, float* __restrict__ out, long long R, int C,
+                                                             long long ld_in, long long sb_in, long long ld_out, long long sb_out) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const float* src = in + (size_t)blockIdx.z * sb_in;
+    float* dst = out + (size_t)blockIdx.z * sb_out;
+    const int q = (t & 15) * 4, rr = t >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rr + 16 * i;
+        const long long gr = r0 + r;
+        const int gc = c0 + q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gr < R && gc < C) {
+            const float* row = src + (size_t)gr * ld_in + gc;
+            if (VIN && gc + 3 < C) {
+                const float4 w = *reinterpret_cast<const float4*>(row);
+                v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gc + e < C) v[e] = row[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][q + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = rr + 16 * i;
+        const int gc = c0 + c;
+        const long long gr = r0 + q;
+        if (gc < C && gr < R) {
+            float* row = dst + (size_t)gc * ld_out + gr;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tile[q + e][c];
+            if (VOUT && gr + 3 < R) {
+                *reinterpret_cast<float4*>(row) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gr + e < R) row[e] = v[e];
+            }
+        }
+    }
+}
+
+int launch_transpose_batched(const float* in, float* out, int B, long long R, int C, long long ld_in, long long sb_in, long long ld_out,
+                             long long sb_out, hipStream_t st) {
+    if (B == 0 || R == 0 || C == 0) return 0;
+    const long long tr = (R + 63) / 64;
+    const int tc = (C + 63) / 64;
+    if (B > 65535 || tc > 65535 || tr > 0x7fffffffLL) { set_error("transpose_batched: at most 65535 batch entries and 4 M columns"); return -2; }
+    ProfScope prof("uno::transpose_tile_kernel", 8.0 * B * (double)R * C, st);
+    // 16-byte accesses where every row starts on a 16-byte boundary
+    const bool vin = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (ld_in & 3) == 0 && (sb_in & 3) == 0;
+    const bool vout = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (ld_out & 3) == 0 && (sb_out & 3) == 0;
+    const dim3 grid((unsigned)tr, (unsigned)tc, (unsigned)B);
+#define UNO_TR_LAUNCH(A_, B_) hipLaunchKernelGGL((transpose_tile_kernel<A_, B_>), grid, dim3(256), 0, st, in, out, R, C, ld_in, sb_in, ld_out, sb_out)
+    if (vin && vout) UNO_TR_LAUNCH(true, true);
+    else if (vin) UNO_TR_LAUNCH(true, false);
+    else if (vout) UNO_TR_LAUNCH(false, true);
+    else UNO_TR_LAUNCH(false, false);
+#undef UNO_TR_LAUNCH
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("transpose_batched launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
 }  // namespace uno

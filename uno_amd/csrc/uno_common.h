@@ -258,6 +258,8 @@ long long gelu_project_ws_floats(int B, int C, long long P);
 int launch_gelu_project_bwd(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, float* ws, int B,
                             int C, long long P, int bf16, hipStream_t s);
 int launch_gelu_pad(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward, int bf16, hipStream_t st);
+int launch_transpose_batched(const float* in, float* out, int B, long long R, int C, long long ld_in, long long sb_in, long long ld_out,
+                             long long sb_out, hipStream_t st);
 int launch_instnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
                         long long N, float eps, int gelu, int bf16, hipStream_t s);
 int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const float* beta, const float* mean, const float* rstd,

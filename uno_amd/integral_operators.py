@@ -90,6 +90,12 @@ def _plain(t: torch.Tensor) -> torch.Tensor:
         t = t.resolve_conj()
     if t.is_neg():
         t = t.resolve_neg()
+    if t.is_contiguous():
+        return t
+    # channels-last activations and gradients (what the reference's model files hand over: darcy_flow_uno2d.py:104-107, :126) go
+    # through the tiled transposing copy; every other layout through torch's strided copy
+    if t.is_cuda and t.dtype == torch.float32 and _native.channels_last_pitch(t) is not None:
+        return _native.to_channels_first(t)
     return t.contiguous()
 
 
