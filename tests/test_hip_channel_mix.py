@@ -464,6 +464,26 @@ def test_wide_wgrad_split_bf16(B, C1, C2, Co, P, act_x):
     assert torch.equal(gw, gw2)                                     # fixed-order reduction: bit-reproducible
 
 
+@pytest.mark.parametrize("B,C1,C2,Co,P,act_x", WIDE_WGRAD)
+def test_wide_wgrad_split_bf16_activations(B, C1, C2, Co, P, act_x):
+    """bf16 activations: both operands are exact in ONE bf16 piece (one product); with GELU-on-read, gelu(x) is an f32 value again and is
+    split into three.  Reference: float64 on the same bf16 values."""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + C2 + Co + P + 1)
+    gy = torch.randn(B, Co, P, generator=g).bfloat16().cuda()
+    x1 = torch.randn(B, C1, P, generator=g).bfloat16().cuda()
+    x2 = torch.randn(B, C2, P, generator=g).bfloat16().cuda() if C2 else None
+    _native.profile_begin(64)
+    gw, gb = _native.channel_wgrad2(gy, x1, x2, act_x=act_x)
+    torch.cuda.synchronize()
+    names = {n for n, _, _ in _native.profile_end()}
+    assert "uno::channel_wgrad_split_kernel" in names, names
+    xs = [_gelu64(x1.float()) if act_x else x1.double()] + ([x2.double()] if C2 else [])
+    assert gw.dtype == torch.float32 and gw.shape == (Co, C1 + C2)
+    assert rel(gw, torch.einsum("bop,bip->oi", gy.double(), torch.cat(xs, 1))) < 2e-6
+    assert rel(gb, gy.double().sum(dim=(0, 2))) < 2e-6
+
+
 def test_wide_wgrad_red_zone():
     """the partial-sum workspace of the split form is sized by the same plan the kernel follows: nothing is written past it"""
     from uno_amd import _native

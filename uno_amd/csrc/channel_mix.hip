@@ -1206,37 +1206,35 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         xact[u] = ACTX && !s2;
         if (ci >= p.Ci) { xsrc[u] = reinterpret_cast<const T*>(p.x); xcs[u] = p.C1; xrow[u] = 0; }
     }
-    float4 rg[4], rxv[4];
-    int sh_cur = 0;
+    // two half chunks in flight (register sets 0 / 1): with one, the loads had the 96 MFMAs of ONE half (~0.8 us) to arrive in and the
+    // wave waited for them at every store (256 x 256 at 111^2: 173 us at 45 % MFMA-pipe use)
+    u32x4 rgs[2][4], rxs[2][4];                                     // RAW loaded pieces: anything computed from them at load time makes the wave wait for its loads at once
+    int shs[2] = {0, 0};
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    auto load_half = [&](int it) {                                  // half chunk it: 32 pixels of chunk it >> 1
+    auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur) {     // half chunk it: 32 pixels of chunk it >> 1
         const int idx = it >> 1;
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
         const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        auto widen = [](const u32x2& t) {
-            return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
-        };
+        auto raw2 = [](const u32x2& t) { return u32x4{t.x, t.y, 0u, 0u}; };
         const int px = pp + c4, pc = min(px, p.P - 4);
         sh_cur = px - pc;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * p.P), 0, xcs[u] * p.P * ES, 0x00020000);
             if constexpr (BF) {
-                if (u < MR) rg[u] = widen(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 2, 0, 0));
-                rxv[u] = widen(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * p.P + pc) * 2, 0, 0));
+                if (u < MR) rg[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 2, 0, 0));
+                rxv[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * p.P + pc) * 2, 0, 0));
             } else {
-                if (u < MR) {
-                    const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 4, 0, 0);
-                    rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
-                }
-                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * p.P + pc) * 4, 0, 0);
-                rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
+                if (u < MR) rg[u] = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 4, 0, 0);
+                rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * p.P + pc) * 4, 0, 0);
             }
         }
     };
-    auto shifted = [&](const float4& v, bool valid) {               // zero fill past the row end / past the channel count (see the vector kernel)
-        float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
+    auto shifted = [&](const u32x4& r, bool valid, int sh_cur) {    // zero fill past the row end / past the channel count (see the vector kernel)
+        float t0, t1, t2, t3;
+        if constexpr (BF) { t0 = __uint_as_float(r.x << 16); t1 = __uint_as_float(r.x & 0xffff0000u); t2 = __uint_as_float(r.y << 16); t3 = __uint_as_float(r.y & 0xffff0000u); }
+        else { t0 = __uint_as_float(r.x); t1 = __uint_as_float(r.y); t2 = __uint_as_float(r.z); t3 = __uint_as_float(r.w); }
         if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
         if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
         if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
@@ -1253,16 +1251,16 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         *reinterpret_cast<uint2*>(d + CWS_PLANE) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(d + 2 * CWS_PLANE) = make_uint2(l0, l1);
     };
-    auto store_half = [&]() {
+    auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 32 * u;
             if (u < MR) {
-                const float4 g = shifted(rg[u], o0 + row < p.Co);
+                const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur);
                 if constexpr (NPG == 1) put1(smem + row * CWS_RS + c4 * 2, g); else put3(smem + row * CWS_RS + c4 * 2, g);
                 bs[u] += (g.x + g.y) + (g.z + g.w);
             }
-            float4 v = shifted(rxv[u], xok[u]);
+            float4 v = shifted(rxv[u], xok[u], sh_cur);
             if constexpr (ACTX) { if (xact[u]) v = cm_gelu4(v); }   // gelu(0) = 0: the zero fill survives
             if constexpr (NPX == 1) put1(smem + (CWS_T + row) * CWS_RS + c4 * 2, v); else put3(smem + (CWS_T + row) * CWS_RS + c4 * 2, v);
         }
@@ -1299,16 +1297,24 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         }
     };
 
-    const int it_begin = 2 * c_begin, it_end = 2 * c_end;
-    if (it_begin < it_end) load_half(it_begin);
-    for (int it = it_begin; it < it_end; ++it) {
-        store_half();                   // (waits for the half chunk's loads)
-        __syncthreads();
-        load_half(min(it + 1, it_end - 1));
+    const int it_begin = 2 * c_begin, it_end = 2 * c_end;          // an even number of half chunks
+    if (it_begin < it_end) {
+        load_half(it_begin, rgs[0], rxs[0], shs[0]);
+        __builtin_amdgcn_sched_barrier(0);          // set 0's loads strictly before set 1's: the loop's vmcnt waits are derived from BOTH orders
+        load_half(it_begin + 1, rgs[1], rxs[1], shs[1]);
         __builtin_amdgcn_sched_barrier(0);
-        compute();
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+    }
+    for (int it = it_begin; it < it_end; it += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            store_half(rgs[h], rxs[h], shs[h]);                     // (waits for this half chunk's loads only: vmcnt counts the other set's)
+            __syncthreads();
+            load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], shs[h]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
     }
 
     float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
@@ -1495,8 +1501,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
         if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
     }
-    static const bool split_bf = getenv("UNO_CW_SPLIT_BF") != nullptr;      // bf16 activations: opt-in until measured
-    const bool split_form = wgrad_split_shape(Ci, Co, P) && (!bf16 || split_bf) && pk == CWV_PK && (!x2 || C1 % 32 == 0);
+    const bool split_form = wgrad_split_shape(Ci, Co, P) && pk == CWV_PK && (!x2 || C1 % 32 == 0);
     {
         ProfScope prof(split_form ? "uno::channel_wgrad_split_kernel" : pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
