@@ -1210,8 +1210,12 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     // wave waited for them at every store (256 x 256 at 111^2: 173 us at 45 % MFMA-pipe use)
     u32x4 rgs[2][4], rxs[2][4];                                     // RAW loaded pieces: anything computed from them at load time makes the wave wait for its loads at once
     int shs[2] = {0, 0};
+    // the zero fill past the row end / past the channel counts is needed only in the last half chunk of a row and in partial weight
+    // tiles - both wave-uniform; everywhere else the staged values go straight to the split (12 of 34 VALU instructions per four values)
+    bool tails[2] = {false, false};
+    const bool edge = o0 + TO > p.Co || i0 + CWS_T > p.Ci;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur) {     // half chunk it: 32 pixels of chunk it >> 1
+    auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur, bool& tail) {     // half chunk it: 32 pixels of chunk it >> 1
         const int idx = it >> 1;
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
         const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
@@ -1219,6 +1223,7 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         auto raw2 = [](const u32x2& t) { return u32x4{t.x, t.y, 0u, 0u}; };
         const int px = pp + c4, pc = min(px, p.P - 4);
         sh_cur = px - pc;
+        tail = pp + CWS_PK > p.P;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * p.P), 0, xcs[u] * p.P * ES, 0x00020000);
@@ -1231,13 +1236,15 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
             }
         }
     };
-    auto shifted = [&](const u32x4& r, bool valid, int sh_cur) {    // zero fill past the row end / past the channel count (see the vector kernel)
+    auto shifted = [&](const u32x4& r, bool valid, int sh_cur, bool slow) {    // slow: zero fill past the row end / past the channel count (see the vector kernel)
         float t0, t1, t2, t3;
         if constexpr (BF) { t0 = __uint_as_float(r.x << 16); t1 = __uint_as_float(r.x & 0xffff0000u); t2 = __uint_as_float(r.y << 16); t3 = __uint_as_float(r.y & 0xffff0000u); }
         else { t0 = __uint_as_float(r.x); t1 = __uint_as_float(r.y); t2 = __uint_as_float(r.z); t3 = __uint_as_float(r.w); }
-        if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
-        if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
-        if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
+        if (slow) {
+            if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
+            if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
+            if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
+        }
         return make_float4(t0, t1, t2, t3);
     };
     auto put1 = [&](char* d, const float4& v) {                    // widened bf16 values: exact in one piece
@@ -1251,16 +1258,16 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         *reinterpret_cast<uint2*>(d + CWS_PLANE) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(d + 2 * CWS_PLANE) = make_uint2(l0, l1);
     };
-    auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur) {
+    auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur, bool slow) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 32 * u;
             if (u < MR) {
-                const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur);
+                const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur, slow);
                 if constexpr (NPG == 1) put1(smem + row * CWS_RS + c4 * 2, g); else put3(smem + row * CWS_RS + c4 * 2, g);
                 bs[u] += (g.x + g.y) + (g.z + g.w);
             }
-            float4 v = shifted(rxv[u], xok[u], sh_cur);
+            float4 v = shifted(rxv[u], xok[u], sh_cur, slow);
             if constexpr (ACTX) { if (xact[u]) v = cm_gelu4(v); }   // gelu(0) = 0: the zero fill survives
             if constexpr (NPX == 1) put1(smem + (CWS_T + row) * CWS_RS + c4 * 2, v); else put3(smem + (CWS_T + row) * CWS_RS + c4 * 2, v);
         }
@@ -1299,17 +1306,18 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
 
     const int it_begin = 2 * c_begin, it_end = 2 * c_end;          // an even number of half chunks
     if (it_begin < it_end) {
-        load_half(it_begin, rgs[0], rxs[0], shs[0]);
+        load_half(it_begin, rgs[0], rxs[0], shs[0], tails[0]);
         __builtin_amdgcn_sched_barrier(0);          // set 0's loads strictly before set 1's: the loop's vmcnt waits are derived from BOTH orders
-        load_half(it_begin + 1, rgs[1], rxs[1], shs[1]);
+        load_half(it_begin + 1, rgs[1], rxs[1], shs[1], tails[1]);
         __builtin_amdgcn_sched_barrier(0);
     }
     for (int it = it_begin; it < it_end; it += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            store_half(rgs[h], rxs[h], shs[h]);                     // (waits for this half chunk's loads only: vmcnt counts the other set's)
+            if (tails[h] || edge) store_half(rgs[h], rxs[h], shs[h], true);          // (waits for this half chunk's loads only: vmcnt counts the other set's)
+            else store_half(rgs[h], rxs[h], shs[h], false);
             __syncthreads();
-            load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], shs[h]);
+            load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], shs[h], tails[h]);
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __builtin_amdgcn_sched_barrier(0);
