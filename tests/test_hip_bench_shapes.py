@@ -285,6 +285,42 @@ def test_c4_ns3d_pointwise_resample_full_size(w, layer):
     COVERED.update(n for n in ran if _spectral(n))
 
 
+@pytest.mark.parametrize("w", [8, 32])
+@pytest.mark.parametrize("layer", range(7))
+def test_c4_ns3d_pointwise_resample_accumulating_full_size(w, layer):
+    """The ACCUMULATING form of the same resampling (uno_fft_resample3d_acc: what the one-buffer OperatorBlock_3D runs - the point-wise
+    branch's last transform adds into the spectral branch's output and writes the GELU in the same pass, reference
+    integral_operators.py:506-512) at the NS-3D model's shapes: s + resample(t) and gelu(s + resample(t)) against float64 on the host."""
+    from uno_amd import _native
+    from uno_amd.integral_operators import _resample3d_plan
+    _, Co, din, dout, _ = _t20_layers(w)[layer]
+    plan = _resample3d_plan(din, dout, dev())
+    if plan is None:
+        pytest.skip("outside the pruned-DFT resampling kernels' range: the model runs stock rocFFT here")
+    g = torch.Generator().manual_seed(w * 10 + layer + 500)
+    t = torch.randn(8, Co, *din, generator=g)
+    s0 = torch.randn(8, Co, *dout, generator=g)
+    spec = torch.fft.rfftn(t.double(), dim=[-3, -2, -1])
+    kept = torch.zeros_like(spec)
+    h1, h2, h3 = dout[0] // 2, dout[1] // 2, dout[2] // 2
+    for rows in (slice(None, h1), slice(-h1, None)):
+        for cols in (slice(None, h2), slice(-h2, None)):
+            kept[:, :, rows, cols, :h3] = spec[:, :, rows, cols, :h3]
+    ref = s0.double() + torch.fft.irfftn(kept, s=dout)
+    t1, t2, m3 = plan
+    scale = 1.0 / (dout[0] * dout[1] * dout[2])
+    td = t.to(dev())
+
+    def run():
+        a = _native.fft_resample3d(td, dout, (t1, t1), (t2, t2), m3, scale, adjoint=False, out=s0.to(dev()))
+        b, act = _native.fft_resample3d(td, dout, (t1, t1), (t2, t2), m3, scale, adjoint=False, out=s0.to(dev()), act=True)
+        return a, b, act
+    (a, b, act), ran = _run_profiled(run)
+    assert rel_err(a.cpu().numpy(), ref.numpy()) < TOL and torch.equal(a, b)
+    assert rel_err(act.cpu().numpy(), torch.nn.functional.gelu(ref).numpy()) < TOL
+    COVERED.update(n for n in ran if _spectral(n))
+
+
 # ------------------------------------------------------------------ C5: 1024^2 block, batch 4, f32 (the mixed form: tests/test_hip_c5.py)
 def test_c5_block_f32_bench_batch():
     _check2d(4, 64, 64, 1024, 1024, 1024, 1024, 32, 32, seed=1024)

@@ -1258,18 +1258,23 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         *reinterpret_cast<uint2*>(d + CWS_PLANE) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(d + 2 * CWS_PLANE) = make_uint2(l0, l1);
     };
+    // Position of a row's four 16-byte k-groups inside its 64 bytes: rows 4 .. 11 of every 16 keep them pairwise swapped.  ds_read_b128 is
+    // serviced in lane groups {0-3, 12-15, 20-27}, ... - rows 0-3 / 12-15 at k-group g together with rows 4-11 at k-group g ^ 1 - and with
+    // 80-byte rows in plain order three of the 16 accesses of every group met another one's banks (PMC, 256 x 256 at 111^2:
+    // SQ_LDS_BANK_CONFLICT 19.0 M of 38.0 M LDS cycles); with the swap the 16 four-bank windows of a group are distinct.
+    const int wpos = 16 * ((c4 >> 2 >> 1) ^ (((row0 & 15) + 4) >> 3 & 1)) + 8 * ((c4 >> 2) & 1);       // rows row0 + 32 u: the same row0 & 15
     auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur, bool slow) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 32 * u;
             if (u < MR) {
                 const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur, slow);
-                if constexpr (NPG == 1) put1(smem + row * CWS_RS + c4 * 2, g); else put3(smem + row * CWS_RS + c4 * 2, g);
+                if constexpr (NPG == 1) put1(smem + row * CWS_RS + wpos, g); else put3(smem + row * CWS_RS + wpos, g);
                 bs[u] += (g.x + g.y) + (g.z + g.w);
             }
             float4 v = shifted(rxv[u], xok[u], sh_cur, slow);
             if constexpr (ACTX) { if (xact[u]) v = cm_gelu4(v); }   // gelu(0) = 0: the zero fill survives
-            if constexpr (NPX == 1) put1(smem + (CWS_T + row) * CWS_RS + c4 * 2, v); else put3(smem + (CWS_T + row) * CWS_RS + c4 * 2, v);
+            if constexpr (NPX == 1) put1(smem + (CWS_T + row) * CWS_RS + wpos, v); else put3(smem + (CWS_T + row) * CWS_RS + wpos, v);
         }
     };
 
@@ -1278,8 +1283,9 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
-    const char* abase = smem + (16 * MR * wa + r16) * CWS_RS + 16 * kk;
-    const char* bbase = smem + (CWS_T + 64 * wb + r16) * CWS_RS + 16 * kk;
+    const int rpos = 16 * (kk ^ ((r16 + 4) >> 3 & 1));
+    const char* abase = smem + (16 * MR * wa + r16) * CWS_RS + rpos;
+    const char* bbase = smem + (CWS_T + 64 * wb + r16) * CWS_RS + rpos;
     auto compute = [&]() {
         cms_u32x4 A[MR][NPG];
 #pragma unroll
