@@ -1154,8 +1154,8 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
 //   * BOTH operands have their k axis (pixels) contiguous in memory, so the MFMA operand of a lane - 8 consecutive k of one row - is
 //     16 contiguous bytes of an LDS row: planes [piece][row: 128 gY + 128 X][32 px] of bf16, rows 80 bytes apart (the 16 rows of a
 //     fragment read cover the 64 banks once), one ds_read_b128 per fragment and piece, no transposing reads;
-//   * the split happens once per element, in the thread that stages it (as K8-S); staging and multiplying are the fixed roles of two
-//     groups of four waves (below); two 60 KB buffers, one workgroup of 8 waves per CU.
+//   * the split happens once per element, in the thread that stages it (as K8-S); the next 32 pixels are in flight in registers
+//     while the current ones are multiplied; 60 KB of LDS, two workgroups per CU.
 // Partial sums leave in the (split, Co, Ci + 1) layout of the other first-stage kernels; the second stage is shared.
 constexpr int CWS_T = 128;
 constexpr int CWS_PK = 32;
@@ -1169,22 +1169,13 @@ static bool wgrad_split_shape(int Ci, int Co, long long P) {
 static int wgrad_split_rows(int Co) { return Co >= 96 ? CWS_T : 64; }      // output channels per weight tile
 
 // BF: bfloat16 activations (exact in ONE piece: gY x X is one product; with the GELU applied on read, gelu(x) is an f32 value again: three
-// pieces of X against the one of gY).
-//
-// Roles.  The first form of this kernel ran 256 threads that staged (global -> split -> LDS) and multiplied in turn, two workgroups per
-// CU.  Its counters at 256 x 256, 111^2 (profiles/r04_k9s_256x256_111_pmc.txt): matrix pipe busy 39 % of the time, the waves unable to
-// issue for 55 % of their cycles - the two waves of a SIMD sat in their MFMA phases together, then in their VALU phases together.  Now
-// a workgroup is 8 waves with FIXED roles, one of each per SIMD: waves 0-3 only multiply (LDS fragment reads + 96 MFMAs per half
-// chunk), waves 4-7 only stage (loads, split, LDS writes, bias sums); the hardware interleaves a SIMD's VALU wave with its MFMA wave
-// instruction by instruction.  Two LDS buffers (120 KB, one workgroup per CU), ONE barrier per half chunk: in step i the staging waves
-// write half chunk i + 1 into buffer (i + 1) & 1 while the multiplying waves read half chunk i from buffer i & 1.
+// pieces of X against the one of gY)
 template <bool ACTX, int MR, bool BF>
-__global__ __launch_bounds__(512, 1) void channel_wgrad_split_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
-    extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-    constexpr int BUF = 3 * CWS_PLANE;
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * CWS_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool staging = wave >= 4;
+    const int wa = wave & 1, wb = wave >> 1;
     const int ntile_i = (p.Ci + CWS_T - 1) / CWS_T;
     constexpr int TO = 32 * MR;                                     // output channels per tile
     using T = typename IoElem<BF>::type;
@@ -1196,153 +1187,106 @@ __global__ __launch_bounds__(512, 1) void channel_wgrad_split_kernel(ChannelWgra
     if (split >= p.nsplit) return;
     const int o0 = (tile / ntile_i) * TO, i0 = (tile % ntile_i) * CWS_T;
     const int c_begin = split * chunks_per_split, c_end = min(c_begin + chunks_per_split, p.B * npc);
-    const int it_begin = 2 * c_begin, it_end = 2 * c_end;          // half chunks of 32 pixels (an even number of them)
-    float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-    if (staging) {
-        // ------------------------------------------------------------------------------------------------ waves 4-7: global -> split -> LDS
-        const int st = tid - 256;
-        const int c4 = (st & 7) * 4, row0 = st >> 3;                // a thread stages four pixels of rows row0 + 32 u of both operands
-        // the 32 input channels of band u lie in one source (C1 % 32 == 0 in two-source calls)
-        const T* xsrc[4];
-        int xcs[4], xrow[4];
-        bool xact[4], xok[4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int c4 = (tid & 7) * 4, row0 = tid >> 3;                  // a thread stages four pixels of rows row0 + 32 u of both operands
+    // the 32 input channels of band u lie in one source (C1 % 32 == 0 in two-source calls)
+    const T* xsrc[4];
+    int xcs[4], xrow[4];
+    bool xact[4], xok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ci = i0 + 32 * u;
+        const bool s2 = ci >= p.C1;
+        xsrc[u] = reinterpret_cast<const T*>(s2 ? p.x2 : p.x);
+        xcs[u] = s2 ? p.Ci - p.C1 : p.C1;
+        const int il = (s2 ? ci - p.C1 : ci) + row0;
+        xok[u] = ci + row0 < p.Ci;
+        xrow[u] = min(il, xcs[u] - 1);
+        xact[u] = ACTX && !s2;
+        if (ci >= p.Ci) { xsrc[u] = reinterpret_cast<const T*>(p.x); xcs[u] = p.C1; xrow[u] = 0; }
+    }
+    // two half chunks in flight (register sets 0 / 1): with one, the loads had the 96 MFMAs of ONE half (~0.8 us) to arrive in and the
+    // wave waited for them at every store (256 x 256 at 111^2: 173 us at 45 % MFMA-pipe use)
+    u32x4 rgs[2][4], rxs[2][4];                                     // RAW loaded pieces: anything computed from them at load time makes the wave wait for its loads at once
+    int shs[2] = {0, 0};
+    // the zero fill past the row end / past the channel counts is needed only in the last half chunk of a row and in partial weight
+    // tiles - both wave-uniform; everywhere else the staged values go straight to the split (12 of 34 VALU instructions per four values)
+    bool tails[2] = {false, false};
+    const bool edge = o0 + TO > p.Co || i0 + CWS_T > p.Ci;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur, bool& tail) {     // half chunk it: 32 pixels of chunk it >> 1
+        const int idx = it >> 1;
+        const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto raw2 = [](const u32x2& t) { return u32x4{t.x, t.y, 0u, 0u}; };
+        const int px = pp + c4, pc = min(px, p.P - 4);
+        sh_cur = px - pc;
+        tail = pp + CWS_PK > p.P;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int ci = i0 + 32 * u;
-            const bool s2 = ci >= p.C1;
-            xsrc[u] = reinterpret_cast<const T*>(s2 ? p.x2 : p.x);
-            xcs[u] = s2 ? p.Ci - p.C1 : p.C1;
-            const int il = (s2 ? ci - p.C1 : ci) + row0;
-            xok[u] = ci + row0 < p.Ci;
-            xrow[u] = min(il, xcs[u] - 1);
-            xact[u] = ACTX && !s2;
-            if (ci >= p.Ci) { xsrc[u] = reinterpret_cast<const T*>(p.x); xcs[u] = p.C1; xrow[u] = 0; }
-        }
-        // two half chunks in flight (register sets 0 / 1) as RAW loaded pieces: anything computed from a loaded value at load time makes the
-        // wave wait for its loads at once
-        u32x4 rgs[2][4], rxs[2][4];
-        int shs[2] = {0, 0};
-        // the zero fill past the row end / past the channel counts is needed only in the last half chunk of a row and in partial weight
-        // tiles - both wave-uniform; everywhere else the staged values go straight to the split (12 of 34 VALU instructions per four values)
-        bool tails[2] = {false, false};
-        const bool edge = o0 + TO > p.Co || i0 + CWS_T > p.Ci;
-        float bs[4] = {0.f, 0.f, 0.f, 0.f};
-        auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur, bool& tail) {     // half chunk it: 32 pixels of chunk it >> 1
-            const int idx = it >> 1;
-            const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
-            const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            auto raw2 = [](const u32x2& t) { return u32x4{t.x, t.y, 0u, 0u}; };
-            const int px = pp + c4, pc = min(px, p.P - 4);
-            sh_cur = px - pc;
-            tail = pp + CWS_PK > p.P;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * p.P), 0, xcs[u] * p.P * ES, 0x00020000);
-                if constexpr (BF) {
-                    if (u < MR) rg[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 2, 0, 0));
-                    rxv[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * p.P + pc) * 2, 0, 0));
-                } else {
-                    if (u < MR) rg[u] = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 4, 0, 0);
-                    rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * p.P + pc) * 4, 0, 0);
-                }
-            }
-        };
-        auto shifted = [&](const u32x4& r, bool valid, int sh_cur, bool slow) {    // slow: zero fill past the row end / past the channel count (see the vector kernel)
-            float t0, t1, t2, t3;
-            if constexpr (BF) { t0 = __uint_as_float(r.x << 16); t1 = __uint_as_float(r.x & 0xffff0000u); t2 = __uint_as_float(r.y << 16); t3 = __uint_as_float(r.y & 0xffff0000u); }
-            else { t0 = __uint_as_float(r.x); t1 = __uint_as_float(r.y); t2 = __uint_as_float(r.z); t3 = __uint_as_float(r.w); }
-            if (slow) {
-                if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
-                if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
-                if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
-            }
-            return make_float4(t0, t1, t2, t3);
-        };
-        auto put1 = [&](char* d, const float4& v) {                    // widened bf16 values: exact in one piece
-            *reinterpret_cast<uint2*>(d) = make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w));
-        };
-        auto put3 = [&](char* d, const float4& v) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            cms_split3(v.x, v.y, h0, m0, l0);
-            cms_split3(v.z, v.w, h1, m1, l1);
-            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(d + CWS_PLANE) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(d + 2 * CWS_PLANE) = make_uint2(l0, l1);
-        };
-        // Position of a row's four 16-byte k-groups inside its 64 bytes: rows 4 .. 11 of every 16 keep them pairwise swapped.  ds_read_b128 is
-        // serviced in lane groups {0-3, 12-15, 20-27}, ... - rows 0-3 / 12-15 at k-group g together with rows 4-11 at k-group g ^ 1 - and with
-        // 80-byte rows in plain order three of the 16 accesses of every group met another one's banks (PMC, 256 x 256 at 111^2:
-        // SQ_LDS_BANK_CONFLICT 19.0 M of 38.0 M LDS cycles); with the swap the 16 four-bank windows of a group are distinct.
-        const int wpos = 16 * ((c4 >> 2 >> 1) ^ (((row0 & 15) + 4) >> 3 & 1)) + 8 * ((c4 >> 2) & 1);       // rows row0 + 32 u: the same row0 & 15
-        auto store_half = [&](char* buf, const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur, bool slow) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = row0 + 32 * u;
-                if (u < MR) {
-                    const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur, slow);
-                    if constexpr (NPG == 1) put1(buf + row * CWS_RS + wpos, g); else put3(buf + row * CWS_RS + wpos, g);
-                    bs[u] += (g.x + g.y) + (g.z + g.w);
-                }
-                float4 v = shifted(rxv[u], xok[u], sh_cur, slow);
-                if constexpr (ACTX) { if (xact[u]) v = cm_gelu4(v); }   // gelu(0) = 0: the zero fill survives
-                if constexpr (NPX == 1) put1(buf + (CWS_T + row) * CWS_RS + wpos, v); else put3(buf + (CWS_T + row) * CWS_RS + wpos, v);
-            }
-        };
-        auto stage = [&](int it, int h) {                               // half chunk `it` (held in register set h) -> buffer (it - it_begin) & 1
-            char* buf = smem_dyn + ((it - it_begin) & 1) * BUF;
-            if (tails[h] || edge) store_half(buf, rgs[h], rxs[h], shs[h], true);
-            else store_half(buf, rgs[h], rxs[h], shs[h], false);
-        };
-        if (it_begin < it_end) {
-            load_half(it_begin, rgs[0], rxs[0], shs[0], tails[0]);
-            __builtin_amdgcn_sched_barrier(0);          // set 0's loads strictly before set 1's: the loop's vmcnt waits are derived from BOTH orders
-            load_half(it_begin + 1, rgs[1], rxs[1], shs[1], tails[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            stage(it_begin, 0);
-            load_half(min(it_begin + 2, it_end - 1), rgs[0], rxs[0], shs[0], tails[0]);
-        }
-        __syncthreads();
-        // step i: half chunk i + 1 goes to LDS (register set (i + 1 - it_begin) & 1), its set is refilled with half chunk i + 3
-        for (int it = it_begin; it < it_end; it += 2) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int nx = it + h + 1;              // the half chunk staged in this step; its register set is (h + 1) & 1
-                if (nx < it_end) {
-                    stage(nx, (h + 1) & 1);
-                    load_half(min(nx + 2, it_end - 1), rgs[(h + 1) & 1], rxs[(h + 1) & 1], shs[(h + 1) & 1], tails[(h + 1) & 1]);
-                }
-                __syncthreads();
+            const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * p.P), 0, xcs[u] * p.P * ES, 0x00020000);
+            if constexpr (BF) {
+                if (u < MR) rg[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 2, 0, 0));
+                rxv[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * p.P + pc) * 2, 0, 0));
+            } else {
+                if (u < MR) rg[u] = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 4, 0, 0);
+                rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * p.P + pc) * 4, 0, 0);
             }
         }
-        if (i0 == 0) {          // bias gradient: the 8 threads that share a row hold its partial sums
-#pragma unroll
-            for (int u = 0; u < MR; ++u) {
-                float v = bs[u];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-                const int o = o0 + row0 + 32 * u;
-                if ((st & 7) == 0 && o < p.Co) part[(size_t)o * (p.Ci + 1) + p.Ci] = v;
-            }
+    };
+    auto shifted = [&](const u32x4& r, bool valid, int sh_cur, bool slow) {    // slow: zero fill past the row end / past the channel count (see the vector kernel)
+        float t0, t1, t2, t3;
+        if constexpr (BF) { t0 = __uint_as_float(r.x << 16); t1 = __uint_as_float(r.x & 0xffff0000u); t2 = __uint_as_float(r.y << 16); t3 = __uint_as_float(r.y & 0xffff0000u); }
+        else { t0 = __uint_as_float(r.x); t1 = __uint_as_float(r.y); t2 = __uint_as_float(r.z); t3 = __uint_as_float(r.w); }
+        if (slow) {
+            if (sh_cur & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
+            if (sh_cur & 2) { t0 = t2; t1 = t3; t2 = 0.f; t3 = 0.f; }
+            if (sh_cur >= 4 || !valid) { t0 = 0.f; t1 = 0.f; t2 = 0.f; t3 = 0.f; }
         }
-        return;
-    }
+        return make_float4(t0, t1, t2, t3);
+    };
+    auto put1 = [&](char* d, const float4& v) {                    // widened bf16 values: exact in one piece
+        *reinterpret_cast<uint2*>(d) = make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w));
+    };
+    auto put3 = [&](char* d, const float4& v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        cms_split3(v.x, v.y, h0, m0, l0);
+        cms_split3(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + CWS_PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 2 * CWS_PLANE) = make_uint2(l0, l1);
+    };
+    // Position of a row's four 16-byte k-groups inside its 64 bytes: rows 4 .. 11 of every 16 keep them pairwise swapped.  ds_read_b128 is
+    // serviced in lane groups {0-3, 12-15, 20-27}, ... - rows 0-3 / 12-15 at k-group g together with rows 4-11 at k-group g ^ 1 - and with
+    // 80-byte rows in plain order three of the 16 accesses of every group met another one's banks (PMC, 256 x 256 at 111^2:
+    // SQ_LDS_BANK_CONFLICT 19.0 M of 38.0 M LDS cycles); with the swap the 16 four-bank windows of a group are distinct.
+    const int wpos = 16 * ((c4 >> 2 >> 1) ^ (((row0 & 15) + 4) >> 3 & 1)) + 8 * ((c4 >> 2) & 1);       // rows row0 + 32 u: the same row0 & 15
+    auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur, bool slow) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 32 * u;
+            if (u < MR) {
+                const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur, slow);
+                if constexpr (NPG == 1) put1(smem + row * CWS_RS + wpos, g); else put3(smem + row * CWS_RS + wpos, g);
+                bs[u] += (g.x + g.y) + (g.z + g.w);
+            }
+            float4 v = shifted(rxv[u], xok[u], sh_cur, slow);
+            if constexpr (ACTX) { if (xact[u]) v = cm_gelu4(v); }   // gelu(0) = 0: the zero fill survives
+            if constexpr (NPX == 1) put1(smem + (CWS_T + row) * CWS_RS + wpos, v); else put3(smem + (CWS_T + row) * CWS_RS + wpos, v);
+        }
+    };
 
-    // ---------------------------------------------------------------------------------------------------- waves 0-3: LDS -> MFMA
-    const int lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
-    const int wa = wave & 1, wb = wave >> 1;
     f32x4 acc[MR][4];                   // [output-channel tile m][input-channel tile t]
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
     const int rpos = 16 * (kk ^ ((r16 + 4) >> 3 & 1));
-    const int aoff = (16 * MR * wa + r16) * CWS_RS + rpos;
-    const int boff = (CWS_T + 64 * wb + r16) * CWS_RS + rpos;
-    auto compute = [&](const char* buf) {
-        const char* abase = buf + aoff;
-        const char* bbase = buf + boff;
+    const char* abase = smem + (16 * MR * wa + r16) * CWS_RS + rpos;
+    const char* bbase = smem + (CWS_T + 64 * wb + r16) * CWS_RS + rpos;
+    auto compute = [&]() {
         cms_u32x4 A[MR][NPG];
 #pragma unroll
         for (int m = 0; m < MR; ++m)
@@ -1365,14 +1309,29 @@ __global__ __launch_bounds__(512, 1) void channel_wgrad_split_kernel(ChannelWgra
                 }
         }
     };
-    __syncthreads();                    // half chunk it_begin is in buffer 0
+
+    const int it_begin = 2 * c_begin, it_end = 2 * c_end;          // an even number of half chunks
+    if (it_begin < it_end) {
+        load_half(it_begin, rgs[0], rxs[0], shs[0], tails[0]);
+        __builtin_amdgcn_sched_barrier(0);          // set 0's loads strictly before set 1's: the loop's vmcnt waits are derived from BOTH orders
+        load_half(it_begin + 1, rgs[1], rxs[1], shs[1], tails[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int it = it_begin; it < it_end; it += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            compute(smem_dyn + h * BUF);                // (it + h - it_begin) & 1 == h
+            if (tails[h] || edge) store_half(rgs[h], rxs[h], shs[h], true);          // (waits for this half chunk's loads only: vmcnt counts the other set's)
+            else store_half(rgs[h], rxs[h], shs[h], false);
+            __syncthreads();
+            load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], shs[h], tails[h]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
     }
+
+    float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -1386,6 +1345,15 @@ __global__ __launch_bounds__(512, 1) void channel_wgrad_split_kernel(ChannelWgra
                 }
             }
         }
+    if (i0 == 0) {          // bias gradient: the 8 threads that share a row hold its partial sums
+#pragma unroll
+        for (int u = 0; u < MR; ++u) {
+            float v = bs[u];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            const int o = o0 + row0 + 32 * u;
+            if ((tid & 7) == 0 && o < p.Co) part[(size_t)o * (p.Ci + 1) + p.Ci] = v;
+        }
+    }
 }
 
 // Weight gradient with few input channels (CI <= 4): a thread owns four pixels at a time and accumulates its 16 output channels x
@@ -1491,10 +1459,10 @@ static void wgrad_plan(int B, int Ci, int Co, long long P, int* nsplit, int* npc
     *npc = (int)((P + *pk - 1) / *pk);
     const long long nchunks = (long long)B * *npc;
     long long want = (1024 + tiles - 1) / tiles;
-    if (wgrad_split_shape(Ci, Co, P)) {             // K9-S: 128 x 128 weight tiles, one resident workgroup (8 waves) per CU = 256
+    if (wgrad_split_shape(Ci, Co, P)) {             // K9-S: 128 x 128 weight tiles, two resident workgroups per CU = 512
         const int to = wgrad_split_rows(Co);
         const int tiles_s = ((Co + to - 1) / to) * ((Ci + CWS_T - 1) / CWS_T);
-        want = (256 + tiles_s - 1) / tiles_s;
+        want = (512 + tiles_s - 1) / tiles_s;
     }
     long long per = (nchunks + want - 1) / want;
     if (per < 4) per = 4;
@@ -1556,15 +1524,11 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
             const int to = wgrad_split_rows(Co);
             const int tiles_s = ((Co + to - 1) / to) * ((Ci + CWS_T - 1) / CWS_T);
             const dim3 gs(8 * tiles_s * ((p.nsplit + 7) / 8));
-            constexpr size_t lds = 2 * 3 * CWS_PLANE;
-#define UNO_CWS1(A_, M_, B_) do { static int slot_[64]; auto k_ = channel_wgrad_split_kernel<A_, M_, B_>; \
-                                  if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k_), lds, slot_)) { set_error("channel_wgrad: cannot raise dynamic LDS to %zu", lds); return -4; } \
-                                  hipLaunchKernelGGL(k_, gs, dim3(512), lds, s, p, npc, cps); } while (0)
-#define UNO_CWS(A_, M_) do { if (bf16) UNO_CWS1(A_, M_, true); else UNO_CWS1(A_, M_, false); } while (0)
+#define UNO_CWS(A_, M_) do { if (bf16) hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, true>), gs, dim3(256), 0, s, p, npc, cps); \
+                             else hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, false>), gs, dim3(256), 0, s, p, npc, cps); } while (0)
             if (to == CWS_T) { if (act_x) UNO_CWS(true, 4); else UNO_CWS(false, 4); }
             else { if (act_x) UNO_CWS(true, 2); else UNO_CWS(false, 2); }
 #undef UNO_CWS
-#undef UNO_CWS1
         } else if (pk == CWV_PK && act_x) {
             if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, true>), gv, dim3(256), 0, s, p, npc, cps);
             else hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false>), gv, dim3(256), 0, s, p, npc, cps);
