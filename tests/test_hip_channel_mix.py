@@ -438,7 +438,7 @@ def test_split_bf16_wide_layers_bf16_activations():
 WIDE_WGRAD = [  # B, C1, C2, Co, P, act_x
     (2, 128, 0, 128, 640, False), (3, 256, 0, 256, 12321 // 9, False), (2, 96, 0, 130, 77, False), (1, 130, 0, 96, 64 + 31, True),
     (2, 64, 32, 128, 446 * 3 + 1, True), (2, 64, 32, 128, 1000, False), (1, 128, 128, 128, 96, False), (2, 64, 64, 100, 200, True),
-    (1, 257, 0, 129, 130, False),
+    (1, 257, 0, 129, 130, False), (2, 128, 0, 50, 300, False), (1, 96, 0, 64, 64 + 17, True), (3, 192, 0, 48, 129, False),
 ]
 
 
