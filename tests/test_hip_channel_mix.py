@@ -434,11 +434,11 @@ def test_split_bf16_wide_layers_bf16_activations():
 
 # K9-S (channel_wgrad_split_kernel): both channel counts >= 96 - three-piece bf16 operands on the bf16 MFMA, 128 x 128 weight tiles.
 # Shapes: full tiles, partial tiles in both directions, rows ending inside a 32-pixel half chunk, inside a 4-pixel group, pixel counts
-# that leave the second half of the last 64-pixel chunk empty, the model's layers (fc1: 64 + 32 -> 128 with GELU-on-read; 256 x 256).
-WIDE_WGRAD = [  # B, C1, C2, Co, P, act_x
-    (2, 128, 0, 128, 640, False), (3, 256, 0, 256, 12321 // 9, False), (2, 96, 0, 130, 77, False), (1, 130, 0, 96, 64 + 31, True),
-    (2, 64, 32, 128, 446 * 3 + 1, True), (2, 64, 32, 128, 1000, False), (1, 128, 128, 128, 96, False), (2, 64, 64, 100, 200, True),
-    (1, 257, 0, 129, 130, False), (2, 128, 0, 50, 300, False), (1, 96, 0, 64, 64 + 17, True), (3, 192, 0, 48, 129, False),
+# that leave the second half of the last 64-pixel chunk empty, two sources, GELU-on-read, the 64-row tiles (Co < 96).
+WIDE_WGRAD = [  # B, C1, C2, Co, P, act_x   (batch x pixels >= 100 000: below that the vector kernel keeps the layer)
+    (2, 128, 0, 128, 51200, False), (2, 256, 0, 256, 50013, False), (2, 96, 0, 130, 50047, False), (1, 130, 0, 96, 100031, True),
+    (2, 64, 32, 128, 50001, True), (4, 64, 32, 128, 25010, False), (1, 128, 128, 128, 100000 + 32, False), (2, 64, 64, 100, 50200, True),
+    (1, 257, 0, 129, 100130, False), (2, 128, 0, 50, 50300, False), (1, 96, 0, 64, 100000 + 64 + 17, True), (3, 192, 0, 48, 33400 + 29, False),
 ]
 
 
@@ -484,10 +484,22 @@ def test_wide_wgrad_split_bf16_activations(B, C1, C2, Co, P, act_x):
     assert rel(gb, gy.double().sum(dim=(0, 2))) < 2e-6
 
 
+def test_small_wide_layers_keep_the_vector_kernel():
+    """below 100 000 pixels per launch the f32-MFMA vector kernel keeps the layer (the NS-2D roll-out's wide layers: A/B in DESIGN.md)"""
+    from uno_amd import _native
+    gy, x = torch.randn(32, 192, 1024, device="cuda"), torch.randn(32, 96, 1024, device="cuda")
+    _native.profile_begin(16)
+    gw, _ = _native.channel_wgrad(gy, x)
+    torch.cuda.synchronize()
+    names = {n for n, _, _ in _native.profile_end()}
+    assert "uno::channel_wgrad_vec_kernel" in names and "uno::channel_wgrad_split_kernel" not in names, names
+    assert rel(gw, torch.einsum("bop,bip->oi", gy.double(), x.double())) < 2e-5
+
+
 def test_wide_wgrad_red_zone():
     """the partial-sum workspace of the split form is sized by the same plan the kernel follows: nothing is written past it"""
     from uno_amd import _native
-    B, Ci, Co, P = 2, 96, 130, 333
+    B, Ci, Co, P = 2, 96, 130, 50333
     gy, x = torch.randn(B, Co, P, device="cuda"), torch.randn(B, Ci, P, device="cuda")
     nf = _native.channel_wgrad_partial_floats(B, Ci, Co, P)
     raw = torch.full((nf + 2048,), 3.25, device="cuda")

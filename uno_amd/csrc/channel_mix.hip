@@ -1162,9 +1162,12 @@ constexpr int CWS_PK = 32;
 constexpr int CWS_RS = CWS_PK * 2 + 16;             // bytes per row of a plane
 constexpr int CWS_PLANE = 2 * CWS_T * CWS_RS;       // 20 480
 
-static bool wgrad_split_shape(int Ci, int Co, long long P) {
+// From 100 000 pixels per launch: below, a launch is a handful of 128 x 128 tiles with a few chunks each and the 60 KB workgroups lose to
+// the vector kernel (A/B on one box: the NS-2D roll-out - 64^2 .. 16^2 grids at batch 32, at most 74 000 pixels per call - 80.7 ms
+// per step with this form on its wide layers, 79.5 without; the Darcy model's smallest level is 197 000).
+static bool wgrad_split_shape(int B, int Ci, int Co, long long P) {
     static const bool off = getenv("UNO_CW_SPLIT_OFF") != nullptr;         // development: A/B against the f32-MFMA form
-    return !off && Ci >= 96 && Co >= 48 && P >= 64;
+    return !off && Ci >= 96 && Co >= 48 && P >= 64 && (long long)B * P >= 100000;
 }
 static int wgrad_split_rows(int Co) { return Co >= 96 ? CWS_T : 64; }      // output channels per weight tile
 
@@ -1459,7 +1462,7 @@ static void wgrad_plan(int B, int Ci, int Co, long long P, int* nsplit, int* npc
     *npc = (int)((P + *pk - 1) / *pk);
     const long long nchunks = (long long)B * *npc;
     long long want = (1024 + tiles - 1) / tiles;
-    if (wgrad_split_shape(Ci, Co, P)) {             // K9-S: 128 x 128 weight tiles, two resident workgroups per CU = 512
+    if (wgrad_split_shape(B, Ci, Co, P)) {             // K9-S: 128 x 128 weight tiles, two resident workgroups per CU = 512
         const int to = wgrad_split_rows(Co);
         const int tiles_s = ((Co + to - 1) / to) * ((Ci + CWS_T - 1) / CWS_T);
         want = (512 + tiles_s - 1) / tiles_s;
@@ -1515,7 +1518,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
         if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
         return 0;
     }
-    const bool split_form = wgrad_split_shape(Ci, Co, P) && pk == CWV_PK && (!x2 || C1 % 32 == 0);
+    const bool split_form = wgrad_split_shape(B, Ci, Co, P) && pk == CWV_PK && (!x2 || C1 % 32 == 0);
     {
         ProfScope prof(split_form ? "uno::channel_wgrad_split_kernel" : pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
