@@ -1146,8 +1146,9 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
 // The weight gradient of the wide layers (both channel counts >= 96) on the bf16 matrix pipe with both operands split into three
 // bfloat16 pieces - the arrangement of K8-S (six products, f32 accumulation, ~1e-7 relative: profiles/r04_split_bf16_error.txt).
 // Why: gW = sum over 16 x P pixels of gY X^T has Co x Ci outputs for 4 (Co + Ci) bytes per pixel - 2 Co Ci / (4 (Co + Ci)) flop/B =
-// 64 at 256 x 256, 27 at 96 x 128 (fc1) - against the f32 ridge of 20: the vector kernel above ran these layers at 1.5-3.6 TB/s,
-// i.e. at the f32 MFMA peak (256 x 256 at 111^2: 25.8 GFLOP, 258 us; fc1 at 446^2: 78 GFLOP, 673 us for 2.44 GB).
+// 64 at 256 x 256, 43 at 128 x 256, 21 at 64 x 128 (fc1, + its GELU on read) - against the f32 ridge of 20: the vector kernel above ran
+// these layers at 1.5-3.6 TB/s, i.e. at the f32 MFMA peak (256 x 256 at 111^2: 25.8 GFLOP, 258 us; fc1 at 446^2: 52 GFLOP + 204 M
+// GELUs, 673 us for 2.44 GB).
 //   * workgroup = (32 MR) x 128 weight tile x one split of the pixels, MR = 4 (Co >= 96) or 2 (Co <= 64 .. 95: fc1 128 -> 64, conv5's
 //     256 -> 64); wave (a, b) owns output channels 16 MR a .. x input channels 64 b .. + 63 = MR x 4 accumulator tiles; K = pixels,
 //     staged 32 at a time;
