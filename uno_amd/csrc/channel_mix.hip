@@ -1296,12 +1296,33 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int pl = 0; pl < NPG; ++pl) A[m][pl] = *reinterpret_cast<const cms_u32x4*>(abase + pl * CWS_PLANE + m * 16 * CWS_RS);
+        if constexpr (MR >= 4) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            cms_u32x4 Bp[NPX];
+            for (int t = 0; t < 4; ++t) {
+                cms_u32x4 Bp[NPX];
 #pragma unroll
-            for (int pl = 0; pl < NPX; ++pl) Bp[pl] = *reinterpret_cast<const cms_u32x4*>(bbase + pl * CWS_PLANE + t * 16 * CWS_RS);
-            // products (i, j) with i + j <= 2, smallest first; the MR row tiles between two uses of an accumulator
+                for (int pl = 0; pl < NPX; ++pl) Bp[pl] = *reinterpret_cast<const cms_u32x4*>(bbase + pl * CWS_PLANE + t * 16 * CWS_RS);
+                // products (i, j) with i + j <= 2, smallest first; the MR row tiles between two uses of an accumulator
+#pragma unroll
+                for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+                    for (int i = NPG - 1; i >= 0; --i) {
+                        const int jx = sum - i;
+                        if (jx < 0 || jx >= NPX) continue;
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) acc[m][t] = cms_mfma(A[m][i], Bp[jx], acc[m][t]);
+                    }
+            }
+        } else {
+            // two row tiles: with the column tiles in the outer loop an accumulator came round again after TWO MFMAs (32 cycles, less than
+            // the instruction's latency: cycle stamps of the -DUNO_CWS_STAMPS build, fc1 128 -> 64 at 446^2: 2 320 cycles per half chunk
+            // for 48 MFMAs = 768 cycles of matrix pipe).  All four column tiles' fragments are read first and the column tiles run
+            // inside each product: eight MFMAs between two uses of an accumulator.
+            cms_u32x4 Bp[4][NPX];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int pl = 0; pl < NPX; ++pl) Bp[t][pl] = *reinterpret_cast<const cms_u32x4*>(bbase + pl * CWS_PLANE + t * 16 * CWS_RS);
 #pragma unroll
             for (int sum = 2; sum >= 0; --sum)
 #pragma unroll
@@ -1309,7 +1330,9 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
                     const int jx = sum - i;
                     if (jx < 0 || jx >= NPX) continue;
 #pragma unroll
-                    for (int m = 0; m < MR; ++m) acc[m][t] = cms_mfma(A[m][i], Bp[jx], acc[m][t]);
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) acc[m][t] = cms_mfma(A[m][i], Bp[t][jx], acc[m][t]);
                 }
         }
     };
@@ -1321,19 +1344,38 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         load_half(it_begin + 1, rgs[1], rxs[1], shs[1], tails[1]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // development build (-DUNO_CWS_STAMPS, tools/dev/mkvariant.py): cycles per phase of every wave of one workgroup, summed over its
+    // half chunks - store (incl. the wait for the loads), barrier, fragment reads + MFMAs, barrier - printed at the end of the kernel
+#ifdef UNO_CWS_STAMPS
+    unsigned long long tS = 0, tB1 = 0, tC = 0, tB2 = 0, t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_begin = t_prev;
+#define CWS_STAMP(acc_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); (acc_) += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define CWS_STAMP(acc_) do { } while (0)
+#endif
     for (int it = it_begin; it < it_end; it += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (tails[h] || edge) store_half(rgs[h], rxs[h], shs[h], true);          // (waits for this half chunk's loads only: vmcnt counts the other set's)
             else store_half(rgs[h], rxs[h], shs[h], false);
+            CWS_STAMP(tS);
             __syncthreads();
+            CWS_STAMP(tB1);
             load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], shs[h], tails[h]);
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __builtin_amdgcn_sched_barrier(0);
+            CWS_STAMP(tC);
             __syncthreads();
+            CWS_STAMP(tB2);
         }
     }
+#ifdef UNO_CWS_STAMPS
+    if (blockIdx.x == 9 && lane == 0)
+        printf("K9-S stamps wg %d wave %d halves %d: store %llu  barrier1 %llu  multiply %llu  barrier2 %llu  loop %llu cycles\n", (int)blockIdx.x, wave,
+               it_end - it_begin, tS, tB1, tC, tB2, t_prev - t_begin);
+#endif
+#undef CWS_STAMP
 
     float* part = p.part + (size_t)split * p.Co * (p.Ci + 1);
 #pragma unroll
