@@ -418,6 +418,44 @@ def test_split_bf16_wide_layers(B, C1, C2, Co, P):
             assert rel(torch.cat([g1, g2], 1), torch.matmul(w.double().t(), gy.double())) < 1e-6
 
 
+SPLIT64 = [  # B, C1, C2, Co, P: 64-channel tiles of K8-S (Co % 64 == 0, not a multiple of 128)
+    (2, 256, 0, 64, 1111), (1, 128, 0, 192, 640), (2, 160, 0, 64, 300), (2, 96, 64, 64, 515), (2, 128, 128, 64, 223 * 223 // 7),
+]
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", SPLIT64)
+def test_split_bf16_64_channel_tiles(B, C1, C2, Co, P):
+    """conv5's 256 -> 64, the input gradients of the 64-channel levels: four waves = four pixel quarters x 64 channels"""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(C1 + 5 * C2 + Co + P + 1)
+    x = (torch.randn(B, C1 + C2, P, generator=g) * torch.exp2(torch.randint(-6, 7, (B, C1 + C2, 1), generator=g).float())).cuda()
+    w = (torch.randn(Co, C1 + C2, generator=g) * torch.exp2(torch.randint(-4, 5, (Co, 1), generator=g).float())).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    x1, x2 = (x[:, :C1].contiguous(), x[:, C1:].contiguous()) if C2 else (x, None)
+    ref = _ref(x, w, b)
+    y, names = _launched(lambda: _native.channel_mix2(x1, x2, w, b))
+    assert names == ["uno::channel_mix_split_kernel"], names
+    assert rel(y, ref) < 1e-6
+    assert (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    base = torch.randn(B, Co, P, generator=g).cuda()
+    out = base.clone()
+    _native.channel_mix2(x1, x2, w, b, out=out, accumulate=True)
+    assert rel(out, ref + base.double()) < 1e-6
+    y2, act = _native.channel_mix2(x1, x2, w, b, y_act=True)
+    assert torch.equal(y2, y) and rel(act, _gelu64(y)) < 2e-6
+    # transposed weights with two 64-channel destinations (fc1's input gradients: 64 -> 64 + 64 needs Ci >= 128, so a 128-channel gy)
+    gy = torch.randn(B, 128, P, generator=g).cuda()
+    wt = torch.randn(128, 128, generator=g).cuda()
+    (g1, g2), names = _launched(lambda: _native.channel_mix2(gy, None, wt, None, transpose_w=True, split_out=64))
+    assert names == ["uno::channel_mix_split_kernel"], names
+    assert rel(torch.cat([g1, g2], 1), torch.matmul(wt.double().t(), gy.double())) < 1e-6
+    # bf16 activations
+    xb = x.to(torch.bfloat16)
+    yb, names = _launched(lambda: _native.channel_mix(xb, w, b))
+    assert names == ["uno::channel_mix_split_kernel"], names
+    assert rel(yb.float(), _ref(xb.float(), w, b)) < 3e-3
+
+
 def test_split_bf16_wide_layers_bf16_activations():
     from uno_amd import _native
     g = torch.Generator().manual_seed(11)

@@ -559,9 +559,12 @@ constexpr int CMS_XPLANE = CMS_KC * CMS_XRS;            // 9 216
 constexpr int CMS_WPLANE = 4 * 128 * 16;                // bytes per W plane: [k-group 4][o 128] atoms of 8 bf16
 constexpr int CMS_FALLBACK = 2 * CM_KC * (CM_PT + 16) * 4 + 2 * CM_KC * CM_WS * 4;      // staging buffers of the guarded fallback path
 
-template <bool BF, bool TR, int XP = 0>      // TR: W contiguous along the output channel (input-gradient call); XP: development knock-outs / stamps
+// CT: output channels per tile, 128 or 64 (layers with Co % 64 == 0 only: conv5's 256 -> 64, the input gradients of the 64-channel
+// levels).  CT = 64: the four waves are four pixel quarters (32 pixels x 64 channels = 2 x 4 accumulator tiles each).
+template <bool BF, bool TR, int XP = 0, int CT = 128>      // TR: W contiguous along the output channel (input-gradient call); XP: development knock-outs / stamps
 __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixParams p) {
     constexpr bool tr = TR;
+    constexpr int MW = CT == 128 ? 4 : 2;               // pixel tiles (of 16) per wave
     using T = typename IoElem<BF>::type;
     constexpr int PT = CM_PT;
     constexpr int NPX = BF ? 1 : 3;                     // pieces of the X operand
@@ -571,18 +574,21 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     char* sWb = smem + NPX * CMS_XPLANE;
     const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
     if (tile >= p.ntile) return;
-    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = blockIdx.y;
-    if (p0 + PT > p.P) {            // the last, partial pixel tile of a row: the guarded 64-channel path twice (as the wide kernel)
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CT, b = blockIdx.y;
+    if (p0 + PT > p.P) {            // the last, partial pixel tile of a row: the guarded 64-channel path (twice for a 128-channel tile, as the wide kernel)
         auto sXn = reinterpret_cast<float (*)[CM_KC * (PT + 16)]>(smem);
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(smem + 2 * CM_KC * (PT + 16) * 4);
         channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0, b);
-        __syncthreads();
-        channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0 + 64, b);
+        if constexpr (CT == 128) {
+            __syncthreads();
+            channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0 + 64, b);
+        }
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave & 1, wb = wave >> 1;
+    const int wpx = CT == 128 ? 64 * wa : 32 * wave, wch = CT == 128 ? 64 * wb : 0;      // this wave's first pixel / channel inside the tile
     const int C1 = p.C1;
     const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;
     const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;
@@ -597,7 +603,18 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
             if constexpr (!(XP & 4)) rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
             else rx[u] = make_float4(1.f, 2.f, 3.f, 4.f);
             if constexpr ((XP & 2) != 0) { rw[u] = make_float4(1.f, 2.f, 3.f, 4.f); continue; }
-            if constexpr (!tr) {
+            if (CT == 64 && u >= 2) continue;             // 64 channels x 32 k = 512 float4: the first two rounds
+            if constexpr (CT == 64) {
+                if constexpr (!tr) {
+                    const int o = (e & 15) | ((e >> 7) << 4), k4 = ((e >> 4) & 7) * 4;        // e < 512: o < 64
+                    const f4u wv = *reinterpret_cast<const f4u*>(p.w + (unsigned)((o0 + o) * p.w_so + k0 + k4));
+                    rw[u] = make_float4(wv.v[0], wv.v[1], wv.v[2], wv.v[3]);
+                } else {
+                    const int o = e & 63, k4 = (e >> 6) * 4;
+                    const float* wp = p.w + (unsigned)((k0 + k4) * p.w_si + o0 + o);
+                    rw[u] = make_float4(wp[0], wp[p.w_si], wp[2 * p.w_si], wp[3 * p.w_si]);
+                }
+            } else if constexpr (!tr) {
                 // 16 consecutive lanes = 16 consecutive output channels at one k-quad (their LDS writes: 2-way, not 4-way), the four
                 // lane groups of a wave = 64 contiguous bytes of each of those rows
                 const int o = (e & 15) | ((e >> 7) << 4), k4 = ((e >> 4) & 7) * 4;
@@ -628,8 +645,9 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
                 }
             }
             if constexpr ((XP & 16) != 0) continue;
-            const int o = tr ? (e & 127) : ((e & 15) | ((e >> 7) << 4));
-            const int k4 = tr ? (e >> 7) * 4 : ((e >> 4) & 7) * 4;
+            if (CT == 64 && u >= 2) continue;
+            const int o = tr ? (CT == 64 ? (e & 63) : (e & 127)) : ((e & 15) | ((e >> 7) << 4));
+            const int k4 = tr ? (CT == 64 ? (e >> 6) * 4 : (e >> 7) * 4) : ((e >> 4) & 7) * 4;
             unsigned h0, m0, l0, h1, m1, l1;
             cms_split3(rw[u].x, rw[u].y, h0, m0, l0);
             cms_split3(rw[u].z, rw[u].w, h1, m1, l1);
@@ -641,15 +659,15 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
         }
     };
 
-    f32x4 acc[4][4];                    // [pixel tile m][channel tile t]
+    f32x4 acc[MW][4];                   // [pixel tile m][channel tile t]
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
 
     // transposing read: lane (group kk, index r16) supplies the address of row 4 kk + (r16 >> 2), segment r16 & 3
-    const char* xat = sXb + (4 * kk + (r16 >> 2)) * CMS_XRS + (64 * wa + 4 * (r16 & 3)) * 2;
-    const char* wat = sWb + ((kk * 128 + 64 * wb + r16) * 16);
+    const char* xat = sXb + (4 * kk + (r16 >> 2)) * CMS_XRS + (wpx + 4 * (r16 & 3)) * 2;
+    const char* wat = sWb + ((kk * 128 + wch + r16) * 16);
     auto compute = [&]() {
         cms_u32x4 Wop[4][3];
 #pragma unroll
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) Wop[t][pl] = *reinterpret_cast<const cms_u32x4*>(wat + pl * CMS_WPLANE + t * 256);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MW; ++m) {
             cms_u32x4 Xp[NPX];
 #pragma unroll
             for (int pl = 0; pl < NPX; ++pl) {
@@ -717,36 +735,40 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     // only that the compiler keeps the order (wave_barrier); the first version synchronised the workgroup 16 times per tile
     // (10 900 of a workgroup's 63 500 cycles were epilogue)
     constexpr int OS = 64 + 16;
+    constexpr int WPX = 16 * MW;                        // pixels per wave: 64 | 32
+    constexpr int LPR = WPX / 4;                        // lanes per staged row (four pixels each): 16 | 8
+    constexpr int RPI = 64 / LPR;                       // rows per store instruction: 4 | 8
     float* sO = reinterpret_cast<float*>(smem) + wave * (16 * OS);
-    const int c4 = (lane & 15) * 4;
-    const CmDest<T> dd = cm_dest<T>(p, o0, b);          // a 128-channel tile lies in one destination (Co1 % 128 == 0)
+    const int c4 = (lane & (LPR - 1)) * 4;
+    const CmDest<T> dd = cm_dest<T>(p, o0, b);          // a tile lies in one destination (Co1 % CT == 0)
     T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
     float bias_l[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bias_l[t] = p.bias ? p.bias[o0 + 64 * wb + 16 * t + r16] : 0.f;
+    for (int t = 0; t < 4; ++t) bias_l[t] = p.bias ? p.bias[o0 + wch + 16 * t + r16] : 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int ob = o0 + 64 * wb + 16 * t;
+        const int ob = o0 + wch + 16 * t;
         float* sT = sO;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MW; ++m)
             *reinterpret_cast<float4*>(sT + r16 * OS + 16 * m + 4 * kk) = make_float4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float4 old[4];
-        T* dst[4];
-        size_t aoff[4];
+        constexpr int NIT = 16 / RPI;                   // store instructions per 16-channel tile: 4 | 2
+        float4 old[NIT];
+        T* dst[NIT];
+        size_t aoff[NIT];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int o = ob + 4 * it + (lane >> 4);
-            dst[it] = dd.base + (size_t)(o - dd.ob) * p.P + p0 + 64 * wa + c4;
-            aoff[it] = (size_t)o * p.P + p0 + 64 * wa + c4;
+        for (int it = 0; it < NIT; ++it) {
+            const int o = ob + RPI * it + lane / LPR;
+            dst[it] = dd.base + (size_t)(o - dd.ob) * p.P + p0 + wpx + c4;
+            aoff[it] = (size_t)o * p.P + p0 + wpx + c4;
             if (p.accumulate) old[it] = io_ld4(dst[it]);
             else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = 4 * it + (lane >> 4);
+        for (int it = 0; it < NIT; ++it) {
+            const int row = RPI * it + lane / LPR;
             const float4 v = *reinterpret_cast<const float4*>(sT + row * OS + c4);
             const float bv = __shfl(bias_l[t], row);
             const float w0 = old[it].x + (v.x + bv), w1 = old[it].y + (v.y + bv), w2 = old[it].z + (v.z + bv), w3 = old[it].w + (v.w + bv);
@@ -842,6 +864,10 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     p.exp = cms_exp;
     if ((cms_exp & 64) && getenv("UNO_CMS_STAMPS")) p.proj_out = reinterpret_cast<void*>((uintptr_t)strtoull(getenv("UNO_CMS_STAMPS"), nullptr, 0));
     const bool split = wide && !split_off && Ci >= 128 && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0);
+    // the same on 64-channel tiles: layers with Co % 64 == 0 that are not a multiple of 128 wide (conv5's 256 -> 64, the input gradients of
+    // the 64-channel levels) - f32-MFMA-bound in the generic kernel (256 -> 64 at 223^2: 26 GFLOP = 166 us of f32 MFMA peak for 1.02 GB)
+    const bool split64 = !wide && !split_off && Co % 64 == 0 && P >= PT && !act_in && !dgelu_of && !a.proj_w && (!two_dst || p.Co1 % 64 == 0) &&
+                         Ci >= 128 && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0);
     if (two_src && (p.C1 < CM_KC || p.C1 >= Ci || p.C1 % CM_KC)) {
         set_error("channel_mix: a two-source call splits the input channels at a multiple of %d inside (0, Ci) (got %d of %d)", CM_KC, p.C1, Ci);
         return -2;
@@ -871,9 +897,16 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     }
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
-        ProfScope prof(split ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
+        ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
-        if (split) {
+        if (split64) {
+            const dim3 grid((unsigned)(8 * p.per_xcd), B);
+            const bool trw = p.w_so == 1 && p.w_si != 1;
+#define UNO_CMS64(BF_, TR_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, 0, 64>), grid, dim3(256), 0, s, p)
+            if (bf16) { if (trw) UNO_CMS64(true, true); else UNO_CMS64(true, false); }
+            else { if (trw) UNO_CMS64(false, true); else UNO_CMS64(false, false); }
+#undef UNO_CMS64
+        } else if (split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
             const bool trw = p.w_so == 1 && p.w_si != 1;
 #define UNO_CMS(BF_, TR_, XP_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, XP_>), grid, dim3(256), 0, s, p)
