@@ -456,6 +456,83 @@ def test_split_bf16_64_channel_tiles(B, C1, C2, Co, P):
     assert rel(yb.float(), _ref(xb.float(), w, b)) < 3e-3
 
 
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("Co", [64, 128, 192])
+def test_split_bf16_gelu_on_read_and_projection(Co, bf):
+    """K8-S with the GELU applied to the first source as it is staged (fc1 behind conv5: darcy_flow_uno2d.py:126-129) and, on a
+    64-channel layer, the fused one-channel projection fc2(gelu(y))"""
+    from uno_amd import _native
+    B, C1, C2, P = 2, 128, 64, 128 * 5 + 37
+    g = torch.Generator().manual_seed(Co + 7)
+    x1, x2 = torch.randn(B, C1, P, generator=g).cuda(), torch.randn(B, C2, P, generator=g).cuda()
+    w = (torch.randn(Co, C1 + C2, generator=g) / 14.0).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    if bf:
+        x1, x2 = x1.to(torch.bfloat16), x2.to(torch.bfloat16)
+    ref = _ref(torch.cat([_gelu64(x1.float()), x2.double()], 1), w, b)
+    tol = 4e-3 if bf else 2e-6
+    y, names = _launched(lambda: _native.channel_mix2(x1, x2, w, b, act_in=True))
+    assert names == ["uno::channel_mix_split_kernel"], names
+    assert rel(y.float(), ref) < tol
+    if Co == 64:
+        w2, b2 = torch.randn(Co, generator=g).cuda(), torch.randn(1, generator=g).cuda()
+        (y2, proj), names = _launched(lambda: _native.channel_mix2(x1, x2, w, b, act_in=True, project=(w2, b2)))
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert torch.equal(y2, y)
+        pref = b2.double() + torch.einsum("o,bop->bp", w2.double(), _gelu64(ref))
+        assert rel(proj.float(), pref) < (1e-2 if bf else 5e-6)
+
+
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("Co,Co1", [(192, 64), (256, 128), (128, 128), (64, 64)])
+def test_split_bf16_gelu_derivative_epilogue(Co, Co1, bf):
+    """the input-gradient call of a layer behind a fused-GELU block: gelu'(pre) on the first destination, written or accumulated, and in
+    its 'completed sum' form (accumulate = 2: (old + product) * gelu')"""
+    from uno_amd import _native
+    B, Ci, P = 2, 128, 128 * 4 + 19
+    g = torch.Generator().manual_seed(Co + Co1)
+    gy = torch.randn(B, Ci, P, generator=g).cuda()
+    w = (torch.randn(Ci, Co, generator=g) / 11.0).cuda()
+    pre = torch.randn(B, Co1, P, generator=g).cuda()
+    if bf:
+        gy, pre = gy.to(torch.bfloat16), pre.to(torch.bfloat16)
+    tol = 4e-3 if bf else 2e-6
+    full = torch.matmul(w.double().t(), gy.double())
+    pd = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(pd).sum().backward()
+    d = pd.grad
+    if Co1 < Co:
+        (g1, g2), names = _launched(lambda: _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=Co1, dgelu_of=pre))
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert rel(g1.float(), full[:, :Co1] * d) < tol and rel(g2.float(), full[:, Co1:]) < tol
+    else:
+        g1, names = _launched(lambda: _native.channel_mix(gy, w, None, transpose_w=True, dgelu_of=pre))
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert rel(g1.float(), full * d) < tol
+        base = torch.randn(B, Co, P, generator=g).cuda().to(gy.dtype)
+        out = base.clone()
+        _native.channel_mix(gy, w, None, transpose_w=True, out=out, dgelu_of=pre)
+        assert rel(out.float(), base.double() + full * d) < tol
+        out = base.clone()
+        _, names = _launched(lambda: _native.channel_mix(gy, w, None, transpose_w=True, out=out, dgelu_of=pre, dgelu_total=True))
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert rel(out.float(), (base.double() + full) * d) < tol
+
+
+def test_split_bf16_narrow_inputs_on_bf16_activations():
+    """bf16 activations: the bf16-MFMA form from 32 input channels on (the lift 32 -> 64, the 64-channel levels' input gradients)"""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(3)
+    for Ci, Co in ((32, 64), (64, 128), (64, 64)):
+        x = torch.randn(2, Ci, 1000, generator=g).cuda().to(torch.bfloat16)
+        w, b = (torch.randn(Co, Ci, generator=g) / 6.0).cuda(), torch.randn(Co, generator=g).cuda()
+        y, names = _launched(lambda: _native.channel_mix(x, w, b))
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert rel(y.float(), _ref(x.float(), w, b)) < 4e-3
+        yf, names = _launched(lambda: _native.channel_mix(x.float(), w, b))
+        assert names != ["uno::channel_mix_split_kernel"], names              # f32 activations: from 128 input channels on
+
+
 def test_split_bf16_wide_layers_bf16_activations():
     from uno_amd import _native
     g = torch.Generator().manual_seed(11)

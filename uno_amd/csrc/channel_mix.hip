@@ -561,13 +561,16 @@ constexpr int CMS_FALLBACK = 2 * CM_KC * (CM_PT + 16) * 4 + 2 * CM_KC * CM_WS * 
 
 // CT: output channels per tile, 128 or 64 (layers with Co % 64 == 0 only: conv5's 256 -> 64, the input gradients of the 64-channel
 // levels).  CT = 64: the four waves are four pixel quarters (32 pixels x 64 channels = 2 x 4 accumulator tiles each).
-template <bool BF, bool TR, int XP = 0, int CT = 128>      // TR: W contiguous along the output channel (input-gradient call); XP: development knock-outs / stamps
+// ACT: x := gelu(x) for the channels of the first source as they are staged (the layer's input is kept pre-activation: fc1 behind conv5,
+// darcy_flow_uno2d.py:126-129); gelu(x) is an f32 value, so bf16 activations take three pieces as well.  Epilogues as in the generic
+// kernel: `dgelu_of` (gelu' of the saved pre-activation on the first destination), the fused one-channel projection (CT = 64, Co = 64).
+template <bool BF, bool TR, int XP = 0, int CT = 128, bool ACT = false>      // TR: W contiguous along the output channel (input-gradient call); XP: development knock-outs / stamps
 __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixParams p) {
     constexpr bool tr = TR;
     constexpr int MW = CT == 128 ? 4 : 2;               // pixel tiles (of 16) per wave
     using T = typename IoElem<BF>::type;
     constexpr int PT = CM_PT;
-    constexpr int NPX = BF ? 1 : 3;                     // pieces of the X operand
+    constexpr int NPX = (BF && !ACT) ? 1 : 3;           // pieces of the X operand
     constexpr int LDS_MAIN = NPX * CMS_XPLANE + 3 * CMS_WPLANE;
     __shared__ __attribute__((aligned(16))) char smem[LDS_MAIN > CMS_FALLBACK ? LDS_MAIN : CMS_FALLBACK];
     char* sXb = smem;
@@ -578,10 +581,13 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     if (p0 + PT > p.P) {            // the last, partial pixel tile of a row: the guarded 64-channel path (twice for a 128-channel tile, as the wide kernel)
         auto sXn = reinterpret_cast<float (*)[CM_KC * (PT + 16)]>(smem);
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(smem + 2 * CM_KC * (PT + 16) * 4);
-        channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0, b);
-        if constexpr (CT == 128) {
-            __syncthreads();
-            channel_mix_tile<1, PT, false, false, BF>(p, sXn, sWn, p0, o0 + 64, b);
+        // (the generic tile code with the same flags: ACT as a template parameter, gelu' / projection by its run-time pointers)
+        if (p.dgelu_of) {
+            channel_mix_tile<1, PT, false, true, BF>(p, sXn, sWn, p0, o0, b);
+            if constexpr (CT == 128) { __syncthreads(); channel_mix_tile<1, PT, false, true, BF>(p, sXn, sWn, p0, o0 + 64, b); }
+        } else {
+            channel_mix_tile<1, PT, ACT, false, BF>(p, sXn, sWn, p0, o0, b);
+            if constexpr (CT == 128) { __syncthreads(); channel_mix_tile<1, PT, ACT, false, BF>(p, sXn, sWn, p0, o0 + 64, b); }
         }
         return;
     }
@@ -594,7 +600,9 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;
 
     float4 rx[4], rw[4];
+    bool act_ld = false;                                 // (uniform) the chunk in the registers belongs to the first source
     auto load_chunk = [&](int k0) {
+        act_ld = ACT && k0 < C1;
         const T* cb = k0 < C1 ? xb : xb2;                // a 32-channel chunk lies in one source (C1 % 32 == 0)
         const int kb = k0 < C1 ? k0 : k0 - C1;
 #pragma unroll
@@ -633,7 +641,8 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
             const int e = tid + 256 * u;
             {
                 char* d = sXb + (e >> 5) * CMS_XRS + (e & 31) * 8;
-                if constexpr (BF) {
+                if constexpr (ACT) { if (act_ld) rx[u] = cm_gelu4(rx[u]); }
+                if constexpr (NPX == 1) {
                     *reinterpret_cast<uint2*>(d) = make_uint2(bf16_pack2(rx[u].x, rx[u].y), bf16_pack2(rx[u].z, rx[u].w));      // exact: widened bf16
                 } else {
                     unsigned h0, m0, l0, h1, m1, l1;
@@ -689,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
                 continue;
             }
             // smallest products first; the four channel tiles between two uses of an accumulator
-            if constexpr (!BF) {
+            if constexpr (NPX == 3) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[NPX > 2 ? 2 : 0], Wop[t][0], acc[m][t]);
 #pragma unroll
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[0], Wop[t][2], acc[m][t]);
-            if constexpr (!BF) {
+            if constexpr (NPX == 3) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[m][t] = cms_mfma(Xp[NPX > 1 ? 1 : 0], Wop[t][0], acc[m][t]);
             }
@@ -745,6 +754,31 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     float bias_l[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bias_l[t] = p.bias ? p.bias[o0 + wch + 16 * t + r16] : 0.f;
+    // gelu' of the saved pre-activation: first destination only (o0 < Co1: the whole tile or nothing)
+    const T* const dall = (p.dgelu_of && o0 < p.Co1) ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * p.P : nullptr;
+    if constexpr (CT == 64) {
+        // fused projection fc2(gelu(y)) with one output channel (Co = 64: the wave holds all channels of its 32 pixels): per lane the
+        // sum over its four channel tiles, then over the 16 lanes of a k-group (fixed butterfly order), four consecutive pixels per store
+        if (p.proj_w) {
+            float pw[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pw[t] = p.proj_w[o0 + 16 * t + r16];
+            const float pb = p.proj_b ? p.proj_b[0] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                float ps[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sum = fmaf(pw[t], cm_gelu(acc[m][t][r] + bias_l[t]), sum);
+                    sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+                    ps[r] = sum + pb;
+                }
+                if (r16 == 0) io_store4(reinterpret_cast<T*>(p.proj_out) + (size_t)b * p.P + p0 + wpx + 16 * m + 4 * kk, ps[0], ps[1], ps[2], ps[3]);
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int ob = o0 + wch + 16 * t;
@@ -755,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         constexpr int NIT = 16 / RPI;                   // store instructions per 16-channel tile: 4 | 2
-        float4 old[NIT];
+        float4 old[NIT], pre[NIT];
         T* dst[NIT];
         size_t aoff[NIT];
 #pragma unroll
@@ -765,13 +799,20 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
             aoff[it] = (size_t)o * p.P + p0 + wpx + c4;
             if (p.accumulate) old[it] = io_ld4(dst[it]);
             else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dall) pre[it] = io_ld4(dall + aoff[it]);        // (first destination: channel index o, Co1 rows per batch entry)
+            else pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = RPI * it + lane / LPR;
             const float4 v = *reinterpret_cast<const float4*>(sT + row * OS + c4);
             const float bv = __shfl(bias_l[t], row);
-            const float w0 = old[it].x + (v.x + bv), w1 = old[it].y + (v.y + bv), w2 = old[it].z + (v.z + bv), w3 = old[it].w + (v.w + bv);
+            float w0 = old[it].x + (v.x + bv), w1 = old[it].y + (v.y + bv), w2 = old[it].z + (v.z + bv), w3 = old[it].w + (v.w + bv);
+            if (dall) {
+                const float d0 = cm_dgelu(pre[it].x), d1 = cm_dgelu(pre[it].y), d2 = cm_dgelu(pre[it].z), d3 = cm_dgelu(pre[it].w);
+                if (p.accumulate == 2) { w0 *= d0; w1 *= d1; w2 *= d2; w3 *= d3; }        // gelu' on the completed sum
+                else { w0 = fmaf(v.x + bv, d0, old[it].x); w1 = fmaf(v.y + bv, d1, old[it].y); w2 = fmaf(v.z + bv, d2, old[it].z); w3 = fmaf(v.w + bv, d3, old[it].w); }
+            }
             io_store4(dst[it], w0, w1, w2, w3);
             if (aall) io_store4(aall + aoff[it], cm_gelu(w0), cm_gelu(w1), cm_gelu(w2), cm_gelu(w3));
         }
@@ -863,11 +904,15 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     static const int cms_exp = getenv("UNO_CMS_EXP") ? atoi(getenv("UNO_CMS_EXP")) : 0;
     p.exp = cms_exp;
     if ((cms_exp & 64) && getenv("UNO_CMS_STAMPS")) p.proj_out = reinterpret_cast<void*>((uintptr_t)strtoull(getenv("UNO_CMS_STAMPS"), nullptr, 0));
-    const bool split = wide && !split_off && Ci >= 128 && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0);
-    // the same on 64-channel tiles: layers with Co % 64 == 0 that are not a multiple of 128 wide (conv5's 256 -> 64, the input gradients of
-    // the 64-channel levels) - f32-MFMA-bound in the generic kernel (256 -> 64 at 223^2: 26 GFLOP = 166 us of f32 MFMA peak for 1.02 GB)
-    const bool split64 = !wide && !split_off && Co % 64 == 0 && P >= PT && !act_in && !dgelu_of && !a.proj_w && (!two_dst || p.Co1 % 64 == 0) &&
-                         Ci >= 128 && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0);
+    // f32 activations: from 128 input channels on; bf16 activations move half the bytes, there the f32 MFMA is the ceiling from 32 on
+    // (profiles/r04_c5_mixed_kernel_stats.csv: the generic forms on bf16 were 4.8 of the mixed C5 step's 16 ms)
+    const bool trw_ = a.transpose_w != 0;
+    const bool s_common = !split_off && P >= PT && Ci >= (bf16 ? 32 : 128) && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0) && !(act_in && trw_);
+    const bool split = s_common && Co % 128 == 0 && !a.proj_w && (!two_dst || p.Co1 % 128 == 0);
+    // the same on 64-channel tiles: layers with Co % 64 == 0 that are not a multiple of 128 wide (conv5's 256 -> 64, fc1 with its fused
+    // projection, the input gradients of the 64-channel levels) - f32-MFMA-bound in the generic kernel (256 -> 64 at 223^2: 26 GFLOP =
+    // 166 us of f32 MFMA peak for 1.02 GB)
+    const bool split64 = s_common && !split && Co % 64 == 0 && (!two_dst || p.Co1 % 64 == 0) && (!a.proj_w || Co == 64);
     if (two_src && (p.C1 < CM_KC || p.C1 >= Ci || p.C1 % CM_KC)) {
         set_error("channel_mix: a two-source call splits the input channels at a multiple of %d inside (0, Ci) (got %d of %d)", CM_KC, p.C1, Ci);
         return -2;
@@ -877,7 +922,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         return -2;
     }
     if (a.y_act && (two_dst || dgelu_of)) { set_error("channel_mix: the activated second output goes with a single destination and no dgelu_of"); return -2; }
-    const long long npt = (P + PT - 1) / PT, ncot = wide ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
+    const long long npt = (P + PT - 1) / PT, ncot = (wide || split) ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
@@ -899,29 +944,24 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         const double dgc = dgelu_of ? p.Co1 : 0;
         ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
-        if (split64) {
+        if (split64 || split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
             const bool trw = p.w_so == 1 && p.w_si != 1;
-#define UNO_CMS64(BF_, TR_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, 0, 64>), grid, dim3(256), 0, s, p)
-            if (bf16) { if (trw) UNO_CMS64(true, true); else UNO_CMS64(true, false); }
-            else { if (trw) UNO_CMS64(false, true); else UNO_CMS64(false, false); }
-#undef UNO_CMS64
-        } else if (split) {
-            const dim3 grid((unsigned)(8 * p.per_xcd), B);
-            const bool trw = p.w_so == 1 && p.w_si != 1;
-#define UNO_CMS(BF_, TR_, XP_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, XP_>), grid, dim3(256), 0, s, p)
-#ifdef UNO_CMS_DEV          // development build: knock-out / stamp instantiations (f32 activations) selected by UNO_CMS_EXP
-#define UNO_CMS_X(XP_) case XP_: if (trw) UNO_CMS(false, true, XP_); else UNO_CMS(false, false, XP_); break;
-            if (!bf16 && cms_exp) {
+#define UNO_CMS(BF_, TR_, XP_, CT_, ACT_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, XP_, CT_, ACT_>), grid, dim3(256), 0, s, p)
+#define UNO_CMS_T(BF_, CT_) do { if (act_in) UNO_CMS(BF_, false, 0, CT_, true); else if (trw) UNO_CMS(BF_, true, 0, CT_, false); else UNO_CMS(BF_, false, 0, CT_, false); } while (0)
+#ifdef UNO_CMS_DEV          // development build: knock-out / stamp instantiations (f32 activations, 128-channel tiles) selected by UNO_CMS_EXP
+#define UNO_CMS_X(XP_) case XP_: if (trw) UNO_CMS(false, true, XP_, 128, false); else UNO_CMS(false, false, XP_, 128, false); break;
+            if (!bf16 && cms_exp && split && !act_in) {
                 switch (cms_exp) {
                     UNO_CMS_X(1) UNO_CMS_X(2) UNO_CMS_X(4) UNO_CMS_X(6) UNO_CMS_X(8) UNO_CMS_X(16) UNO_CMS_X(31) UNO_CMS_X(64) UNO_CMS_X(70)
-                    default: if (trw) UNO_CMS(false, true, 0); else UNO_CMS(false, false, 0);
+                    default: UNO_CMS_T(false, 128);
                 }
             } else
 #undef UNO_CMS_X
 #endif
-            if (bf16) { if (trw) UNO_CMS(true, true, 0); else UNO_CMS(true, false, 0); }
-            else { if (trw) UNO_CMS(false, true, 0); else UNO_CMS(false, false, 0); }
+            if (split) { if (bf16) UNO_CMS_T(true, 128); else UNO_CMS_T(false, 128); }
+            else { if (bf16) UNO_CMS_T(true, 64); else UNO_CMS_T(false, 64); }
+#undef UNO_CMS_T
 #undef UNO_CMS
         }
         else if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
