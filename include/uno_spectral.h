@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 8
+#define UNO_SPECTRAL_ABI_VERSION 9
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -262,12 +262,16 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
                         double weight_decay, int step, void* stream);
 
 /* The same with the step count kept ON THE DEVICE (ABI 7), so that the update can be captured in a HIP graph and replayed:
- * `step_counter` (one int32, zero before the first step) is advanced by one and the bias corrections lr / (1 - beta1^t),
- * 1 / sqrt(1 - beta2^t) are evaluated in double by a one-thread kernel into `scalars` (two floats of device scratch owned by the
- * caller), which the update kernel reads instead of kernel arguments.  Same arithmetic as uno_adam_step_multi with step = t. */
+ * `step_counter` (one int32, the number of steps taken so far: zero before the first step, the loaded count after a resume) is
+ * advanced by one and the bias corrections lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) are evaluated in double by a one-thread kernel
+ * into `scalars` (FOUR floats of device scratch owned by the caller: the two corrections, eps, weight_decay), which the update
+ * kernel reads instead of kernel arguments.  Same arithmetic as uno_adam_step_multi with step = t.
+ * ABI 9: `hyper` (NULL, or three doubles on the device: lr, eps, weight_decay) - when given, the three are read from the device at
+ * execution time instead of from the arguments, so a learning-rate schedule (reference ns_train_2d.py:37,113) takes effect on
+ * the next replay of a captured step: the caller rewrites the doubles between replays. */
 int uno_adam_step_multi_dev(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                             const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, int* step_counter, float* scalars, void* stream);
+                            double weight_decay, int* step_counter, float* scalars, const double* hyper, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Mixed precision (BASELINE.json configs[4]: bf16 activations, half-precision weight storage, f32 accumulation).

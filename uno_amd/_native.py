@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 _lock = threading.Lock()
@@ -68,7 +68,7 @@ _SIGNATURES = {
     "uno_adam_step_multi": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
                                       C.POINTER(_i)] + [C.c_double] * 5 + [_i, _fp]),
     "uno_adam_step_multi_dev": (C.c_int, [_i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(C.c_longlong),
-                                          C.POINTER(_i)] + [C.c_double] * 5 + [_fp, _fp, _fp]),
+                                          C.POINTER(_i)] + [C.c_double] * 5 + [_fp, _fp, _fp, _fp]),
     "uno_spectral_conv2d_forward_mixed": (C.c_int, [_fp] * 6 + [_i] * 9 + [_fp]),
     "uno_spectral_conv2d_backward_mixed": (C.c_int, [_fp] * 8 + [_i] * 9 + [_fp]),
     "uno_mode_mix_f16w": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
@@ -868,12 +868,17 @@ class AdamPlan:
                                            weight_decay, int(step), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         _check(rc, "uno_adam_step_multi")
 
-    def step_dev(self, counter, scalars, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
-        """the update with the step count on the device (`counter`: int32 tensor of one element, advanced here; `scalars`: two floats
-        of scratch): capturable in a HIP graph"""
+    def step_dev(self, counter, scalars, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, hyper=None):
+        """the update with the step count on the device (`counter`: int32 tensor of one element, advanced here; `scalars`: four floats
+        of scratch; `hyper`: None or a float64 tensor (lr, eps, weight_decay) read at execution time instead of the arguments):
+        capturable in a HIP graph"""
+        if scalars.numel() < 4 or scalars.dtype != torch.float32 or counter.dtype != torch.int32:
+            raise RuntimeError("uno_amd: Adam device scratch must be an int32 counter and four float32 scalars")
+        if hyper is not None and (hyper.dtype != torch.float64 or hyper.numel() < 3 or hyper.device != self.device):
+            raise RuntimeError("uno_amd: Adam device hyper-parameters must be three float64 values on the parameters' device")
         with torch.cuda.device(self.device):
             rc = lib().uno_adam_step_multi_dev(self.n, self.p, self.g, self.m, self.v, self.sizes, self.cplx, lr, beta1, beta2, eps,
-                                               weight_decay, _ptr(counter), _ptr(scalars),
+                                               weight_decay, _ptr(counter), _ptr(scalars), _ptr(hyper) if hyper is not None else None,
                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         _check(rc, "uno_adam_step_multi_dev")
 

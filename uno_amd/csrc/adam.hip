@@ -86,24 +86,30 @@ struct AdamMultiParams {
     unsigned cplx_mask;
     int n_tensors;
     AdamScalars a;
-    const float* dev_scalars;       // optional: {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} on the device (step count kept on the device)
+    const float* dev_scalars;       // optional: {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), eps, wd} on the device (step count kept on the device)
 };
 
 // Step count on the DEVICE (so that the update can be part of a captured HIP graph: the bias corrections then cannot be kernel
 // arguments, reference Adam.py:27-52 computes them from state['step'] on the host): one thread advances the counter and evaluates
-// the two step-dependent scalars in double, as the host path does.
-__global__ void adam_advance_kernel(int* step, float* scalars, double lr, double beta1, double beta2) {
+// the two step-dependent scalars in double, as the host path does.  `hyper` (optional): {lr, eps, weight_decay} as doubles ON THE
+// DEVICE - a learning-rate schedule (reference ns_train_2d.py:37,113: StepLR) changes group['lr'] between replays of a captured
+// step, and a kernel argument would be frozen into the graph; the caller refreshes the three doubles before a replay instead.
+__global__ void adam_advance_kernel(int* step, float* scalars, const double* hyper, double lr, double eps, double wd, double beta1,
+                                    double beta2) {
     const int t = *step + 1;
     *step = t;
+    if (hyper) { lr = hyper[0]; eps = hyper[1]; wd = hyper[2]; }
     scalars[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
     scalars[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+    scalars[2] = (float)eps;
+    scalars[3] = (float)wd;
 }
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiParams q) {
     // (the argument struct itself must stay read-only: written to, it is copied to scratch memory and the descriptor look-up
     // below goes through it - measured 52 ms instead of 4 ms on the NS-3D parameter set)
     AdamScalars a = q.a;
-    if (q.dev_scalars) { a.step_size = q.dev_scalars[0]; a.inv_sqrt_bc2 = q.dev_scalars[1]; }
+    if (q.dev_scalars) { a.step_size = q.dev_scalars[0]; a.inv_sqrt_bc2 = q.dev_scalars[1]; a.eps = q.dev_scalars[2]; a.wd = q.dev_scalars[3]; }
     int t = 0;
 #pragma unroll 1
     for (int i = 1; i < q.n_tensors; ++i)
@@ -123,8 +129,9 @@ static AdamScalars adam_scalars(double lr, double beta1, double beta2, double ep
     return a;
 }
 
-int launch_adam_advance(int* step, float* scalars, double lr, double beta1, double beta2, hipStream_t s) {
-    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step, scalars, lr, beta1, beta2);
+int launch_adam_advance(int* step, float* scalars, const double* hyper, double lr, double eps, double wd, double beta1, double beta2,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step, scalars, hyper, lr, eps, wd, beta1, beta2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("adam advance launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

@@ -23,25 +23,26 @@ void set_error(const char* fmt, ...) {
 
 // (cos, sin)(2 pi n / N) evaluated in double with the phase reduced in integers, exact at the
 // multiples of pi/2 (so that sin(pi l) terms of Nyquist / w = 0 columns vanish identically).
+float2 twiddle_value(long long n, int N) {
+    const double two_pi = 6.283185307179586476925286766559;
+    double c, s;
+    const long long n4 = 4LL * n;
+    if (n4 % N == 0) {
+        switch ((n4 / N) & 3) {
+            case 0: c = 1; s = 0; break;
+            case 1: c = 0; s = 1; break;
+            case 2: c = -1; s = 0; break;
+            default: c = 0; s = -1; break;
+        }
+    } else {
+        c = std::cos(two_pi * n / N);
+        s = std::sin(two_pi * n / N);
+    }
+    return make_float2((float)c, (float)s);
+}
 static void fill_twiddles(int N, std::vector<float2>& t) {
     t.resize(N);
-    const double two_pi = 6.283185307179586476925286766559;
-    for (int n = 0; n < N; ++n) {
-        double c, s;
-        const long long n4 = 4LL * n;
-        if (n4 % N == 0) {
-            switch ((n4 / N) & 3) {
-                case 0: c = 1; s = 0; break;
-                case 1: c = 0; s = 1; break;
-                case 2: c = -1; s = 0; break;
-                default: c = 0; s = -1; break;
-            }
-        } else {
-            c = std::cos(two_pi * n / N);
-            s = std::sin(two_pi * n / N);
-        }
-        t[n] = make_float2((float)c, (float)s);
-    }
+    for (int n = 0; n < N; ++n) t[n] = twiddle_value(n, N);
 }
 
 const float2* twiddle_table(int N) {
@@ -524,7 +525,7 @@ int uno_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
 
 int uno_adam_step_multi_dev(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                             const long long* n, const int* is_complex, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, int* step_counter, float* scalars, void* stream) {
+                            double weight_decay, int* step_counter, float* scalars, const double* hyper, void* stream) {
     if (n_tensors < 0 || (n_tensors > 0 && (!p || !g || !m || !v || !n || !is_complex)) || !step_counter || !scalars) {
         set_error("uno_adam_step_multi_dev: bad arguments");
         return -1;
@@ -534,7 +535,7 @@ int uno_adam_step_multi_dev(int n_tensors, float* const* p, const float* const* 
         if (n[t] < 0) { set_error("uno_adam_step_multi_dev: tensor %d has n=%lld", t, n[t]); return -1; }
         if (n[t] > 0 && (!p[t] || !g[t] || !m[t] || !v[t])) { set_error("uno_adam_step_multi_dev: null pointer (tensor %d)", t); return -1; }
     }
-    if (int rc = launch_adam_advance(step_counter, scalars, lr, beta1, beta2, (hipStream_t)stream)) return rc;
+    if (int rc = launch_adam_advance(step_counter, scalars, hyper, lr, eps, weight_decay, beta1, beta2, (hipStream_t)stream)) return rc;
     return launch_adam_multi(n_tensors, p, g, m, v, n, is_complex, lr, beta1, beta2, eps, weight_decay, 1, (hipStream_t)stream, scalars);
 }
 

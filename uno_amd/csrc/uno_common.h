@@ -190,9 +190,11 @@ struct Vol3dParams {
     int n_vol, D1, D2, D3, m1, m2, m3;
     float scale;
     int herm;               // 1: multiply T-mode l by the Hermitian weight c_l of D3
+    const float* ctab;      // host-built operand table of the kernel (filled in by the launcher)
 };
 
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
+float2 twiddle_value(long long n, int N);      // host: (cos, sin)(2 pi n / N) as the tables hold it (f32 from f64, exact at multiples of pi / 2)
 
 // Raise a kernel's dynamic-LDS limit to the largest size any launch of it (on this device) has asked for so far.  The driver call is
 // made only when the request grows: it costs tens of microseconds, and the transforms are launched thousands of times per step.
@@ -250,7 +252,8 @@ int launch_channel_mix(const void* x, const float* w, const float* bias, void* y
 int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
                       const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s,
                       const float* dev_scalars = nullptr);
-int launch_adam_advance(int* step, float* scalars, double lr, double beta1, double beta2, hipStream_t s);
+int launch_adam_advance(int* step, float* scalars, const double* hyper, double lr, double eps, double wd, double beta1, double beta2,
+                        hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, int is_complex, double lr, double beta1, double beta2,
                 double eps, double wd, int step, hipStream_t s);
 int launch_gelu_project_fwd(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, hipStream_t s);
