@@ -20,6 +20,7 @@
 #include "uno_common.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace uno {
 
@@ -236,8 +237,14 @@ __device__ __forceinline__ float lane_pull(int src_lane_x4, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_x4, __float_as_int(v)));
 }
 
+// adjacent_modes: the (4 / KS) wave groups of a workgroup take ADJACENT MODE GROUPS of the same columns instead of adjacent column groups of
+// one mode group - their 128-byte pieces are then neighbours in memory (512-byte runs requested together).  Round 5 sweep (tools/dev/k2dev.py:
+// twenty layer shapes x three roles x KS x this switch, cold operands, every configuration checked against the float64 einsum): it pays
+// on the 3-D layers with ~1000 modes or more per corner and enough channels to fill the chip with such workgroups - C4 block forward
+// 27.2 -> 20.8 us, input gradient 28.2 -> 22.8, weight gradient 23.3 -> 19.9; Uno3D_T20 (width 32) layer 1 65 -> 57 / 65 -> 59 / 71 -> 62,
+// layer 2 81 -> 75 / 83 -> 69 - and loses everywhere else (C2 block 17 -> 26, 256 x 256 channels at 64 modes weight gradient 25 -> 76).
 template <int MTW, int NTW, int K2B_PF, bool BH, bool ACC = false>
-__global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p, int KS, int ngw, int per_group) {
+__global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p, int KS, int ngw, int per_group, int adjacent_modes) {
     extern __shared__ __attribute__((aligned(16))) float smb[];
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -250,10 +257,12 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
     // XCD's L2 instead of being fetched over the fabric once per workgroup.
     const int nq = (p.Mc + 15) >> 4;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int grp = (slot / per_group) * 8 + xcd, within = slot % per_group;      // mode group, (column-group workgroup, row group) inside it
+    int grp = (slot / per_group) * 8 + xcd;                                        // mode group (adjacent_modes: group of 4 / KS)
+    const int within = slot % per_group;                                           // (column-group workgroup, row group) inside it
+    if (adjacent_modes) grp = (4 / KS) * grp + wave / KS;
     if (grp >= p.ncorner * nq) return;
     const int corner = grp / nq, q0 = (grp % nq) * 16;
-    const int kidx = wave % KS, ng = (within % ngw) * (4 / KS) + wave / KS;
+    const int kidx = wave % KS, ng = adjacent_modes ? within % ngw : (within % ngw) * (4 / KS) + wave / KS;
     const int n0 = ng * 4 * NTW, m0 = (within / ngw) * 4 * MTW;
     const bool active = n0 < p.N;
     constexpr int ESB = BH ? 4 : 8;
@@ -411,16 +420,27 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
 }
 
 template <int MTW, int NTW, int PF>
-static void launch_blocks_t(const ModeGemmParams& p, int KS, hipStream_t s) {
+static void launch_blocks_t(const ModeGemmParams& p, int KS, int adjacent_modes, hipStream_t s) {
+#ifdef UNO_K2_DEV
+    if (getenv("UNO_K2_KS") && atoi(getenv("UNO_K2_KS"))) KS = atoi(getenv("UNO_K2_KS"));
+    if (getenv("UNO_K2_REMAP")) adjacent_modes = atoi(getenv("UNO_K2_REMAP"));
+#endif
     const int nq = (p.Mc + 15) / 16;
     const int ngroups = (p.N + 4 * NTW - 1) / (4 * NTW), mgroups = (p.M + 4 * MTW - 1) / (4 * MTW);
-    const int per_wg = 4 / KS;
+    const int per_wg = adjacent_modes ? 1 : 4 / KS;
     const int ngw = (ngroups + per_wg - 1) / per_wg, per_group = ngw * mgroups;
-    dim3 grid(((p.ncorner * nq + 7) / 8) * 8 * per_group);
+    const int sub = 4 / KS;
+    const int wg_groups = adjacent_modes ? (p.ncorner * nq + sub - 1) / sub : p.ncorner * nq;      // mode groups (sets of them) dealt to the XCDs
+    dim3 grid(((wg_groups + 7) / 8) * 8 * per_group);
     const size_t lds = KS > 1 ? (size_t)4 * MTW * NTW * 8 * 64 * sizeof(float) : 0;
-    if (p.B.half) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
-    else if (p.accumulate) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
-    else hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false>), grid, dim3(256), lds, s, p, KS, ngw, per_group);
+    static int lds_slot[3][64];
+    const void* k = p.B.half ? reinterpret_cast<const void*>(mode_gemm_blocks_kernel<MTW, NTW, PF, true>)
+                  : p.accumulate ? reinterpret_cast<const void*>(mode_gemm_blocks_kernel<MTW, NTW, PF, false, true>)
+                                 : reinterpret_cast<const void*>(mode_gemm_blocks_kernel<MTW, NTW, PF, false>);
+    ensure_dynamic_lds(k, lds, lds_slot[p.B.half ? 0 : p.accumulate ? 1 : 2]);
+    if (p.B.half) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group, adjacent_modes);
+    else if (p.accumulate) hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false, true>), grid, dim3(256), lds, s, p, KS, ngw, per_group, adjacent_modes);
+    else hipLaunchKernelGGL((mode_gemm_blocks_kernel<MTW, NTW, PF, false>), grid, dim3(256), lds, s, p, KS, ngw, per_group, adjacent_modes);
 }
 
 // 16 modes: one staging buffer (33.8 KB, also holds the 34.8 KB output tile); 8 modes: two (34.8 KB)
@@ -465,15 +485,18 @@ int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {
             const bool square = short_k;
             const bool wide_m = p.M > 8;
             const int tm = wide_m ? 16 : 8, tn = wide_m ? 8 : 16;
-            const long long tasks = (long long)p.ncorner * groups * ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn);
-            const int KS = square ? 1 : (tasks < 1024 && p.K >= 32) ? 4 : (tasks < 2048 && p.K >= 16) ? 2 : 1;
+            const long long tiles_per_group = (long long)((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn);
+            const long long tasks = (long long)p.ncorner * groups * tiles_per_group;
+            // many mode groups per corner and at least one four-group workgroup per CU: adjacent mode groups, no K split (see the kernel)
+            const bool adjacent = groups >= 48 && (long long)((p.ncorner * groups + 3) / 4) * tiles_per_group >= 200;
+            const int KS = (square || adjacent) ? 1 : (tasks < 1024 && p.K >= 32) ? 4 : (tasks < 2048 && p.K >= 16) ? 2 : 1;
             char name[64];
             snprintf(name, sizeof(name), "uno::mode_gemm_blocks_kernel<%s, %s, %s>", square ? "4, 4, 2" : wide_m ? "4, 2, 4" : "2, 4, 4", p.B.half ? "true" : "false",
                      (p.accumulate && !p.B.half) ? "true" : "false");
             ProfScope prof(name, k2_bytes, s);
-            if (square) launch_blocks_t<4, 4, 2>(p, KS, s);
-            else if (wide_m) launch_blocks_t<4, 2, 4>(p, KS, s);
-            else launch_blocks_t<2, 4, 4>(p, KS, s);
+            if (square) launch_blocks_t<4, 4, 2>(p, KS, adjacent ? 1 : 0, s);
+            else if (wide_m) launch_blocks_t<4, 2, 4>(p, KS, adjacent ? 1 : 0, s);
+            else launch_blocks_t<2, 4, 4>(p, KS, adjacent ? 1 : 0, s);
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) { set_error("mode_gemm launch: %s", hipGetErrorString(e)); return -5; }
             return 0;
