@@ -303,69 +303,47 @@ __global__ __launch_bounds__(64 * VF_WAVES) void dft3d_fwd_volume_kernel(Vol3dPa
     VOL_STAMP_NOWAIT(1);
     VOL_STAMP_NOWAIT(2);
 
-    // ---- phase 1: planes -> paired, twisted per-plane spectra in LDS
-    auto slot_body = [&](int slot, auto prefetch, auto is_slot0) {
-        constexpr bool PREFETCH = decltype(prefetch)::value, SLOT0 = decltype(is_slot0)::value;      // SLOT0: planes 0 and D1 / 2
+    // ---- phase 1: planes -> paired, twisted per-plane spectra in LDS.
+    // Program order inside a wave is what lets VALU work run under the MFMAs (see above), so the stages of consecutive unit positions
+    // are interleaved in the source: while position pos is twisted and goes through its dim2 stage, the T-axis MFMAs of position
+    // pos + 1 (at the last position: of the next slot's first) are already issued, and the plane epilogue of position pos - 1 (VALU
+    // + LDS stores) sits between them.  REM = slots this wave still has, this one included (1, 2, or 3 = more).
+    auto t_axis = [&](const Piece& P_, const Piece& Q_, f32x4& TP_, f32x4& TQ_) {
+        TP_ = f32x4{0, 0, 0, 0}; TQ_ = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NBW; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tw = twA(4 * c + e);
+                TP_ = mfma16(__uint_as_float(P_.w[c][e]), tw, TP_);
+                TQ_ = mfma16(__uint_as_float(Q_.w[c][e]), tw, TQ_);
+            }
+        if (NARROW) {
+            const float tw = twA(4 * NBW);
+            TP_ = mfma16(__uint_as_float(P_.nrw), tw, TP_);
+            TQ_ = mfma16(__uint_as_float(Q_.nrw), tw, TQ_);
+        }
+    };
+    f32x4 TP, TQ;                                                             // T-axis results of the position about to be processed
+    auto slot_body = [&](int slot, auto rem, auto is_slot0) {
+        constexpr int REM = decltype(rem)::value;
+        constexpr bool SLOT0 = decltype(is_slot0)::value;                    // planes 0 and D1 / 2
         const float2 t1 = p.tw1[slot];
         const float t1ys = t1.y * sg;
         float* rowD = sDE + (size_t)slot * 2 * g.RP;
         f32x4 C[MT2], S[MT2], Xa_p[MT2], Xa_m[MT2];
+        // plane epilogues (called one position late)
+        auto first_plane = [&]() {
 #pragma unroll
-        for (int pos = 0; pos < 2 * U; ++pos) {
-            const int second = pos / U, u = pos % U;
-            // T axis: rows of P and Q
-            f32x4 TP = f32x4{0, 0, 0, 0}, TQ = f32x4{0, 0, 0, 0};
+            for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-            for (int c = 0; c < NBW; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float tw = twA(4 * c + e);
-                    TP = mfma16(__uint_as_float(LP[pos].w[c][e]), tw, TP);
-                    TQ = mfma16(__uint_as_float(LQ[pos].w[c][e]), tw, TQ);
+                for (int r = 0; r < 4; ++r) {
+                    const float js = sg * vol_xor1(S[mt][r]);
+                    Xa_p[mt][r] = C[mt][r] - js;
+                    Xa_m[mt][r] = C[mt][r] + js;
                 }
-            if (NARROW) {
-                const float tw = twA(4 * NBW);
-                TP = mfma16(__uint_as_float(LP[pos].nrw), tw, TP);
-                TQ = mfma16(__uint_as_float(LQ[pos].nrw), tw, TQ);
-            }
-            // the rows of this position in the wave's next slot
-            if (PREFETCH) issue(LP[pos], LQ[pos], plane_of(slot + VF_WAVES, second), u);
-            if (u == 0) {
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) { C[mt] = f32x4{0, 0, 0, 0}; S[mt] = f32x4{0, 0, 0, 0}; }
-            }
-            // twist + pair, then the dim2 stage
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float2 t = tws(u, r);                                   // (cos, sin * sg)
-                const float sum = TP[r] + TQ[r], dif = TP[r] - TQ[r];
-                float Dp = t.x * sum + t.y * vol_xor1(dif);
-                float Ep = t.x * dif + t.y * vol_xor1(sum);
-                if (r == 0 && u == 0) {
-                    const float jq = sg * vol_xor1(TQ[0]);
-                    if (gq == 0) { Dp = TP[0]; Ep = even2 ? jq : 0.f; }
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) {
-                    const float2 tb = twB(u, r, mt);
-                    C[mt] = mfma16(tb.x, Dp, C[mt]);
-                    S[mt] = mfma16(tb.y, Ep, S[mt]);
-                }
-            }
-            if (u != U - 1) continue;
-            // plane spectrum: +kappa = C - i S, -kappa = C + i S
-            if (!second) {
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float js = sg * vol_xor1(S[mt][r]);
-                        Xa_p[mt][r] = C[mt][r] - js;
-                        Xa_m[mt][r] = C[mt][r] + js;
-                    }
-                continue;
-            }
-            // second plane of the slot: twist + pair along dim1, to LDS
+        };
+        auto second_plane = [&]() {                                          // twist + pair along dim1, to LDS
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
@@ -388,16 +366,62 @@ __global__ __launch_bounds__(64 * VF_WAVES) void dft3d_fwd_volume_kernel(Vol3dPa
                         rowD[at + g.RP] = Ep;
                     }
                 }
+        };
+#pragma unroll
+        for (int pos = 0; pos < 2 * U; ++pos) {
+            const int u = pos % U;
+            // the T-axis stage one position ahead, and the rows that position needs one slot later
+            f32x4 TPn = f32x4{0, 0, 0, 0}, TQn = f32x4{0, 0, 0, 0};
+            if (pos + 1 < 2 * U) {
+                t_axis(LP[pos + 1], LQ[pos + 1], TPn, TQn);
+                if (REM >= 2) issue(LP[pos + 1], LQ[pos + 1], plane_of(slot + VF_WAVES, (pos + 1) / U), (pos + 1) % U);
+            } else if (REM >= 2) {
+                t_axis(LP[0], LQ[0], TPn, TQn);
+                if (REM >= 3) issue(LP[0], LQ[0], slot + 2 * VF_WAVES, 0);
+            }
+            // the epilogue of the plane the previous position completed
+            if (pos > 0 && (pos - 1) % U == U - 1) first_plane();
+            if (u == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) { C[mt] = f32x4{0, 0, 0, 0}; S[mt] = f32x4{0, 0, 0, 0}; }
+            }
+            // twist + pair, then the dim2 stage
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 t = tws(u, r);                                   // (cos, sin * sg)
+                const float sum = TP[r] + TQ[r], dif = TP[r] - TQ[r];
+                float Dp = t.x * sum + t.y * vol_xor1(dif);
+                float Ep = t.x * dif + t.y * vol_xor1(sum);
+                if (r == 0 && u == 0) {
+                    const float jq = sg * vol_xor1(TQ[0]);
+                    if (gq == 0) { Dp = TP[0]; Ep = even2 ? jq : 0.f; }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) {
+                    const float2 tb = twB(u, r, mt);
+                    C[mt] = mfma16(tb.x, Dp, C[mt]);
+                    S[mt] = mfma16(tb.y, Ep, S[mt]);
+                }
+            }
+            TP = TPn; TQ = TQn;
         }
+        second_plane();
     };
-    int q = 0;
-    if (wave == 0 && my_slots > 0) {
-        if (my_slots > 1) slot_body(0, std::true_type{}, std::true_type{});
-        else slot_body(0, std::false_type{}, std::true_type{});
-        q = 1;
+    // this wave's first slot: its first position's T-axis stage, and that position's rows for the second slot
+    if (my_slots > 0) {
+        t_axis(LP[0], LQ[0], TP, TQ);
+        if (my_slots > 1) issue(LP[0], LQ[0], wave + VF_WAVES, 0);
     }
-    for (; q + 1 < my_slots; ++q) slot_body(wave + VF_WAVES * q, std::true_type{}, std::false_type{});
-    if (q < my_slots) slot_body(wave + VF_WAVES * q, std::false_type{}, std::false_type{});
+    for (int q = 0; q < my_slots; ++q) {
+        const int slot = wave + VF_WAVES * q, remaining = my_slots - q;
+        if (slot == 0) {
+            if (remaining >= 3) slot_body(slot, std::integral_constant<int, 3>{}, std::true_type{});
+            else if (remaining == 2) slot_body(slot, std::integral_constant<int, 2>{}, std::true_type{});
+            else slot_body(slot, std::integral_constant<int, 1>{}, std::true_type{});
+        } else if (remaining >= 3) slot_body(slot, std::integral_constant<int, 3>{}, std::false_type{});
+        else if (remaining == 2) slot_body(slot, std::integral_constant<int, 2>{}, std::false_type{});
+        else slot_body(slot, std::integral_constant<int, 1>{}, std::false_type{});
+    }
     VOL_STAMP(3);
     __syncthreads();
     VOL_STAMP_NOWAIT(4);
