@@ -324,6 +324,9 @@ __global__ __launch_bounds__(64 * VF_WAVES) void dft3d_fwd_volume_kernel(Vol3dPa
             TQ_ = mfma16(__uint_as_float(Q_.nrw), tw, TQ_);
         }
     };
+    // (the variants with the most constants and rows in flight - two tile pairs with two column blocks or two kappa tiles - have no
+    // registers left for the look-ahead: they run the stages of a position in sequence)
+    constexpr bool AHEAD = !(U == 2 && NBW + MT2 > 2);
     f32x4 TP, TQ;                                                             // T-axis results of the position about to be processed
     auto slot_body = [&](int slot, auto rem, auto is_slot0) {
         constexpr int REM = decltype(rem)::value;
@@ -372,7 +375,10 @@ __global__ __launch_bounds__(64 * VF_WAVES) void dft3d_fwd_volume_kernel(Vol3dPa
             const int u = pos % U;
             // the T-axis stage one position ahead, and the rows that position needs one slot later
             f32x4 TPn = f32x4{0, 0, 0, 0}, TQn = f32x4{0, 0, 0, 0};
-            if (pos + 1 < 2 * U) {
+            if (!AHEAD) {
+                t_axis(LP[pos], LQ[pos], TP, TQ);
+                if (REM >= 2) issue(LP[pos], LQ[pos], plane_of(slot + VF_WAVES, pos / U), u);
+            } else if (pos + 1 < 2 * U) {
                 t_axis(LP[pos + 1], LQ[pos + 1], TPn, TQn);
                 if (REM >= 2) issue(LP[pos + 1], LQ[pos + 1], plane_of(slot + VF_WAVES, (pos + 1) / U), (pos + 1) % U);
             } else if (REM >= 2) {
@@ -403,12 +409,12 @@ __global__ __launch_bounds__(64 * VF_WAVES) void dft3d_fwd_volume_kernel(Vol3dPa
                     S[mt] = mfma16(tb.y, Ep, S[mt]);
                 }
             }
-            TP = TPn; TQ = TQn;
+            if (AHEAD) { TP = TPn; TQ = TQn; }
         }
         second_plane();
     };
     // this wave's first slot: its first position's T-axis stage, and that position's rows for the second slot
-    if (my_slots > 0) {
+    if (AHEAD && my_slots > 0) {
         t_axis(LP[0], LQ[0], TP, TQ);
         if (my_slots > 1) issue(LP[0], LQ[0], wave + VF_WAVES, 0);
     }
@@ -724,15 +730,18 @@ __global__ __launch_bounds__(64 * VI_WAVES) void dft3d_inv_volume_kernel(Vol3dPa
             for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(d[e], yrs, e < nlast ? offl + 4u * e : OOB, sbase, 0);
         }
     };
-    for (int d1 = wave; d1 < D1; d1 += VI_WAVES) {
+    // The three stages of a plane (dim2 GEMM -> untwist -> T-axis GEMM + stores) depend on each other, and a wave's VALU work only runs
+    // under MFMAs that precede it in ITS OWN program order (see K1v): so the loop is software-pipelined across planes - while plane j goes
+    // through its T-axis stage, the LDS reads, the dim2 stage and the untwist of plane j + 1 are interleaved with it in the source.
+    struct Plane { f32x4 UP[U], UQ[U]; };
+    auto read_rows = [&](int d1, float (&lo)[NK2], float (&hi)[NK2]) {
         const float* Z = sZ + d1 * g.RP;
-        const unsigned sbase = (unsigned)d1 * plane_bytes;
-        f32x4 Pc2[U], Qs2[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { Pc2[u] = f32x4{0, 0, 0, 0}; Qs2[u] = f32x4{0, 0, 0, 0}; }
-        float lo[NK2], hi[NK2];
 #pragma unroll
         for (int ks = 0; ks < NK2; ++ks) { lo[ks] = Z[zlo[ks]]; hi[ks] = Z[zhi[ks]]; }
+    };
+    auto dim2_stage = [&](const float (&lo)[NK2], const float (&hi)[NK2], f32x4 (&Pc2)[U], f32x4 (&Qs2)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { Pc2[u] = f32x4{0, 0, 0, 0}; Qs2[u] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
         for (int ks = 0; ks < NK2; ++ks) {
             const float ek = lo[ks] + hi[ks], jd = sg * vol_xor1(lo[ks] - hi[ks]);
@@ -743,6 +752,8 @@ __global__ __launch_bounds__(64 * VI_WAVES) void dft3d_inv_volume_kernel(Vol3dPa
                 Qs2[u] = mfma16(jd, tw.y, Qs2[u]);
             }
         }
+    };
+    auto untwist = [&](const f32x4 (&Pc2)[U], const f32x4 (&Qs2)[U], Plane& pl) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float2 t2 = twist2(u);
@@ -758,18 +769,66 @@ __global__ __launch_bounds__(64 * VI_WAVES) void dft3d_inv_volume_kernel(Vol3dPa
                 UP = Pc2[u];
                 UQ[0] = Qs2[u][1]; UQ[1] = -Qs2[u][0]; UQ[2] = Qs2[u][3]; UQ[3] = -Qs2[u][2];
             }
+            pl.UP[u] = UP; pl.UQ[u] = UQ;
+        }
+    };
+    auto t_stage = [&](const Plane& pl, int u, unsigned sbase) {
 #pragma unroll
-            for (int wt = 0; wt < NWT; ++wt) {
-                f32x4 YP = f32x4{0, 0, 0, 0}, YQ = f32x4{0, 0, 0, 0};
+        for (int wt = 0; wt < NWT; ++wt) {
+            f32x4 YP = f32x4{0, 0, 0, 0}, YQ = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    YP = mfma16(G(wt, r), UP[r], YP);
-                    YQ = mfma16(G(wt, r), UQ[r], YQ);
-                }
-                put(YP, oP[u], oPl[u], wt, sbase);
-                put(YQ, oQ[u], oQl[u], wt, sbase);
+            for (int r = 0; r < 4; ++r) {
+                YP = mfma16(G(wt, r), pl.UP[u][r], YP);
+                YQ = mfma16(G(wt, r), pl.UQ[u][r], YQ);
+            }
+            put(YP, oP[u], oPl[u], wt, sbase);
+            put(YQ, oQ[u], oQl[u], wt, sbase);
+        }
+    };
+    const int my_planes = max((D1 - wave + VI_WAVES - 1) / VI_WAVES, 0);
+    Plane cur;
+    if (my_planes > 0) {
+        float lo[NK2], hi[NK2];
+        f32x4 Pc2[U], Qs2[U];
+        read_rows(wave, lo, hi);
+        dim2_stage(lo, hi, Pc2, Qs2);
+        untwist(Pc2, Qs2, cur);
+    }
+    for (int j = 0; j + 1 < my_planes; ++j) {
+        const int d1 = wave + VI_WAVES * j;
+        const unsigned sbase = (unsigned)d1 * plane_bytes;
+        float lo[NK2], hi[NK2];
+        f32x4 Pc2[U], Qs2[U];
+        Plane nxt;
+        read_rows(d1 + VI_WAVES, lo, hi);
+        t_stage(cur, 0, sbase);
+        dim2_stage(lo, hi, Pc2, Qs2);
+        if (U > 1) t_stage(cur, U - 1, sbase);
+        untwist(Pc2, Qs2, nxt);
+        cur = nxt;
+        // the interleave, spelled out for the scheduler (it clusters the MFMAs and leaves the untwist behind them otherwise):
+        // row reads | T-axis MFMAs of tile pair 0 with the sums / differences of the next plane | its dim2 MFMAs | T-axis MFMAs of tile
+        // pair 1 with its untwist
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NK2, 0);
+#pragma unroll
+        for (int i = 0; i < 8 * NWT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NK2 * U; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (U > 1) {
+#pragma unroll
+            for (int i = 0; i < 8 * NWT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
         }
+    }
+    if (my_planes > 0) {
+        const unsigned sbase = (unsigned)(wave + VI_WAVES * (my_planes - 1)) * plane_bytes;
+#pragma unroll
+        for (int u = 0; u < U; ++u) t_stage(cur, u, sbase);
     }
     VOL_STAMP_NOWAIT(5);
     VOL_STAMP(6);
