@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("c2", "c4", "c5"), default="c2",
+                    help="data-parallel workload (BASELINE.json configs): c2 Darcy 421^2 (the headline, default), c4 Navier-Stokes 3-D "
+                         "64x64x20 Uno3D_T20 width 32 batch 8 / GPU, c5 Darcy 1024^2 mixed precision batch 4 / GPU")
     ap.add_argument("--strong", action="store_true", help="strong scaling: a global batch of 16 split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host CPU leg (developer runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (C3 / C4 / C5, reference-style caller)")
@@ -112,6 +115,51 @@ def cpu_baseline_bounded(batch: int, steps: int):
                       + (f", {main['s_per_step']:.1f} s/step" if main else ", DID NOT FINISH in 420 s")),
            "one_thread": ({"value": one["samples_per_s"], "unit": "samples/s", "sample": f"1 step on 2 samples, 1 thread ({one['s_per_step']:.1f} s)"}
                           if one else None)}
+    return out
+
+
+def gpu_stock_baseline(dev):
+    """Same-GPU comparator (SURVEY 8(d) "GPU comparator"): the reference's op sequence as stock PyTorch-ROCm runs it on THIS device -
+    torch.fft.rfft2 -> einsum -> irfft2 (rocFFT + rocBLAS), F.interpolate, Conv2d, F.gelu (MIOpen / ATen) - through the oracle's
+    blocks: the C2 spectral block forward / backward and the whole UNO_9 training step.  A baseline leg like cpu_baseline: the
+    oracle is timed here, never shipped; the product path does not import it."""
+    import torch
+    from oracle import spectral_oracle as so            # baseline leg only
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    out = {"what": "the reference's op sequence (integral_operators.py:187-206, :218-243, :272-284) as stock PyTorch-ROCm ops on this "
+                   f"GPU (torch {torch.__version__}: rocFFT, rocBLAS, MIOpen, ATen), via oracle/spectral_oracle.py"}
+    g = torch.Generator().manual_seed(0)
+    B, C, m = BATCH, WIDTH, BLOCK_MODES
+    x = torch.randn(B, C, S, S, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(B, C, S, S, generator=g).to(dev)
+    w1 = ((1 / (2 * C)) ** 0.5 * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)).to(dev).requires_grad_(True)
+    w2 = ((1 / (2 * C)) ** 0.5 * torch.randn(C, C, m, m, dtype=torch.cfloat, generator=g)).to(dev).requires_grad_(True)
+
+    def fwd():
+        # reference integral_operators.py:187-206
+        x_ft = torch.fft.rfft2(x, norm="forward")
+        out_ft = torch.zeros(B, C, S, S // 2 + 1, dtype=torch.cfloat, device=dev)
+        out_ft[:, :, :m, :m] = torch.einsum("bixy,ioxy->boxy", x_ft[:, :, :m, :m], w1)
+        out_ft[:, :, -m:, :m] = torch.einsum("bixy,ioxy->boxy", x_ft[:, :, -m:, :m], w2)
+        return torch.fft.irfft2(out_ft, s=(S, S), norm="forward")
+
+    def fwd_bwd():
+        x.grad = w1.grad = w2.grad = None
+        fwd().backward(gy)
+    with torch.no_grad():
+        tf = _timed(fwd, dev, iters=5, reps=3, warm=2)
+    tfb = _timed(fwd_bwd, dev, iters=3, reps=3, warm=1)
+    img, wb = B * C * S * S * 4, 2 * C * C * m * m * 8
+    out["spectral_block_c2"] = {"fwd_us": tf * 1e6, "fwd_plus_bwd_us": tfb * 1e6, "fwd_frac_of_8TBs": (2 * img + wb) / tf / 1e9 / HBM_PEAK_GBS}
+    del x, gy
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    model = UNO_9(3, WIDTH, pad=PAD, block_cls=so.OracleOperatorBlock2d).to(dev)
+    tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    a, u = synthetic_darcy_batch(BATCH, S, 1234, dev)
+    ms = _train_ms(lambda: tr.step(a, u), dev, steps=3, warmup=2, reps=2)
+    out["uno9_step"] = {"ms_per_step": ms, "samples_per_s": BATCH / ms * 1e3,
+                        "config": f"UNO_9(3,{WIDTH},pad={PAD}) {S}^2 batch {BATCH}: harness model on the oracle's stock-op blocks, same loss, same ComplexAdam"}
     return out
 
 
@@ -366,6 +414,7 @@ def extra_workloads(dev):
         return {"config": f"C5 model: UNO_9(3,64,pad=5) at 1024^2 (padded 1089^2), batch {B}, f32", "ms_per_step": ms,
                 "samples_per_s": B / ms * 1e3, "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
+    guarded("gpu_stock", lambda: gpu_stock_baseline(dev))
     guarded("darcy_reference_style_caller", ref_style)
     guarded("c3_ns2d", ns2d)
     guarded("c4_ns3d_w8", ns3d(8))
@@ -425,6 +474,83 @@ def dp_selfcheck(dev, world, rank):
     return {"ranks": world, "buckets": len(tr_dp.grads.buckets), "max_rel_grad_diff_over_2_steps": worst, "tolerance": 2e-4}
 
 
+def dp_selfcheck_workload(name, dev, world, rank):
+    """The same check for the c4 / c5 steps: two steps of the workload's small form on a global batch of 2 x world samples sharded
+    over the ranks against the same two steps in one process on the whole batch (every rank computes both)."""
+    import torch
+    import torch.distributed as dist
+    from uno_amd.harness import workloads
+    per = 2
+    w_dp = workloads.build(name, dev, batch=per * world, seed=4321, small=True, model_seed=7, bucket_mb=0.05)
+    w_one = workloads.build(name, dev, batch=per * world, seed=4321, small=True, model_seed=7, group=dist.new_group([rank]))
+    for _ in range(2):
+        w_dp.step(rank * per, (rank + 1) * per)
+        w_one.step()
+    a, b = workloads.flat_params(w_dp.trainer.model), workloads.flat_params(w_one.trainer.model)
+    t = torch.tensor([float((a - b).norm() / b.norm().clamp_min(1e-30))], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst, tol = float(t.item()), (2e-3 if name == "c5" else 2e-4)
+    if not worst < tol:
+        raise SystemExit(f"data-parallel self-check FAILED ({name}): parameters after 2 steps on {world} ranks vs one process differ by {worst:.3e}")
+    return {"ranks": world, "buckets": len(w_dp.trainer.grads.buckets), "max_rel_param_diff_after_2_steps": worst, "tolerance": tol}
+
+
+def run_secondary(args, dev, world, rank, backend):
+    """--workload c4 | c5: the data-parallel training step of BASELINE.json configs[3] / [4], timed with the headline's protocol
+    (W untimed steps, K timed steps between barrier + synchronize pairs, max over ranks), one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from uno_amd.harness import workloads
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    selfcheck = dp_selfcheck_workload(args.workload, dev, world, rank) if world > 1 else None
+    w = workloads.build(args.workload, dev, seed=1234 + rank)              # this rank's shard, resident in HBM
+    for _ in range(args.warmup):
+        w.step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = w.step()
+    torch.cuda.synchronize(dev)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    comm = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = w.trainer.grads
+        comm = {"backend": backend, "ranks": dist.get_world_size(), "grad_bytes": g.flat.numel() * 4, "buckets": len(g.buckets),
+                "bucket_mb": 32.0, "selfcheck": selfcheck}
+    lv = float(loss)
+    assert lv == lv, "training produced NaN"
+    if rank == 0:
+        roofline = None
+        if world == 1:
+            if args.workload == "c4":
+                b = spectral_block3d_roofline(dev)
+                roofline = {"bound": "hbm", "kernel": "3-D spectral block forward = " + " + ".join(sorted(b["fwd_kernels"])),
+                            "achieved": b["fwd_bytes"] / (b["fwd_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": b["fwd_frac_of_8TBs"], "traffic": b.get("fwd_traffic"),
+                            "avg_launch_us": b["fwd_us"], "algorithmic_bytes_per_launch": b["fwd_bytes"], "config": b["config"],
+                            "backward": {"frac": b["bwd_frac_of_8TBs"], "avg_launch_us": b["bwd_us"], "algorithmic_bytes_per_launch": b["bwd_bytes"]}}
+        gb = world * w.batch
+        print(json.dumps({
+            "metric": w.metric, "value": gb * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
+            "config": {"workload": w.describe + f", batch {w.batch}/GPU", "global_batch": gb, "parallelism": f"dp{world}", "final_loss": lv},
+            "roofline": roofline, "comm": comm, "rccl_ranks": comm["ranks"] if comm and backend == "nccl" else (1 if world == 1 else None),
+            "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------------------------- launch
 def _free_port():
     with socket.socket() as s:
@@ -477,6 +603,10 @@ def main():
     from uno_amd import _native
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
 
+    if args.workload != "c2":
+        if args.strong:
+            sys.exit("--strong goes with the headline workload (c2) only")
+        return run_secondary(args, dev, world, rank, backend)
     per_rank = BATCH // world if args.strong else BATCH
     if args.strong and BATCH % world:
         sys.exit(f"--strong needs a world size that divides {BATCH}")

@@ -282,3 +282,37 @@ def test_reference_style_caller_reproduces_the_reference_on_cpu():
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in c.sub("sd").items()}, strict=True)
     pred = model(torch.from_numpy(c.a)).reshape(B, S, S)
     assert rel_err(pred.detach().numpy(), c.pred0) < 1e-6
+
+
+# ----------------------------------------------------------------------------- data parallel, NS-3D workload (gloo)
+def _dp_workload_worker(rank, world, port, out_path, name):
+    from uno_amd.harness import workloads
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # different init per rank (the trainer's broadcast must fix it), the same global batch of 4 everywhere
+        w = workloads.build(name, "cpu", batch=4, seed=11, small=True, model_seed=100 + rank,
+                            block_cls=so.OracleOperatorBlock3d if name == "c4" else so.OracleOperatorBlock2d, bucket_mb=0.01)
+        assert len(w.trainer.grads.buckets) > 3
+        for _ in range(2):
+            w.step(2 * rank, 2 * rank + 2)
+        if rank == 0:
+            torch.save(workloads.flat_params(w.trainer.model), out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ns3d_workload_data_parallel_equals_single_process(tmp_path):
+    """BASELINE.json configs[3] (NS-3D, DDP): the step bench.py --workload c4 times - Uno3D_T20 + ns3d_loss under FlatGradients -
+    at world size 2 (gloo, oracle blocks): two ranks on half batches == one process on the whole batch after two steps
+    (reference ns_train_3d.py:48-70: the loss is a sum over samples, so gradients are SUMMED across ranks)."""
+    from uno_amd.harness import workloads
+    out_path = str(tmp_path / "dp_c4.pt")
+    mp.spawn(_dp_workload_worker, args=(2, _free_port(), out_path, "c4"), nprocs=2, join=True)
+    got = torch.load(out_path)
+    w = workloads.build("c4", "cpu", batch=4, seed=11, small=True, model_seed=100, block_cls=so.OracleOperatorBlock3d)
+    for _ in range(2):
+        w.step()
+    ref = workloads.flat_params(w.trainer.model)
+    assert float((got - ref).norm()) <= 2e-4 * float(ref.norm())

@@ -76,3 +76,85 @@ def test_adam_multi_tensor_launches_many_mixed_tensors():
         x = torch.view_as_real(b.detach()).cpu() if b.is_complex() else b.detach().cpu()
         y = torch.view_as_real(a.detach()) if a.is_complex() else a.detach()
         assert rel_err(x.numpy(), y.numpy()) < 1e-6, tuple(a.shape)
+
+
+def _toy_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    pc = torch.nn.Parameter(torch.randn(9, 5, dtype=torch.cfloat, generator=g).cuda())
+    pr = torch.nn.Parameter(torch.randn(33, generator=g).cuda())
+    return [pc, pr]
+
+
+def _toy_grads(seed, params):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(p.shape, dtype=p.dtype, generator=g).cuda() for p in params]
+
+
+def test_capturable_lr_schedule_reaches_a_replayed_update():
+    """the captured update must not freeze lr / eps / weight decay.  One capture of opt.step(); between replays a
+    scheduler halves group['lr'] (reference ns_train_2d.py:37,113: StepLR): the replays equal the eager (host-counted) optimiser
+    bit for bit."""
+    pe, pg = _toy_params(3), _toy_params(3)
+    oe = ComplexAdam(pe, lr=1e-2, weight_decay=1e-3)
+    og = ComplexAdam(pg, lr=1e-2, weight_decay=1e-3, capturable=True)
+    for p in pg:
+        p.grad = torch.zeros_like(p)
+    og.init_state()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        og.step()
+    # (capture does not execute: counters and parameters are untouched so far)
+    for t in range(4):
+        if t == 2:
+            for o in (oe, og):
+                o.param_groups[0]["lr"] *= 0.5
+                o.param_groups[0]["weight_decay"] = 5e-4
+        gs = _toy_grads(100 + t, pe)
+        for p, q, g in zip(pe, pg, gs):
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        oe.step()
+        og.sync_hyper()
+        graph.replay()
+        torch.cuda.synchronize()
+        for p, q in zip(pe, pg):
+            assert torch.equal(p.detach(), q.detach()), t
+    assert int(og.state[pg[0]]["step"]) == 4
+
+
+def test_capturable_step_count_survives_state_dict_round_trip():
+    """a resumed capturable optimiser continues the bias corrections from the loaded step count (reference Adam.py
+    resumes from state['step']), it does not restart at t = 1 against warm moments."""
+    pa, pb, pe = _toy_params(4), _toy_params(4), _toy_params(4)
+    oa = ComplexAdam(pa, lr=1e-2, weight_decay=1e-3, capturable=True)
+    oe = ComplexAdam(pe, lr=1e-2, weight_decay=1e-3)
+    for t in range(3):
+        gs = _toy_grads(200 + t, pa)
+        for p, q, g in zip(pa, pe, gs):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        oa.step()
+        oe.step()
+    sd = oa.state_dict()
+    ob = ComplexAdam(pb, lr=1e-2, weight_decay=1e-3, capturable=True)
+    with torch.no_grad():
+        for p, q in zip(pb, pa):
+            p.copy_(q)
+    ob.load_state_dict(sd)
+    for t in range(3, 5):
+        gs = _toy_grads(200 + t, pb)
+        for p, q, g in zip(pb, pe, gs):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        ob.step()
+        oe.step()
+        for p, q in zip(pb, pe):
+            assert torch.equal(p.detach(), q.detach()), t
+    assert int(ob.state[pb[0]]["step"]) == 5
+    # and the other direction: a host-counted optimiser's state loaded into a capturable one
+    oc = ComplexAdam(_toy_params(4), lr=1e-2, weight_decay=1e-3, capturable=True)
+    oc.load_state_dict(oe.state_dict())
+    oc.init_state()
+    assert int(oc.state[oc.param_groups[0]["params"][0]]["step"]) == 5

@@ -171,3 +171,42 @@ def test_bench_data_parallel_selfcheck_passes_with_two_ranks(tmp_path):
     mp.spawn(_bench_selfcheck_worker, args=(2, port, out_path), nprocs=2, join=True)
     rec = torch.load(out_path)
     assert rec["ranks"] == 2 and rec["buckets"] > 3 and rec["max_rel_grad_diff_over_2_steps"] < 2e-4
+
+
+def _workload_worker(rank, world, port, out_path, name):
+    import torch.distributed as dist
+    from uno_amd.harness import workloads
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")                     # both ranks share the one GPU of the test box (gloo: RCCL refuses that)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = workloads.build(name, dev, batch=4, seed=11, small=True, model_seed=100 + rank, bucket_mb=0.05)
+        assert len(w.trainer.grads.buckets) > 3
+        for _ in range(2):
+            w.step(2 * rank, 2 * rank + 2)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save(workloads.flat_params(w.trainer.model), out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["c4", "c5"])
+def test_two_ranks_secondary_workloads_equal_single_process(tmp_path, name):
+    """BASELINE.json configs[3] / [4] say "DDP over 8 MI355X": the NS-3D step (Uno3D_T20 + ns3d_loss, reference
+    ns_train_3d.py:48-70) and the mixed-precision Darcy step (MixedDarcyTrainer) under FlatGradients with the product kernels,
+    world size 2 on the one GPU of the test box (gloo): two ranks on half batches == one process on the whole batch after two
+    steps.  (In the mixed step every sample sees the same bf16 roundings in both runs; only float32 summation order differs.)"""
+    import torch.multiprocessing as mp
+    from uno_amd.harness import workloads
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_path = str(tmp_path / f"dp_{name}.pt")
+    mp.spawn(_workload_worker, args=(2, port, out_path, name), nprocs=2, join=True)
+    got = torch.load(out_path)
+    w = workloads.build(name, torch.device("cuda:0"), batch=4, seed=11, small=True, model_seed=100)
+    for _ in range(2):
+        w.step()
+    ref = workloads.flat_params(w.trainer.model)
+    assert float((got - ref).norm()) <= (2e-4 if name == "c4" else 2e-3) * float(ref.norm())

@@ -67,3 +67,15 @@ def test_switches():
         finally:
             setattr(io, name, True)
     assert io._stack_take(torch.zeros(4, 6, 3, 3, dtype=torch.cfloat), shape, w.device, True) is None     # not a leaf parameter with a hint
+
+
+def test_stale_backward_pass_entries_are_swept(monkeypatch):
+    """a backward pass that raises never runs its final callback; its _PASSES entry must not live for ever."""
+    import time
+    from uno_amd import integral_operators as io
+    io._PASSES.clear()
+    io._PASSES[123456] = {"id": 123456, "acc": {}, "stacks": {}, "uses": {}, "born": time.monotonic() - 2 * io._STALE_PASS_SECONDS}
+    io._PASSES[123457] = {"id": 123457, "acc": {}, "stacks": {}, "uses": {}, "born": time.monotonic()}
+    assert io._pass_state() is None            # outside a pass: sweeps
+    assert 123456 not in io._PASSES and 123457 in io._PASSES
+    io._PASSES.clear()

@@ -136,7 +136,10 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
     if (inverse ? dft2d_inv_plane_applies(p) : dft2d_fwd_plane_applies(p))
         return inverse ? launch_dft2d_inv_plane(p, s) : launch_dft2d_fwd_plane(p, s);
     // bfloat16 images: row stage on the bf16 MFMA (dft2d_b16.hip)
-    if (dft2d_b16_applies(p)) return inverse ? launch_dft2d_inv_b16(p, s) : launch_dft2d_fwd_b16(p, s);
+    if (dft2d_b16_applies(p)) {
+        const int rc = inverse ? launch_dft2d_inv_b16(p, s) : launch_dft2d_fwd_b16(p, s);
+        if (rc != -3) return rc;        // -3: the shape's LDS need exceeds a CU (tall images with many row modes): the f32-MFMA forms take it
+    }
     return inverse ? launch_dft2d_inv(p, s) : launch_dft2d_fwd(p, s);
 }
 

@@ -900,10 +900,15 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
     const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0);
     // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
-    static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;          // development: A/B against the f32-MFMA form
+#ifdef UNO_CMS_DEV        // development build only (tools/dev/mkvariant.py): A/B switch, knock-outs, stamp buffer from the environment
+    static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;
     static const int cms_exp = getenv("UNO_CMS_EXP") ? atoi(getenv("UNO_CMS_EXP")) : 0;
     p.exp = cms_exp;
     if ((cms_exp & 64) && getenv("UNO_CMS_STAMPS")) p.proj_out = reinterpret_cast<void*>((uintptr_t)strtoull(getenv("UNO_CMS_STAMPS"), nullptr, 0));
+#else
+    constexpr bool split_off = false;
+    p.exp = 0;
+#endif
     // f32 activations: from 128 input channels on; bf16 activations move half the bytes, there the f32 MFMA is the ceiling from 32 on
     // (profiles/r04_c5_mixed_kernel_stats.csv: the generic forms on bf16 were 4.8 of the mixed C5 step's 16 ms)
     const bool trw_ = a.transpose_w != 0;
@@ -1240,7 +1245,11 @@ constexpr int CWS_PLANE = 2 * CWS_T * CWS_RS;       // 20 480
 // the vector kernel (A/B on one box: the NS-2D roll-out - 64^2 .. 16^2 grids at batch 32, at most 74 000 pixels per call - 80.7 ms
 // per step with this form on its wide layers, 79.5 without; the Darcy model's smallest level is 197 000).
 static bool wgrad_split_shape(int B, int Ci, int Co, long long P) {
-    static const bool off = getenv("UNO_CW_SPLIT_OFF") != nullptr;         // development: A/B against the f32-MFMA form
+#ifdef UNO_CMS_DEV
+    static const bool off = getenv("UNO_CW_SPLIT_OFF") != nullptr;         // development build only: A/B against the f32-MFMA form
+#else
+    constexpr bool off = false;
+#endif
     return !off && Ci >= 96 && Co >= 48 && P >= 64 && (long long)B * P >= 100000;
 }
 static int wgrad_split_rows(int Co) { return Co >= 96 ? CWS_T : 64; }      // output channels per weight tile

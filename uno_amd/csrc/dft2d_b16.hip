@@ -486,6 +486,7 @@ static int launch_fwd_b16_v(Dft2dParams p, hipStream_t s) {
     });
     if (!tab) return -6;
     const size_t lds = fwd_b16_lds(p, NT, MP);
+    if (lds > 160 * 1024) { set_error("dft2d_fwd_b16: %zu bytes of LDS", lds); return -3; }       // (the caller falls back to the f32-MFMA form)
     auto k = dft2d_fwd_b16_kernel<NT, MT, PAIRW, XP>;
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_slot)) { set_error("dft2d_fwd_b16: cannot raise dynamic LDS to %zu", lds); return -4; }
@@ -815,8 +816,10 @@ static int launch_inv_b16_t(const Dft2dParams& p, hipStream_t s) {
 // bf16 images, corner rule (no frequency tables), the compiled mode range, rows long enough for a k-step to be mostly data
 bool dft2d_b16_applies(const Dft2dParams& p) {
     if (!p.bf16 || p.rowfreq) return false;
-    static const int off = b16_exp("UNO_B16_OFF", 0);           // development: A/B against the f32-MFMA forms
+#ifdef UNO_B16_DEV
+    static const int off = b16_exp("UNO_B16_OFF", 0);           // development build only: A/B against the f32-MFMA forms
     if (off) return false;
+#endif
     if (p.m1 > 40 || p.m2 > 32 || p.W < 64 || p.H < 16) return false;               // (48 column modes: three accumulator tiles per half spill)
     if (((p.m2 + 15) / 16) * ((2 * p.m1 + 15) / 16) > 8) return false;              // those instantiations spill: the f32-MFMA forms keep them
     if ((unsigned long long)p.H * p.W * 2ull >= 0x7fffffffull) return false;       // 32-bit byte offsets inside an image

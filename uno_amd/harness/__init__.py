@@ -8,3 +8,4 @@ from .optim import ComplexAdam  # noqa: F401
 from .losses import lp_loss_rel_sum  # noqa: F401
 from .mixed import MixedDarcyTrainer  # noqa: F401
 from .train import DarcyTrainer, GraphedStep, ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch  # noqa: F401
+from . import workloads  # noqa: F401,E402

@@ -17,13 +17,17 @@ class ComplexAdam(Optimizer):
         """capturable: keep the step count of the device parameters ON THE DEVICE (one counter per parameter group, advanced by the
         update itself), so that step() can be recorded in a HIP graph (harness.GraphedStep) - the bias corrections of the reference
         (Adam.py:27-52: from state['step']) are then evaluated on the device in double.  All device parameters of a group must take
-        part in every step (they share the counter); state[p]['step'] is that counter tensor."""
+        part in every step (they share the counter); state[p]['step'] is that counter tensor.  lr, eps and weight_decay are read by
+        the update from three doubles ON THE DEVICE as well (sync_hyper() refreshes them from the param group whenever they changed):
+        a scheduler that edits group['lr'] (reference ns_train_2d.py:37,113: StepLR) takes effect on the next replay of a captured
+        step, exactly as on the eager path."""
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._plans = {}            # per param group: pointer tables of the device tensors (not part of state_dict)
         self.capturable = bool(capturable)
-        self._dev_counters = {}     # id(group) -> (int32 step counter, float32[2] scalars) on the group's device
+        # per group INDEX: (int32 step counter, float32[4] scratch, float64[3] (lr, eps, weight_decay), the three as last uploaded)
+        self._dev_counters = {}
 
     def _device_step(self, group, params, step, lr, beta1, beta2, eps, wd):
         """K10 over all device tensors of the group in one native call; the pointer tables are rebuilt only when a
@@ -40,14 +44,54 @@ class ComplexAdam(Optimizer):
             plan = _native.AdamPlan([p.data for p in params], [p.grad for p in params],
                                     [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params])
             self._plans[key] = plan
-        if step is None:            # capturable: the group's device counter
-            ctr, scal = self._dev_counters[id(group)]
-            plan.step_dev(ctr, scal, lr, beta1, beta2, eps, wd)
+        if step is None:            # capturable: the group's device counter and device hyper-parameters
+            ctr, scal, hyper, _ = self._dev_counters[self._group_index(group)]
+            plan.step_dev(ctr, scal, lr, beta1, beta2, eps, wd, hyper=hyper)
         else:
             plan.step(step, lr, beta1, beta2, eps, wd)
         # the kernel writes the parameters through raw pointers: tell autograd they changed (version counters guard saved tensors
         # and key the half-precision weight copies of the mixed-precision layers)
         torch.autograd.graph.increment_version(params)
+
+    def _group_index(self, group):
+        for i, g in enumerate(self.param_groups):
+            if g is group:
+                return i
+        raise RuntimeError("ComplexAdam: unknown parameter group")
+
+    def _counter(self, group, device):
+        """The group's device-side step counter (+ scratch and hyper-parameters), created on first use.  A count that already exists
+        in the group's state - an int from non-capturable steps, or the tensor load_state_dict() put there - is carried over:
+        the bias corrections continue from it (reference Adam.py resumes from state['step'])."""
+        gi = self._group_index(group)
+        entry = self._dev_counters.get(gi)
+        if entry is None:
+            start = 0
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    start = max(start, int(st["step"]))            # (a one-off host read when the counter is created)
+            ctr = torch.full((1,), start, dtype=torch.int32, device=device)
+            now = (float(group["lr"]), float(group["eps"]), float(group["weight_decay"]))
+            entry = [ctr, torch.zeros(4, dtype=torch.float32, device=device), torch.tensor(now, dtype=torch.float64).to(device), now]
+            self._dev_counters[gi] = entry
+        return entry
+
+    def sync_hyper(self):
+        """Upload (lr, eps, weight_decay) of every capturable group to the device if they changed since the last upload.  step() calls
+        it when no stream capture is running; harness.GraphedStep calls it before every replay."""
+        for gi, entry in self._dev_counters.items():
+            g = self.param_groups[gi]
+            now = (float(g["lr"]), float(g["eps"]), float(g["weight_decay"]))
+            if entry[3] != now:
+                entry[2].copy_(torch.tensor(now, dtype=torch.float64))
+                entry[3] = now
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # the loaded state replaced the moment tensors and the step entries: plans and device counters are rebuilt from it on next use
+        self._plans.clear()
+        self._dev_counters.clear()
 
     @staticmethod
     def _real(t):
@@ -71,11 +115,8 @@ class ComplexAdam(Optimizer):
                     continue
                 st = self._init_param_state(p)
                 if self.capturable and p.is_cuda and p.dtype in (torch.float32, torch.complex64):
-                    if id(group) not in self._dev_counters:
-                        self._dev_counters[id(group)] = (torch.zeros(1, dtype=torch.int32, device=p.device),
-                                                         torch.zeros(2, dtype=torch.float32, device=p.device))
-                    if not torch.is_tensor(st["step"]):
-                        st["step"] = self._dev_counters[id(group)][0]
+                    st["step"] = self._counter(group, p.device)[0]
+        self.sync_hyper()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -95,10 +136,7 @@ class ComplexAdam(Optimizer):
                 st = self._init_param_state(p)
                 on_dev = p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous() and p.grad.is_contiguous()
                 if self.capturable and on_dev:
-                    if id(group) not in self._dev_counters:
-                        self._dev_counters[id(group)] = (torch.zeros(1, dtype=torch.int32, device=p.device),
-                                                         torch.zeros(2, dtype=torch.float32, device=p.device))
-                    st["step"] = self._dev_counters[id(group)][0]
+                    st["step"] = self._counter(group, p.device)[0]
                     devb.setdefault(None, []).append(p)
                     continue
                 st["step"] += 1
@@ -106,6 +144,8 @@ class ComplexAdam(Optimizer):
                     devb.setdefault(st["step"], []).append(p)
                 else:
                     host.setdefault(st["step"], []).append(p)
+            if None in devb and not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper()
             for t, dev_p in devb.items():
                 self._device_step(group, dev_p, t, lr, beta1, beta2, eps, wd)
             for t, plist in host.items():

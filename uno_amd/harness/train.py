@@ -243,6 +243,8 @@ class GraphedStep:
     def step(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src, non_blocking=True)
+        if self.opt_in_graph:
+            self.opt.sync_hyper()                       # lr / eps / weight decay live on the device: a scheduler's edit reaches the replay
         self.graph.replay()                             # gradients are overwritten by the captured backward
         if self.opt_in_graph:
             torch.autograd.graph.increment_version(self._params)       # the replayed update wrote the parameters through raw pointers

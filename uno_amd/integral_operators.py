@@ -24,6 +24,7 @@ layers (they are not part of the spectral path and the CPU-side harness tests us
 from __future__ import annotations
 
 import threading
+import time
 
 import torch
 import torch.nn as nn
@@ -192,19 +193,36 @@ INPLACE_PARAM_GRADS = True
 #   uses:   id(weights1 leaf) -> [leaf, [spectral-layer backward calls of this pass that did NOT go through a stack]]
 _PASSES = {}
 _PASSES_LOCK = threading.Lock()
+_STALE_PASS_SECONDS = 120.0
+
+
+def _sweep_stale_passes():
+    """Autograd skips a pass's final callbacks when the pass raises (an out-of-memory error the training loop catches and retries):
+    its entry would stay in _PASSES for ever - graph-task ids are never reused - keep its gradient buffers alive and push every
+    parameter it recorded off the in-place path.  Called from a thread that is NOT inside a backward pass; an entry older than
+    _STALE_PASS_SECONDS seen from there belongs to no pass that could still be running (a live pass of another thread is younger
+    than that by orders of magnitude: the longest step of this package is a fraction of a second)."""
+    now = time.monotonic()
+    with _PASSES_LOCK:
+        for tid in [t for t, ps in _PASSES.items() if now - ps["born"] > _STALE_PASS_SECONDS]:
+            _PASSES.pop(tid, None)
 
 
 def _pass_state():
     """The dictionaries of the running backward pass (registered with the engine on first use), or None outside a pass."""
     tid = torch._C._current_graph_task_id()
     if tid < 0:
+        if _PASSES:
+            _sweep_stale_passes()
         return None
     ps = _PASSES.get(tid)
     if ps is None:
+        if _PASSES:
+            _sweep_stale_passes()              # (a pass that raised never ran its callback; see there)
         with _PASSES_LOCK:
             ps = _PASSES.get(tid)
             if ps is None:
-                ps = _PASSES[tid] = {"id": tid, "acc": {}, "stacks": {}, "uses": {}}
+                ps = _PASSES[tid] = {"id": tid, "acc": {}, "stacks": {}, "uses": {}, "born": time.monotonic()}
                 # final callbacks belong to the graph task that is current when they are queued: this one runs when THIS pass completes
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_pass(tid))
     return ps
