@@ -429,6 +429,96 @@ def extra_workloads(dev):
     return out
 
 
+def workload_kernel_names(dev):
+    """{workload: sorted names of every library kernel ONE step / call of it launches at the geometry this file times} - read off the
+    library's own launch records (uno_profile_*) of a run made HERE, not from a committed file: the coverage tests
+    (tests/test_hip_bench_shapes.py, tests/test_hip_headline_parity.py) check that every one of them also ran inside a full-size
+    oracle comparison."""
+    import torch
+    from uno_amd import _native
+    from uno_amd.harness import (ComplexAdam, DarcyTrainer, UNO, UNO_9_ReferenceStyle, Uno3D_T20, ns2d_rollout_loss, ns3d_loss,
+                                 synthetic_darcy_batch, workloads)
+    out = {}
+
+    def names(fn, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        _native.profile_begin(200000)
+        try:
+            fn()
+            torch.cuda.synchronize(dev)
+        finally:
+            rec = _native.profile_end()
+        torch.cuda.empty_cache()
+        return sorted({n for n, _, _ in rec})
+
+    w = workloads.build("c2", dev)
+    out["c2_step"] = names(lambda: w.step())
+    del w
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(BATCH, WIDTH, S, S, generator=g).to(dev)
+    w1, w2 = ((0.1 * torch.randn(WIDTH, WIDTH, BLOCK_MODES, BLOCK_MODES, dtype=torch.cfloat, generator=g)).to(dev) for _ in range(2))
+    y, xt = _native.spectral_conv2d_forward(x, w1, w2, S, S)
+    out["c2_block"] = names(lambda: (_native.spectral_conv2d_forward(x, w1, w2, S, S), _native.spectral_conv2d_backward(x, xt, w1, w2, S, S)), warm=0)
+    del x, y, xt
+    x3 = torch.randn(8, 32, 64, 64, 20, generator=g).to(dev)
+    ws = [(0.1 * torch.randn(32, 32, 16, 16, 8, dtype=torch.cfloat, generator=g)).to(dev) for _ in range(4)]
+    y3, xt3 = _native.spectral_conv3d_forward(x3, ws, 64, 64, 20)
+    out["c4_block"] = names(lambda: (_native.spectral_conv3d_forward(x3, ws, 64, 64, 20), _native.spectral_conv3d_backward(x3, xt3, ws, 64, 64, 20)), warm=0)
+    del x3, y3, xt3, ws
+    torch.manual_seed(0)
+    m = UNO_9_ReferenceStyle(3, WIDTH, pad=PAD).to(dev)
+    tr = DarcyTrainer(m, lr=1e-3, weight_decay=1e-3)
+    a, u = synthetic_darcy_batch(BATCH, S, 1234, dev)
+    out["darcy_reference_style_caller"] = names(lambda: tr.step(a, u))
+    del m, tr
+    m = UNO(14, 32).to(dev)
+    xx, yy = torch.randn(32, 64, 64, 10, device=dev), torch.randn(32, 64, 64, 40, device=dev)
+    opt = ComplexAdam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+
+    def ns2d_step():
+        opt.zero_grad(set_to_none=True)
+        ns2d_rollout_loss(m, xx, yy, T_f=2, step=1).backward()
+        opt.step()
+    out["c3_ns2d"] = names(ns2d_step)
+    del m, opt
+    for width in (8, 32):
+        m3 = Uno3D_T20(6, width, pad=3).to(dev)
+        x, y = torch.randn(8, 64, 64, 10, 1, device=dev), torch.randn(8, 64, 64, 20, device=dev)
+        opt = ComplexAdam(m3.parameters(), lr=1e-3, weight_decay=1e-4)
+
+        def ns3d_step():
+            opt.zero_grad(set_to_none=True)
+            ns3d_loss(m3, x, y).backward()
+            opt.step()
+        out[f"c4_ns3d_w{width}"] = names(ns3d_step)
+        del m3, opt
+    for name in ("c5",):
+        w = workloads.build(name, dev)
+        out["c5_model_mixed"] = names(lambda: w.step())
+        del w
+    torch.manual_seed(0)
+    from uno_amd.harness import UNO_9
+    m5 = UNO_9(3, 64, pad=5).to(dev)
+    tr = DarcyTrainer(m5, lr=1e-3, weight_decay=1e-3)
+    a, u = synthetic_darcy_batch(4, 1024, 1234, dev)
+    out["c5_model_f32"] = names(lambda: tr.step(a, u))
+    del m5, tr, a, u
+    C, S5, mm, B = 64, 1024, 32, 4
+    x = torch.randn(B, C, S5, S5, generator=g).to(dev)
+    w1, w2 = ((0.1 * torch.randn(C, C, mm, mm, dtype=torch.cfloat, generator=g)).to(dev) for _ in range(2))
+    y, xt = _native.spectral_conv2d_forward(x, w1, w2, S5, S5)
+    n5 = names(lambda: (_native.spectral_conv2d_forward(x, w1, w2, S5, S5), _native.spectral_conv2d_backward(x, xt, w1, w2, S5, S5)), warm=0)
+    xb = x.bfloat16()
+    del x, y
+    w1h, w2h = (torch.view_as_real(w_).half().contiguous() for w_ in (w1, w2))
+    yb, xtb = _native.spectral_conv2d_forward(xb, w1h, w2h, S5, S5)
+    n5 += names(lambda: (_native.spectral_conv2d_forward(xb, w1h, w2h, S5, S5), _native.spectral_conv2d_backward(xb, xtb, w1h, w2h, S5, S5)), warm=0)
+    out["c5_block"] = sorted(set(n5))
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- data-parallel self-check
 def dp_selfcheck(dev, world, rank):
     """Before anything is timed with N > 1 ranks: two training steps of a small UNO_9 on a global batch of 2 x world samples,

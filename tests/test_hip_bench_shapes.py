@@ -326,39 +326,38 @@ def test_c5_block_f32_bench_batch():
     _check2d(4, 64, 64, 1024, 1024, 1024, 1024, 32, 32, seed=1024)
 
 
-# ------------------------------------------------------------------ the committed bench line's tables
-def _bench_line():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")),
-                   key=lambda f: int(re.search(r"r(\d+)_bench", os.path.basename(f)).group(1)))
-    for line in reversed(open(files[-1]).read().strip().splitlines()):
-        if line.startswith("{"):
-            return files[-1], json.loads(line)
-    raise AssertionError(f"no JSON line in {files[-1]}")
+# C5 model, f32: UNO_9(3, 64, pad=5) at 1024^2 (padded grid 1089), batch 4 - the transforms of its levels (1089 / 544 / 272)
+D5 = 1089
+C5_LAYERS = {"conv0": (64, 128, D5, D5 // 2, 18), "conv1": (128, 256, D5 // 2, D5 // 4, 8), "conv4": (256, 128, D5 // 4, D5 // 2, 8),
+             "conv5": (128, 64, D5 // 2, D5, 18)}
 
 
-def _table_names(obj, out):
-    """kernel names = keys of every per-kernel table in the line (dicts whose values are dicts with a duration field) and the
-    entries of every `spectral_kernels` list."""
-    if isinstance(obj, dict):
-        for k, v in obj.items():
-            if k == "spectral_kernels" and isinstance(v, list):
-                out.update(v)
-            elif isinstance(v, dict) and ("avg_us" in v or "total_ms" in v):
-                out.add(k)
-            else:
-                _table_names(v, out)
-    elif isinstance(obj, list):
-        for v in obj:
-            _table_names(v, out)
+@pytest.mark.parametrize("layer", list(C5_LAYERS))
+def test_c5_model_layers_full_size(layer):
+    Ci, Co, H, Ho, m = C5_LAYERS[layer]
+    _check2d(4, Ci, Co, H, H, Ho, Ho, m, m, seed=5000 + H)
 
 
+def _mixed(name):
+    """mixed-precision kernels (bf16 images / fp16 weights): their full-size comparisons are tests/test_hip_c5.py and
+    tests/test_hip_b16_transforms.py (1024^2 and 1089-column cases against the float64 oracle and the float32 reference)"""
+    return "b16" in name or "bf16" in name or "__hip_bfloat16" in name or re.search(r"mode_gemm_blocks_kernel<\d+, \d+, \d+, true", name) \
+        or re.search(r"mode_gemm_kernel<\d+, (true|false), true", name)
+
+
+# ------------------------------------------------------------------ the workloads' own launch records
 def test_zz_every_bench_table_kernel_was_oracle_checked():
+    """Every spectral-path kernel that ONE step / call of any workload bench.py times launches - read off the library's launch
+    records of a run made HERE (bench.workload_kernel_names), not from a committed file - also ran inside a full-size oracle
+    comparison of this module."""
     if len(COVERED) < 10:
         pytest.skip("the full-size parity tests of this module did not run in this session")
-    path, line = _bench_line()
-    named = set()
-    _table_names(line, named)
-    spectral = {n.replace("uno::", "") for n in named if _spectral(n) and "bf16" not in n and "__hip_bfloat16" not in n}
+    import bench
+    census = bench.workload_kernel_names(torch.device("cuda:0"))
     covered = {n.replace("uno::", "") for n in COVERED}
-    missing = sorted(spectral - covered)
-    assert not missing, f"{os.path.basename(path)} names spectral kernels no full-size oracle comparison reached: {missing}"
+    missing = {}
+    for wl, names in census.items():
+        miss = sorted({n.replace("uno::", "") for n in names if _spectral(n) and not _mixed(n)} - covered)
+        if miss:
+            missing[wl] = miss
+    assert not missing, f"spectral kernels of bench workloads that no full-size oracle comparison reached: {missing}"

@@ -36,14 +36,18 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _profiled(fn):
+def _profiled(fn, record=True):
+    """record=True: the kernels fn launches count as oracle-checked (RAN), fn's result is returned; record=False: their names are returned"""
     from uno_amd import _native
     _native.profile_begin(8192)
     try:
         out = fn()
         torch.cuda.synchronize()
     finally:
-        RAN.update(re.sub(r"<.*", "", n) for n, _, _ in _native.profile_end())
+        names = [n for n, _, _ in _native.profile_end()]
+    if not record:
+        return names
+    RAN.update(re.sub(r"<.*", "", n) for n in names)
     return out
 
 
@@ -205,19 +209,15 @@ def test_headline_optimiser_full_size():
         assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-9
 
 
-def _bench_line():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")),
-                   key=lambda f: int(re.search(r"r(\d+)_bench", os.path.basename(f)).group(1)))
-    for line in reversed(open(files[-1]).read().strip().splitlines()):
-        if line.startswith("{"):
-            return files[-1], json.loads(line)
-    raise AssertionError(f"no JSON line in {files[-1]}")
-
-
 def test_zz_every_kernel_of_the_timed_step_was_oracle_checked_at_bench_geometry():
+    """The kernels of the headline step - taken from the library's launch records of two steps of the workload run HERE, at the
+    bench geometry (not from a committed profile) - all ran inside a full-size oracle comparison of this module."""
     if len(RAN) < 10:
         pytest.skip("the full-size parity tests of this module did not run in this session")
-    path, line = _bench_line()
-    named = {re.sub(r"<.*", "", k) for k in line["roofline"]["step_kernels"]}
+    from uno_amd.harness import workloads
+    w = workloads.build("c2", dev())
+    w.step()
+    names = _profiled(lambda: (w.step(), w.step()), record=False)
+    named = {re.sub(r"<.*", "", k) for k in names}
     missing = sorted(named - RAN)
-    assert not missing, f"{os.path.basename(path)}: roofline.step_kernels names kernels no full-size oracle comparison launched: {missing}"
+    assert not missing, f"the timed step launches kernels no full-size oracle comparison launched: {missing}"

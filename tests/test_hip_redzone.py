@@ -4,7 +4,7 @@ out-of-bounds store of any kernel (clamped raw-buffer addressing, ragged tails, 
 fails the test instead of silently corrupting a neighbouring tensor.  The parity tests compare values only.  pytest -m gpu
 
 How: inside the fixture torch.empty / empty_like / zeros / zeros_like (the only allocation calls of uno_amd/_native.py,
-uno_amd/integral_operators.py and uno_amd/harness/*) return views into [4 KiB guard | tensor | 4 KiB guard] blocks filled with 0xA5;
+uno_amd/integral_operators.py and uno_amd/harness/*) return views into [64 KiB guard | tensor | 64 KiB guard] blocks filled with 0xA5;
 the workloads are the library's own ragged-shape cases (odd grids, prime sizes, overlapping corners, partial tiles, one- and
 two-source blocks, bf16 forms, 3-D volumes and planes, the roll-out's stacked spectra) driven through the public modules, so every C
 entry point that the models reach runs with guarded outputs."""
@@ -13,7 +13,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-GUARD = 4096
+GUARD = 65536          # 64 KiB on both sides (round 4 used 4 KiB: a far stride - a row or plane pitch off by one - jumped over it)
 PATTERN = 0xA5
 
 
@@ -202,3 +202,118 @@ def test_spectral_conv3d(redzone, cfg):
     y = spectral_conv3d(x, ws, *dout)
     y.backward(torch.randn(B, Co, *dout, generator=g).to(dev()))
     assert redzone.check(f"spectral_conv3d {cfg}") >= 4
+
+
+# ---------------------------------------------------------------------------------------------------------------- read side
+# The guards above see stores.  Out-of-bounds READS (clamped raw-buffer loads, rows past a tile multiplied by zero weights) are checked
+# from the other side: every input - activations, weights, gradients - lives between two 64 KiB runs of NaN.  A kernel that reads a
+# neighbouring value AND lets it reach a result (0 x NaN = NaN) produces a non-finite or different output; results must equal the
+# run on ordinary tensors bit for bit (all kernels are deterministic).
+def nan_wrapped(t):
+    """a copy of device tensor t whose storage is preceded and followed by 64 KiB of NaN"""
+    flat = (torch.view_as_real(t) if t.is_complex() else t).detach().contiguous().reshape(-1)
+    pad = GUARD // flat.element_size()
+    raw = torch.full((pad + flat.numel() + pad,), float("nan"), dtype=flat.dtype, device=t.device)
+    raw[pad:pad + flat.numel()] = flat
+    v = raw[pad:pad + flat.numel()]
+    v = torch.view_as_complex(v.view(*t.shape, 2)) if t.is_complex() else v.view(t.shape)
+    return v.requires_grad_(t.requires_grad)
+
+
+def _same(a, b, what):
+    for x, y in zip(a, b):
+        assert bool(torch.isfinite(torch.view_as_real(x) if x.is_complex() else x.float()).all()), f"{what}: non-finite result"
+        assert torch.equal(x, y), f"{what}: a value outside an input reached the result"
+
+
+@pytest.mark.parametrize("cfg", SPECTRAL_2D)
+def test_reads_stay_inside_inputs_spectral_conv2d(cfg):
+    from uno_amd.integral_operators import spectral_conv2d
+    B, Ci, Co, H, W, Ho, Wo, m1, m2 = cfg
+    g = torch.Generator().manual_seed(1)
+    base = [torch.randn(B, Ci, H, W, generator=g).to(dev()), torch.randn(Ci, Co, m1, m2, dtype=torch.cfloat, generator=g).to(dev()),
+            torch.randn(Ci, Co, m1, m2, dtype=torch.cfloat, generator=g).to(dev())]
+    gy = torch.randn(B, Co, Ho, Wo, generator=g).to(dev())
+    res = []
+    for wrap in (False, True):
+        x, w1, w2 = ((nan_wrapped(t.requires_grad_(True)) if wrap else t.clone().requires_grad_(True)) for t in base)
+        y = spectral_conv2d(x, w1, w2, Ho, Wo)
+        y.backward(nan_wrapped(gy) if wrap else gy)
+        res.append([y.detach(), x.grad, w1.grad, w2.grad])
+    _same(res[1], res[0], f"spectral_conv2d {cfg}")
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 2, (16, 16, 10), (12, 12, 16), (4, 4, 3)), (8, 8, 8, (32, 32, 13), (16, 16, 15), (6, 6, 5)),
+                                 (7, 7, 8, (64, 64, 20), (48, 48, 13), (16, 16, 8))])
+def test_reads_stay_inside_inputs_spectral_conv3d(cfg):
+    from uno_amd.spectral3d import spectral_conv3d
+    B, Ci, Co, din, dout, modes = cfg
+    g = torch.Generator().manual_seed(4)
+    base = [torch.randn(B, Ci, *din, generator=g).to(dev())] + [torch.randn(Ci, Co, *modes, dtype=torch.cfloat, generator=g).to(dev()) for _ in range(4)]
+    gy = torch.randn(B, Co, *dout, generator=g).to(dev())
+    res = []
+    for wrap in (False, True):
+        x, *ws = ((nan_wrapped(t.requires_grad_(True)) if wrap else t.clone().requires_grad_(True)) for t in base)
+        y = spectral_conv3d(x, ws, *dout)
+        y.backward(nan_wrapped(gy) if wrap else gy)
+        res.append([y.detach(), x.grad] + [w.grad for w in ws])
+    _same(res[1], res[0], f"spectral_conv3d {cfg}")
+
+
+def _wrap_module(m):
+    for p in m.parameters():
+        p.data = nan_wrapped(p.data)
+    return m
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("geom", [(37, 37, 55, 55), (55, 55, 37, 37), (70, 66, 35, 33), (223, 223, 111, 111)])
+def test_reads_stay_inside_inputs_operator_block_2d(geom, normalize):
+    """spectral branch + banded resampling (K7: rows past a tile meet zero weights) + 1x1 layer and its weight gradient + norm"""
+    from uno_amd.integral_operators import OperatorBlock_2D
+    H, W, Ho, Wo = geom
+    res = []
+    for wrap in (False, True):
+        torch.manual_seed(3)
+        blk = OperatorBlock_2D(6, 5, Ho, Wo, 5, 6, Normalize=normalize).to(dev())
+        x = torch.randn(2, 6, H, W, device=dev())
+        if wrap:
+            blk, x = _wrap_module(blk), nan_wrapped(x)
+        x.requires_grad_(True)
+        y = blk(x)
+        y.square().sum().backward()
+        res.append([y.detach(), x.grad] + [p.grad for p in blk.parameters()])
+    _same(res[1], res[0], f"OperatorBlock_2D {geom} normalize={normalize}")
+
+
+def test_reads_stay_inside_inputs_training_steps():
+    """two Darcy steps (S = 75, ragged levels) and two NS-3D steps with every parameter, input and target between NaN runs"""
+    from uno_amd.harness import ComplexAdam, DarcyTrainer, UNO_9, Uno3D_T20, ns3d_loss, synthetic_darcy_batch
+    res = []
+    for wrap in (False, True):
+        torch.manual_seed(0)
+        model = UNO_9(3, 16, pad=5).to(dev())
+        a, u = synthetic_darcy_batch(2, 75, 5, dev())
+        if wrap:
+            model, a, u = _wrap_module(model), nan_wrapped(a), nan_wrapped(u)
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+        losses = [tr.step(a, u) for _ in range(2)]
+        res.append(losses + [p.detach().clone() for p in model.parameters()])
+    _same(res[1], res[0], "Darcy steps")
+    res = []
+    for wrap in (False, True):
+        torch.manual_seed(0)
+        model = Uno3D_T20(6, 4, pad=3).to(dev())
+        x, y = torch.randn(2, 32, 32, 10, 1, device=dev()), torch.randn(2, 32, 32, 20, device=dev())
+        if wrap:
+            model, x, y = _wrap_module(model), nan_wrapped(x), nan_wrapped(y)
+        opt = ComplexAdam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+        out = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = ns3d_loss(model, x, y)
+            loss.backward()
+            opt.step()
+            out.append(loss.detach())
+        res.append(out + [p.detach().clone() for p in model.parameters()])
+    _same(res[1], res[0], "NS-3D steps")

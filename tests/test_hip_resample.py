@@ -105,3 +105,28 @@ def test_trilinear_resample_vs_torch_cpu(sizes):
     assert yd.shape == yc.shape
     assert rel_err(yd.detach().cpu().numpy(), yc.detach().numpy()) < 2e-6
     assert rel_err(xd.grad.cpu().numpy(), xc.grad.numpy()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [((40, 40), (28, 28)), ((45, 45), (22, 22)), ((22, 37), (45, 50))])
+def test_resample_non_finite_row_stays_in_its_tiles(sizes):
+    """An Inf in one input row reaches, in the reference's banded interpolation, only the output rows with a tap on it.  The fused
+    kernel applies a dense 16 x NP row operator per tile of 16 output rows, so the row's own tiles may turn non-finite as a whole
+     - but no OTHER tile: the rows a tile's last k-step loads beyond its band are replaced by zero, not
+    multiplied by a zero weight (round 5; before, an Inf up to three rows past a tile's band made that tile NaN too)."""
+    from uno_amd.resample import resample2d_bicubic_aa
+    (H, W), (Ho, Wo) = sizes
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randn(1, 2, H, W, generator=g)
+    for r in range(H):
+        x = x0.clone()
+        x[:, :, r, :] = float("inf")
+        ref_bad = ~torch.isfinite(F.interpolate(x, size=(Ho, Wo), mode="bicubic", align_corners=True, antialias=True)).all(dim=(0, 1, 3))   # (Ho,)
+        got_bad = ~torch.isfinite(resample2d_bicubic_aa(x.to(dev), Ho, Wo).cpu()).all(dim=(0, 1, 3))
+        allowed = torch.zeros(Ho, dtype=torch.bool)
+        for i in ref_bad.nonzero().flatten().tolist():
+            allowed[(i // 16) * 16:(i // 16) * 16 + 16] = True
+        assert bool(ref_bad.any())
+        assert not bool((got_bad & ~allowed).any()), f"input row {r}: output rows {(got_bad & ~allowed).nonzero().flatten().tolist()} are non-finite outside the tiles of {ref_bad.nonzero().flatten().tolist()}"
+        assert bool((got_bad | ~ref_bad).all()), f"input row {r}: a row the reference makes non-finite came out finite"

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
     };
     // Register stage s holds step k + s.  Per step: multiply the transposed operands of this step, refill the stage they came from
     // (unconditionally, clamped row), transpose the next step's stage - whose loads were issued PF - 1 steps ago, so the waits in
-    // the loop are s_waitcnt vmcnt((PF - 1) steps' loads), never 0.  Steps past the end of this wave's K range multiply the (valid,
+    // the loop are s_waitcnt vmcnt((PF - 1) steps' loads), never 0.  Steps past the end of this wave's K range replace the (valid,
     // clamped) row by zero: one straight-line loop body, no tail code.
     if (active && kb < ke) {
 #pragma unroll
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
 #pragma unroll
             for (int s = 0; s < K2B_PF; ++s) {
                 const int d = s & 1;
-                const float live = (k + s < ke) ? 1.f : 0.f, la = live * sgnA;
+                const bool live = k + s < ke;          // (a select, not a multiplication by 0 / 1: the clamped row may hold Inf / NaN)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    const float ar = live * pa[d][mt].x, ai = la * pa[d][mt].y, nai = -ai;
+                    const float ar = live ? pa[d][mt].x : 0.f, ai = live ? sgnA * pa[d][mt].y : 0.f, nai = -ai;
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const float br = pb[d][nt].x, bi = sgnB * pb[d][nt].y;

@@ -140,11 +140,21 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
     // accumulating 223 -> 446 490 -> 400 us, 111 -> 223 272 -> 206, 334 -> 446 595 -> 499, 223 -> 334 629 -> 508; plain 223 -> 446
     // 302 -> 277; the down-sampling shapes - half of the threads idle in phase 2 - LOSE 10-20 % with it and keep the rolled loop)
     const bool straight = G == 1 && Wo >= W;
+    // down-sampling by two or more (the workgroup is at least twice as wide as an output row, rounded to half waves): TWO row groups of
+    // 8 rows each, every thread one column, straight-line - no idle half of the workgroup, all LDS reads of a thread in flight together
+    // (round 5; the rolled one-group loop ran these shapes at 2.8-3.7 TB/s: 446 -> 223, 223 -> 111 and their adjoints' columns)
+    const int WoH = (Wo + 31) & ~31;
+    const bool halves = !straight && nthreads >= 2 * WoH;
+    const int gh = tid / WoH, jh = tid - gh * WoH;                       // halves: row group (0, 1; beyond: idle) and column
     if constexpr (ACCUM) {
         if (straight) {
             const int jc = min(j0, Wo - 1);
 #pragma unroll
             for (int i = 0; i < RS_TR; ++i) old[i] = io_widen(dst[(size_t)min(i, nr - 1) * Wo + jc]);
+        } else if (halves) {
+            const int jc = min(jh, Wo - 1);
+#pragma unroll
+            for (int i = 0; i < RS_TR / 2; ++i) old[i] = io_widen(dst[(size_t)min(min(gh, 1) + 2 * i, nr - 1) * Wo + jc]);
         }
     }
     if constexpr (MF) {
@@ -152,11 +162,22 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
         const int nks = (NP + 3) >> 2;
         // the row operator in A-operand layout: [k-step][lane (out row n16, k-slot kk)]
+        // np_tile: rows of THIS tile's band (NP is the widest tile's; the table is zero beyond a tile's own band).  The rows a k-step
+        // loads past it are replaced by zero below instead of meeting a zero weight: an Inf / NaN in a row just below a tile's band
+        // must not become 0 x Inf = NaN in that tile's 16 output rows (the reference's banded interpolation never touches it)
+        int& s_np = *reinterpret_cast<int*>(sWd + nks * 64);               // (one word of the dynamic allocation: a static __shared__ object on top of a 160 KB dynamic request fails)
+        if (tid == 0) s_np = 0;
+        __syncthreads();
+        int my_np = 0;
         for (int e = tid; e < nks * 64; e += nthreads) {
             const int u = 4 * (e >> 6) + ((e & 63) >> 4);
-            sWd[e] = u < NP ? tile_w[((size_t)tile * NP + u) * RS_TR + (e & 15)] : 0.f;
+            const float wv = u < NP ? tile_w[((size_t)tile * NP + u) * RS_TR + (e & 15)] : 0.f;
+            sWd[e] = wv;
+            if (wv != 0.f) my_np = max(my_np, u + 1);
         }
+        if (my_np) atomicMax(&s_np, my_np);
         __syncthreads();
+        const int np_tile = s_np;
         for (int c0 = 64 * wave; c0 < W; c0 += 64 * nwaves) {
             // this lane's four columns; pieces past the row end are pulled back inside the row (their results are not stored)
             const int col = min(c0 + 4 * n16, max(W - 4, 0));
@@ -175,7 +196,11 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
                     const int ks = ks0 + d;
                     if (ks < nks) {                                                      // uniform
                         const float a = sWd[ks * 64 + lane];
-                        const float4 x = xb[d];
+                        float4 x = xb[d];
+                        // rows past the tile's band carry weight 0 - and are replaced by 0 here (see np_tile)
+                        if (4 * ks + 3 >= np_tile) {                                     // uniform: the tile's last k-steps only
+                            if (4 * ks + kk >= np_tile) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                         xb[d] = fetch(min(ks + RS_PD, nks - 1));                        // unconditional: the waits stay partial
                         acc[0] = mfma16(a, x.x, acc[0]);
                         acc[1] = mfma16(a, x.y, acc[1]);
@@ -297,7 +322,27 @@ __global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict
             }
         }
     };
-    if (straight) {
+    if (halves) {
+        if (gh < 2 && jh < Wo) {
+            const int j = jh, s = startW[j];
+            float w[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                float wv = wtW[(size_t)j * KW + min(t, KW - 1)];
+                asm volatile("" : "+v"(wv));
+                w[t] = t < KW ? wv : 0.f;
+            }
+#pragma unroll
+            for (int ii = 0; ii < RS_TR / 2; ++ii) {
+                const int i = gh + 2 * ii;
+                const float* v = V + i * WP;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) acc = fmaf(w[t], v[min(s + t, W - 1)], acc);
+                if (i < nr) io_store1(dst + (size_t)i * Wo + j, ACCUM ? old[ii] + acc : acc);
+            }
+        }
+    } else if (straight) {
         for (int j = j0; j < Wo; j += jstride) sweep(j, std::true_type{});
     } else if (g < G) {
         for (int j = j0; j < Wo; j += jstride) sweep(j, std::false_type{});
@@ -332,7 +377,7 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
     // dynamic LDS of the fused kernel: the 16 x W tile (rows padded to 4 floats) + the dense row-operator tile.  Gated on the
     // REAL request (W ~ 980..1024 passes a tile-only test and then asks for more than the 64 KB a launch gets without the
     // dynamic-LDS attribute: the launch fails instead of falling through to the two-pass form)
-    const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float);
+    const size_t lds = (size_t)RS_TR * ((W + 3) & ~3) * sizeof(float) + (size_t)((NP + 3) / 4) * 64 * sizeof(float) + 16;
     // (round 3: up to 150 KB - one workgroup per CU - through the dynamic-LDS attribute; the two-pass form took 2.0 ms per call at
     // the 1089 -> 544 level of the C5 model where this kernel needs 0.5)
     if (!wide_band && tile_p0 && tile_w && NP >= 1 && NP <= 96 && lds <= 150 * 1024) {
