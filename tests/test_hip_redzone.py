@@ -244,7 +244,7 @@ def test_reads_stay_inside_inputs_spectral_conv2d(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 3, 2, (16, 16, 10), (12, 12, 16), (4, 4, 3)), (8, 8, 8, (32, 32, 13), (16, 16, 15), (6, 6, 5)),
-                                 (7, 7, 8, (64, 64, 20), (48, 48, 13), (16, 16, 8))])
+                                 (7, 7, 8, (64, 64, 20), (48, 48, 20), (16, 16, 8))])
 def test_reads_stay_inside_inputs_spectral_conv3d(cfg):
     from uno_amd.spectral3d import spectral_conv3d
     B, Ci, Co, din, dout, modes = cfg

@@ -178,50 +178,44 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
             // ---- stage A, full chunks: lane (row r16, k-slot kk) owns column pairs w = 1 + 16 c + 4 kk + s, s = 0..3.
             // One wave per SIMD: image operands AND twiddles of chunk c + 1 are requested before the MFMAs of chunk c are issued
             // (sched_barrier keeps the requests there), so no LDS latency sits in front of an MFMA.
-            float xl[4], xr[4];
-            float2 twF[4][NTFA], tw4[4][NQ];
+            // (two operand sets in ping-pong, as in the half-tile form: no copies of the next chunk's operands after every MFMA block)
+            struct RowOps { float xl[4], xr[4]; float2 twF[4][NTFA], tw4[4][NQ]; };
+            RowOps opA, opB;
             const float* pl = row + 1 + 4 * kk;                 // left columns of chunk 0
             const float* pr = row + W - 4 - 4 * kk;             // mirrored columns of chunk 0 (ascending address)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                xl[s] = pl[s]; xr[s] = pr[s];
-#pragma unroll
-                for (int t = 0; t < NTF; ++t) twF[s][t] = tabF[(s * NTF + t) * 64];
-#pragma unroll
-                for (int g = 0; g < R4; ++g) tw4[s][g] = tab4[(s * R4 + g) * 16];
-            }
-            for (int c = 0; c < nfull; ++c) {
-                const int cn = min(c + 1, nfull - 1);
-                float nl[4], nr[4];
-                float2 ntwF[4][NTFA], ntw4[4][NQ];
-                // k-steps 4 (c + 1) .. 4 (c + 1) + 3: the next chunk, or (after the last chunk) the first tail k-steps
-                const float2* tf = tabF + (size_t)(4 * (c + 1)) * (NTF * 64);
-                const float2* t4 = tab4 + (size_t)(4 * (c + 1)) * (R4 * 16);
+            auto load_ops = [&](RowOps& o, int c) {
+                // k-steps 4 c .. 4 c + 3: chunk c, or (c = nfull) the first tail k-steps' twiddles with the last chunk's (unused) image values
+                const int cn = min(c, max(nfull - 1, 0));
+                const float2* tf = tabF + (size_t)(4 * c) * (NTF * 64);
+                const float2* t4 = tab4 + (size_t)(4 * c) * (R4 * 16);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    nl[s] = pl[16 * cn + s]; nr[s] = pr[-16 * cn + s];
+                    o.xl[s] = pl[16 * cn + s]; o.xr[s] = pr[-16 * cn + s];
 #pragma unroll
-                    for (int t = 0; t < NTF; ++t) ntwF[s][t] = tf[(s * NTF + t) * 64];
+                    for (int t = 0; t < NTF; ++t) o.twF[s][t] = tf[(s * NTF + t) * 64];
 #pragma unroll
-                    for (int g = 0; g < R4; ++g) ntw4[s][g] = t4[(s * R4 + g) * 16];
+                    for (int g = 0; g < R4; ++g) o.tw4[s][g] = t4[(s * R4 + g) * 16];
                 }
+            };
+            auto chunk = [&](RowOps& cur, RowOps& nxt, int c) {
+                load_ops(nxt, c + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float E = xl[s] + xr[3 - s];
-                    const float D = xl[s] - xr[3 - s];
-                    UNO_FT_MFMA(E, D, twF[s], tw4[s]);
+                    const float E = cur.xl[s] + cur.xr[3 - s];
+                    const float D = cur.xl[s] - cur.xr[3 - s];
+                    UNO_FT_MFMA(E, D, cur.twF[s], cur.tw4[s]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    xl[s] = nl[s]; xr[s] = nr[s];
-#pragma unroll
-                    for (int t = 0; t < NTF; ++t) twF[s][t] = ntwF[s][t];
-#pragma unroll
-                    for (int g = 0; g < R4; ++g) tw4[s][g] = ntw4[s][g];
-                }
+            };
+            load_ops(opA, 0);
+            {
+                int c = 0;
+                for (; c + 2 <= nfull; c += 2) { chunk(opA, opB, c); chunk(opB, opA, c + 1); }
+                if (c < nfull) { chunk(opA, opB, c); opA = opB; }               // (odd chunk count: one copy per tile)
             }
+            float2 (&twF)[4][NTFA] = opA.twF;
+            float2 (&tw4)[4][NQ] = opA.tw4;
             // ---- tail k-steps: pairs beyond the last full chunk, then w = 0, then the Nyquist column; the twiddles of the first
             // four are already in twF / tw4
             {

@@ -227,50 +227,40 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
     } while (0)
             // chunks [c_lo, c_hi) of the row stage: lane (row r16, k-slot kk) owns column pairs w = 1 + 16 c + 4 kk + s; pl / pr
             // point at this lane's four left / mirrored columns of chunk c_lo and move by +-16 floats per chunk
+            // (two operand sets in ping-pong - round 5: the rolled loop copied the next chunk's 8 image values and 8 NT twiddle
+            // registers into the current set after every MFMA block, ~24 v_mov per 8 + 8 MFMAs that no MFMA covered: a wave's
+            // VALU instructions run under its OWN MFMAs only when they sit between them in program order)
+            struct RowOps { float xl[4], xr[4]; float2 twF[4][NTFA], tw4[4][NQ]; };
             auto row_stage = [&](const float* pl, const float* pr, int c_lo, int c_hi) {
-                float xl[4], xr[4];
-                float2 twF[4][NTFA], tw4[4][NQ];
-                const float2* tf0 = tabF + (size_t)(4 * c_lo) * (NTF * 64);
-                const float2* t40 = tab4 + (size_t)(4 * c_lo) * (R4 * 16);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    xl[s] = pl[s]; xr[s] = pr[s];
-#pragma unroll
-                    for (int t = 0; t < NTF; ++t) twF[s][t] = tf0[(s * NTF + t) * 64];
-#pragma unroll
-                    for (int g = 0; g < R4; ++g) tw4[s][g] = t40[(s * R4 + g) * 16];
-                }
-                for (int c = c_lo; c < c_hi; ++c) {
-                    const int dn = 16 * (min(c + 1, c_hi - 1) - c_lo);
-                    float nl[4], nr[4];
-                    float2 ntwF[4][NTFA], ntw4[4][NQ];
-                    const float2* tf = tabF + (size_t)(4 * (c + 1)) * (NTF * 64);
-                    const float2* t4 = tab4 + (size_t)(4 * (c + 1)) * (R4 * 16);
+                RowOps A, B;
+                auto load_ops = [&](RowOps& o, int c) {                    // operands of chunk c (clamped to the last chunk of the range)
+                    const int dn = 16 * (min(c, c_hi - 1) - c_lo);
+                    const float2* tf = tabF + (size_t)(4 * c) * (NTF * 64);
+                    const float2* t4 = tab4 + (size_t)(4 * c) * (R4 * 16);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        nl[s] = pl[dn + s]; nr[s] = pr[-dn + s];
+                        o.xl[s] = pl[dn + s]; o.xr[s] = pr[-dn + s];
 #pragma unroll
-                        for (int t = 0; t < NTF; ++t) ntwF[s][t] = tf[(s * NTF + t) * 64];
+                        for (int t = 0; t < NTF; ++t) o.twF[s][t] = tf[(s * NTF + t) * 64];
 #pragma unroll
-                        for (int g = 0; g < R4; ++g) ntw4[s][g] = t4[(s * R4 + g) * 16];
+                        for (int g = 0; g < R4; ++g) o.tw4[s][g] = t4[(s * R4 + g) * 16];
                     }
+                };
+                auto chunk = [&](RowOps& cur, RowOps& nxt, int c) {
+                    load_ops(nxt, c + 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float E = xl[s] + xr[3 - s];
-                        const float D = xl[s] - xr[3 - s];
-                        UNO_HT_MFMA(E, D, twF[s], tw4[s]);
+                        const float E = cur.xl[s] + cur.xr[3 - s];
+                        const float D = cur.xl[s] - cur.xr[3 - s];
+                        UNO_HT_MFMA(E, D, cur.twF[s], cur.tw4[s]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        xl[s] = nl[s]; xr[s] = nr[s];
-#pragma unroll
-                        for (int t = 0; t < NTF; ++t) twF[s][t] = ntwF[s][t];
-#pragma unroll
-                        for (int g = 0; g < R4; ++g) tw4[s][g] = ntw4[s][g];
-                    }
-                }
+                };
+                load_ops(A, c_lo);
+                int c = c_lo;
+                for (; c + 2 <= c_hi; c += 2) { chunk(A, B, c); chunk(B, A, c + 1); }
+                if (c < c_hi) chunk(A, B, c);
             };
 
             // ---- outer half

@@ -390,24 +390,26 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
         // ping-pong, no copies), and interior tiles take a branch-free path.
         const int rowbase = phase + r16 * W;
         const bool row_ok = r16 < rows;
-        float2 twc[KS];                         // twiddles of the column tile whose chain is issued next
+        // twiddles of the column tiles in two sets, ping-pong: even tiles multiply out of twA while twB is filled, odd tiles the other
+        // way round (round 5: the single set was refilled by 2 KS copies after every chain, which no MFMA covered)
+        float2 twA[KS], twB[KS];
 #pragma unroll
-        for (int sp = 0; sp < KS; ++sp) twc[sp] = tabLane[sp * 64];
-        auto chain_mfma = [&](int wt, f32x4& Ey, f32x4& Dy) {
+        for (int sp = 0; sp < KS; ++sp) twA[sp] = tabLane[sp * 64];
+        auto chain_sets = [&](int wt, f32x4& Ey, f32x4& Dy, float2 (&cur)[KS], float2 (&nxtset)[KS]) {
             // request the NEXT tile's twiddles first (sched_barrier keeps the reads in front of the MFMAs), then run this chain
             const float2* nxt = tabLane + (size_t)min(wt + 1, nwt - 1) * (KS * 64);
-            float2 twn[KS];
 #pragma unroll
-            for (int sp = 0; sp < KS; ++sp) twn[sp] = nxt[sp * 64];
+            for (int sp = 0; sp < KS; ++sp) nxtset[sp] = nxt[sp * 64];
             __builtin_amdgcn_sched_barrier(0);
             Ey = f32x4{0, 0, 0, 0}; Dy = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int sp = 0; sp < KS; ++sp) {
-                Ey = mfma16(twc[sp].x, Ur[sp >> 2][sp & 3], Ey);
-                Dy = mfma16(twc[sp].y, Ui[sp >> 2][sp & 3], Dy);
+                Ey = mfma16(cur[sp].x, Ur[sp >> 2][sp & 3], Ey);
+                Dy = mfma16(cur[sp].y, Ui[sp >> 2][sp & 3], Dy);
             }
-#pragma unroll
-            for (int sp = 0; sp < KS; ++sp) twc[sp] = twn[sp];
+        };
+        auto chain_mfma = [&](int wt, f32x4& Ey, f32x4& Dy) {
+            if (wt & 1) chain_sets(wt, Ey, Dy, twB, twA); else chain_sets(wt, Ey, Dy, twA, twB);      // (uniform)
         };
         auto stage_fast = [&](int wt, const f32x4& Ey, const f32x4& Dy) {
             const int w0 = 16 * wt + 4 * kk;
