@@ -698,3 +698,25 @@ def test_join_is_voided_when_a_consumer_cannot_defer(fallback):
         (y.square().sum() + second.sin().sum()).backward()
         res[mode] = [x.grad.clone()] + [p.grad.clone() for m in (prod, cons, other, lin) for p in m.parameters() if p.grad is not None]
     _assert_same_grads(res["plain"], res["joined"], tol=2e-5)
+
+
+@pytest.mark.gpu
+def test_training_step_without_the_private_autograd_entry_points(monkeypatch):
+    """with torch._C._current_graph_task_id / the engine's callback queue unavailable (simulated) the whole Darcy
+    step - flat gradient buffer, joined skip gradients, a layer used three times - runs on the ordinary gradient path and gives the
+    default path's parameters."""
+    import uno_amd.integral_operators as io
+    from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    res = []
+    for available in (True, False):
+        monkeypatch.setattr(io, "_PASS_STATE_AVAILABLE", available)
+        torch.manual_seed(0)
+        model = UNO_9(3, 8, pad=5).to(dev())
+        tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+        a, u = synthetic_darcy_batch(2, 72, 3, dev())
+        for _ in range(2):
+            loss = tr.step(a, u)
+        res.append([loss.clone()] + [p.detach().clone() for p in model.parameters()])
+    for x, y in zip(*res):
+        xr, yr = (torch.view_as_real(t) if t.is_complex() else t for t in (x, y))
+        assert float((xr - yr).norm()) <= 1e-5 * float(xr.norm()) + 1e-12

@@ -79,3 +79,14 @@ def test_stale_backward_pass_entries_are_swept(monkeypatch):
     assert io._pass_state() is None            # outside a pass: sweeps
     assert 123456 not in io._PASSES and 123457 in io._PASSES
     io._PASSES.clear()
+
+
+def test_private_autograd_entry_points_are_optional(monkeypatch):
+    """without torch._C._current_graph_task_id / the engine's callback queue the library must take the ordinary
+    gradient path (no pass state), not fail."""
+    from uno_amd import integral_operators as io
+    assert io._PASS_STATE_AVAILABLE                  # this torch has both
+    monkeypatch.setattr(io, "_PASS_STATE_AVAILABLE", False)
+    assert io._graph_task_id() == -1 and io._pass_state() is None
+    p = torch.nn.Parameter(torch.zeros(3))
+    assert io._grad_plan(p, None) is None and io._grad_targets([p]) is None

@@ -208,9 +208,22 @@ def _sweep_stale_passes():
             _PASSES.pop(tid, None)
 
 
+# The pass state hangs on two private entry points of autograd (the id of the running graph task, the engine's final-callback
+# queue).  Should a torch release drop either, the library falls back to the ordinary path - every weight-gradient kernel returns
+# its gradient as a fresh tensor and autograd accumulates - instead of failing: slower (one zero fill + one add per parameter
+# and use), same results.
+_current_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_queue_callback = getattr(getattr(torch.autograd.Variable, "_execution_engine", None), "queue_callback", None)
+_PASS_STATE_AVAILABLE = _current_graph_task_id is not None and _queue_callback is not None
+
+
+def _graph_task_id() -> int:
+    return _current_graph_task_id() if _PASS_STATE_AVAILABLE else -1
+
+
 def _pass_state():
     """The dictionaries of the running backward pass (registered with the engine on first use), or None outside a pass."""
-    tid = torch._C._current_graph_task_id()
+    tid = _graph_task_id()
     if tid < 0:
         if _PASSES:
             _sweep_stale_passes()
@@ -224,7 +237,7 @@ def _pass_state():
             if ps is None:
                 ps = _PASSES[tid] = {"id": tid, "acc": {}, "stacks": {}, "uses": {}, "born": time.monotonic()}
                 # final callbacks belong to the graph task that is current when they are queued: this one runs when THIS pass completes
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_pass(tid))
+                _queue_callback(lambda: _end_of_pass(tid))
     return ps
 
 
@@ -256,7 +269,7 @@ def _end_of_pass(tid):
 
 def _grad_plan(p, ps):
     """('acc', tensor): later contribution of this pass | ('new', registered buffer or None): first contribution | None: ordinary path"""
-    if not INPLACE_PARAM_GRADS or not isinstance(p, torch.Tensor) or not p.is_leaf or not p.requires_grad or not p.is_cuda:
+    if not (INPLACE_PARAM_GRADS and _PASS_STATE_AVAILABLE) or not isinstance(p, torch.Tensor) or not p.is_leaf or not p.requires_grad or not p.is_cuda:
         return None
     if ps is None:
         return None
@@ -362,7 +375,7 @@ class _SpectrumStack:
 def _stack_take(leaf, shape, device, wanted):
     """Forward pass of a spectral layer: (stack, slot) for this use's truncated input spectrum, or None (layer used once per pass,
     no gradient wanted, stacking off)."""
-    if not (TIME_BATCHED_WGRAD and wanted and INPLACE_PARAM_GRADS) or not isinstance(leaf, torch.Tensor) or not leaf.is_leaf:
+    if not (TIME_BATCHED_WGRAD and wanted and INPLACE_PARAM_GRADS and _PASS_STATE_AVAILABLE) or not isinstance(leaf, torch.Tensor) or not leaf.is_leaf:
         return None
     cap = getattr(leaf, "_uno_uses", 0)
     # the per-mode GEMM addresses an operand with 32-bit byte offsets: a stack (and the stack of output-gradient spectra) stays under 2 GiB
@@ -1304,7 +1317,7 @@ class OperatorBlock_2D(nn.Module):
         if Normalize:
             self.normalize_layer = nn.InstanceNorm2d(int(out_codim), affine=True)
 
-    def forward(self, x, dim1=None, dim2=None, join=None, out_join=None):
+    def forward(self, x, dim1=None, dim2=None, *, join=None, out_join=None):
         """join / out_join (optional, beyond the reference signature): GradJoin objects of the input / of this block's output - see
         GradJoin and _OperatorBlock2dFn."""
         if self.non_lin and not self.normalize:
