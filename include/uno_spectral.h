@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 9
+#define UNO_SPECTRAL_ABI_VERSION 10
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -230,6 +230,25 @@ int uno_gelu_project_forward(const float* pre, const float* w, const float* bias
 long long uno_gelu_project_bwd_ws_bytes(int B, int C, long long P);
 int uno_gelu_project_backward(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb,
                               void* ws, int B, int C, long long P, void* stream);
+
+/* The same three calls on a WINDOW of a wider plane (ABI 10).  The reference crops the domain padding before its last two layers
+ * (darcy_flow_uno2d.py:125-131: `x_c5[..., :-padding, :-padding]`, then fc1 - GELU - fc2 on S x S points); here those layers read
+ * the padded (S + pad)^2 tensors in place and touch the domain only: the pixel axis of the call is rows x cols logical pixels,
+ * row r starting r * pitch elements into a channel plane, channel planes `plane` elements apart (plane >= rows * pitch) - for
+ * EVERY operand of the call (x1, x2, y1, y2, y_act, dgelu_of; gy; pre, gpre; proj_out and gout with one plane per batch entry).
+ * cols is a multiple of 4 with 260 <= cols <= pitch and rows * cols < 2^24: pass the domain width rounded UP to a multiple of 4 -
+ * the extra columns are ordinary points of the padded grid (their output gradient is zero).  Elements outside the window are
+ * neither read nor written: a gradient tensor produced by a windowed call must have its border cleared by the caller.
+ * Float32 only; uno_channel_mix2_win runs the tiled and split kernels (not the wide / few-input forms), uno_channel_wgrad2_win needs
+ * more than 4 input channels; scratch sizes as for the dense calls with P = rows * cols. */
+int uno_channel_mix2_win(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
+                         float* y_act, int B, int Ci, int Co, int rows, int cols, int pitch, long long plane, int transpose_w,
+                         int accumulate, int act_in, const float* dgelu_of, const float* proj_w, const float* proj_b, float* proj_out,
+                         void* stream);
+int uno_channel_wgrad2_win(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
+                           int Co, int rows, int cols, int pitch, long long plane, int act_x, int accumulate, void* stream);
+int uno_gelu_project_backward_win(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws,
+                                  int B, int C, int rows, int cols, int pitch, long long plane, void* stream);
 
 /* GELU followed by zero padding at the end of both axes (the lift's last activation + domain padding, reference
  * darcy_flow_uno2d.py:103-107): backward = 0: out (n_img, Hp, Wp) = pad(gelu(s (n_img, H, W))), gy ignored;

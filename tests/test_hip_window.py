@@ -1,0 +1,164 @@
+"""Windowed channel-mix calls (uno_channel_mix2_win / uno_channel_wgrad2_win / uno_gelu_project_backward_win, ABI 10): the last
+two layers of the Darcy model on the S x S domain INSIDE the padded tensors (reference darcy_flow_uno2d.py:125-131 crops the
+padding, then fc1 - GELU - fc2).  Every windowed call is compared with the dense call on a contiguous copy of the window, in
+float64 where the dense call's own tests do; elements outside the window must be left exactly as they were."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# rows, cols (multiple of 4, >= 260), pitch, plane rows of the padded tensor
+WINDOWS = [
+    (9, 264, 264, 9),            # the window IS the plane
+    (7, 260, 301, 11),           # odd pitch: rows start 4-byte aligned only
+    (37, 424, 446, 40),          # the Darcy geometry (421 -> 424 of 446), a few rows
+    (5, 512, 515, 5),            # full height, three spare columns
+]
+
+
+def rel(a, b):
+    d = (a.double() - b.double()).norm().item()
+    n = b.double().norm().item()
+    return d / n if n > 0 else d
+
+
+def _planes(B, C, H, pitch, g, fill=None):
+    t = torch.randn(B, C, H * pitch, generator=g)
+    if fill is not None:
+        t.fill_(fill)
+    return t.cuda()
+
+
+def _crop(t, rows, cols, pitch):
+    """(B, C, plane) -> contiguous (B, C, rows * cols)"""
+    B, C = t.shape[:2]
+    return t.view(B, C, -1, pitch)[:, :, :rows, :cols].reshape(B, C, rows * cols).contiguous()
+
+
+def _outside_untouched(t, before, rows, cols, pitch):
+    v, b = t.view(*t.shape[:2], -1, pitch), before.view(*t.shape[:2], -1, pitch)
+    return torch.equal(v[:, :, rows:], b[:, :, rows:]) and torch.equal(v[:, :, :rows, cols:], b[:, :, :rows, cols:])
+
+
+@pytest.mark.parametrize("rows,cols,pitch,H", WINDOWS)
+@pytest.mark.parametrize("C1,C2,Co,act_in", [(64, 64, 64, True), (32, 0, 40, False), (128, 0, 128, False), (64, 64, 64, False), (16, 16, 24, True)])
+def test_forward_window_equals_dense_on_the_crop(rows, cols, pitch, H, C1, C2, Co, act_in):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(rows + cols + C1 + Co)
+    B = 2
+    x1 = _planes(B, C1, H, pitch, g)
+    x2 = _planes(B, C2, H, pitch, g) if C2 else None
+    w, b = (torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    out = torch.full((B, Co, H * pitch), 7.25).cuda()
+    before = out.clone()
+    _native.channel_mix2(x1, x2, w, b, act_in=act_in, out=out, window=(rows, cols, pitch))
+    ref = _native.channel_mix2(_crop(x1, rows, cols, pitch), _crop(x2, rows, cols, pitch) if C2 else None, w, b, act_in=act_in)
+    assert rel(_crop(out, rows, cols, pitch), ref) < 1e-6
+    assert _outside_untouched(out, before, rows, cols, pitch)
+
+
+@pytest.mark.parametrize("rows,cols,pitch,H", WINDOWS)
+def test_fused_projection_window(rows, cols, pitch, H):
+    """the fc1 - GELU - fc2 kernel of the model (two sources, GELU on the first, 64 channels, one projected output)"""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(rows * 3 + cols)
+    B, C1, C2, Co = 2, 64, 64, 64
+    x1, x2 = _planes(B, C1, H, pitch, g), _planes(B, C2, H, pitch, g)
+    w, b = (torch.randn(Co, C1 + C2, generator=g) / 11).cuda(), torch.randn(Co, generator=g).cuda()
+    w2, b2 = torch.randn(Co, generator=g).cuda(), torch.randn(1, generator=g).cuda()
+    y, proj = _native.channel_mix2(x1, x2, w, b, act_in=True, project=(w2, b2), window=(rows, cols, pitch))
+    yr, pr = _native.channel_mix2(_crop(x1, rows, cols, pitch), _crop(x2, rows, cols, pitch), w, b, act_in=True, project=(w2, b2))
+    assert y.shape == (B, Co, H * pitch) and proj.shape == (B, H * pitch)
+    assert rel(_crop(y, rows, cols, pitch), yr) < 1e-6
+    assert rel(_crop(proj.view(B, 1, -1), rows, cols, pitch), pr.view(B, 1, -1)) < 1e-6
+
+
+@pytest.mark.parametrize("rows,cols,pitch,H", WINDOWS)
+@pytest.mark.parametrize("Ci,Co,dgelu,acc", [(64, 64, True, 0), (64, 64, False, 1), (64, 64, True, 2), (64, 32, False, 0), (128, 128, True, 1), (128, 64, False, 0)])
+def test_input_gradient_window(rows, cols, pitch, H, Ci, Co, dgelu, acc):
+    """transposed calls: fresh output, accumulating output, gelu' on the product (acc 0 / 1) and on the completed sum (acc 2)"""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(rows + Ci + Co + acc)
+    B = 2
+    gy = _planes(B, Ci, H, pitch, g)
+    w = (torch.randn(Ci, Co, generator=g) / Ci ** 0.5).cuda()
+    pre = _planes(B, Co, H, pitch, g) if dgelu else None
+    out = _planes(B, Co, H, pitch, g)
+    before = out.clone()
+    win = (rows, cols, pitch)
+    if acc:
+        _native.channel_mix(gy, w, None, transpose_w=True, out=out, dgelu_of=pre, dgelu_total=acc == 2, window=win)
+        ref = _crop(before, rows, cols, pitch)
+        _native.channel_mix(_crop(gy, *win), w, None, transpose_w=True, out=ref, dgelu_of=_crop(pre, *win) if dgelu else None, dgelu_total=acc == 2)
+    else:
+        _native.channel_mix2(gy, None, w, None, transpose_w=True, out=out, dgelu_of=pre, window=win)
+        ref = _native.channel_mix(_crop(gy, *win), w, None, transpose_w=True, dgelu_of=_crop(pre, *win) if dgelu else None)
+    assert rel(_crop(out, *win), ref) < 1e-6
+    assert _outside_untouched(out, before, *win)
+
+
+@pytest.mark.parametrize("rows,cols,pitch,H", WINDOWS)
+@pytest.mark.parametrize("C1,C2,Co,act_x", [(64, 64, 64, True), (64, 0, 64, False), (128, 128, 128, False), (64, 64, 32, False), (128, 0, 256, True)])
+def test_weight_gradient_window(rows, cols, pitch, H, C1, C2, Co, act_x):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(rows + C1 + Co)
+    B = 3
+    win = (rows, cols, pitch)
+    gy, x1 = _planes(B, Co, H, pitch, g), _planes(B, C1, H, pitch, g)
+    x2 = _planes(B, C2, H, pitch, g) if C2 else None
+    gw, gb = _native.channel_wgrad2(gy, x1, x2, need_bias=True, act_x=act_x, window=win)
+    x1c = _crop(x1, *win).double()
+    if act_x:
+        x1c = torch.nn.functional.gelu(x1c)
+    xc = torch.cat([x1c] + ([_crop(x2, *win).double()] if C2 else []), 1)
+    gyc = _crop(gy, *win).double()
+    assert rel(gw, torch.einsum("bop,bip->oi", gyc, xc)) < 2e-5
+    assert rel(gb, gyc.sum((0, 2))) < 2e-5
+
+
+@pytest.mark.parametrize("rows,cols,pitch,H", WINDOWS)
+def test_gelu_project_backward_window(rows, cols, pitch, H):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(rows + pitch)
+    B, Cc = 2, 64
+    win = (rows, cols, pitch)
+    pre, gout = _planes(B, Cc, H, pitch, g), _planes(B, 1, H, pitch, g).view(B, -1)
+    w = torch.randn(Cc, generator=g).cuda()
+    gpre, gw, gb = _native.gelu_project_backward(pre, w, gout, need_bias=True, window=win)
+    rp, rw, rb = _native.gelu_project_backward(_crop(pre, *win), w, _crop(gout.view(B, 1, -1), *win).view(B, -1), need_bias=True)
+    assert rel(_crop(gpre, *win), rp) < 1e-6 and rel(gw, rw) < 2e-5 and rel(gb, rb) < 2e-5
+
+
+def test_cat_project_with_crop_matches_the_uncropped_layer():
+    """channel_mix_cat_project(crop=): output and every gradient of the cropped result agree with the call that computes the whole
+    padded grid and crops afterwards (what the model did before ABI 10), the input gradients are exactly zero outside the domain."""
+    from uno_amd.integral_operators import channel_mix_cat_project
+    torch.manual_seed(11)
+    B, C1, C2, Co, H, W, S1, S2 = 2, 64, 64, 64, 40, 300, 33, 277
+    base = [torch.randn(B, C1, H, W), torch.randn(B, C2, H, W), torch.randn(Co, C1 + C2) / 11, torch.randn(Co), torch.randn(1, Co), torch.randn(1)]
+    gout = torch.randn(B, 1, S1, S2).cuda()
+    res = []
+    for crop in ((S1, S2), None):
+        t = [v.clone().cuda().requires_grad_(True) for v in base]
+        out = channel_mix_cat_project(t[:2], t[2], t[3], t[4], t[5], gelu_first=True, crop=crop)[:, :, :S1, :S2]
+        out.backward(gout)
+        res.append((out.detach(), [v.grad for v in t]))
+    (o1, g1), (o0, g0) = res
+    assert rel(o1, o0) < 1e-6
+    for a, b, tol in zip(g1, g0, (2e-6, 2e-6, 2e-5, 2e-5, 2e-5, 2e-5)):
+        assert rel(a, b) < tol
+    for gx in g1[:2]:
+        assert float(gx[:, :, S1:].abs().max()) == 0.0 and float(gx[:, :, :, S2:].abs().max()) == 0.0
+
+
+def test_window_argument_errors():
+    from uno_amd import _native
+    x = torch.randn(1, 64, 20 * 300).cuda()
+    w = torch.randn(64, 64).cuda()
+    for win in ((20, 258, 300), (20, 262, 300), (20, 304, 300), (21, 260, 300)):
+        with pytest.raises(RuntimeError):
+            _native.channel_mix2(x, None, w, None, window=win)
+    with pytest.raises(RuntimeError):
+        _native.channel_mix2(x.bfloat16(), None, w, None, window=(20, 260, 300))
+    with pytest.raises(RuntimeError):                                           # few input channels: dense only
+        _native.channel_wgrad2(torch.randn(1, 8, 20 * 300).cuda(), torch.randn(1, 3, 20 * 300).cuda(), None, window=(20, 260, 300))

@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 _lock = threading.Lock()
@@ -54,6 +54,9 @@ _SIGNATURES = {
     "uno_channel_wgrad": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _fp]),
     "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
+    "uno_channel_mix2_win": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    "uno_channel_wgrad2_win": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
+    "uno_gelu_project_backward_win": (C.c_int, [_fp] * 7 + [_i, _i, _i, _i, _i, C.c_longlong, _fp]),
     "uno_channel_wgrad_finish": (C.c_int, [_fp, _fp, _fp, _i, _i, C.c_longlong, _i, _fp]),
     "uno_mode_wgrad_acc": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
     "uno_spectral_conv2d_backward_acc": (C.c_int, [_fp] * 8 + [_i] * 11 + [_fp]),
@@ -476,10 +479,26 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
     return out
 
 
-def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bool = False, dgelu_of=None, dgelu_total: bool = False):
+def _window_args(window, plane: int, bf16: bool):
+    """(rows, cols, pitch) of a windowed call (uno_spectral.h, ABI 10): the tensors' last axis is a whole plane of `plane` elements."""
+    rows, cols, pitch = (int(v) for v in window)
+    if bf16:
+        raise RuntimeError("uno_amd: pixel windows are float32 only")
+    if rows < 1 or cols % 4 or cols < 260 or pitch < cols or (rows - 1) * pitch + cols > plane or rows * cols >= 1 << 24:
+        raise RuntimeError(f"uno_amd: window rows={rows} cols={cols} pitch={pitch} does not fit a plane of {plane} elements "
+                           "(cols: a multiple of 4, 260 <= cols <= pitch; rows * cols < 2^24)")
+    return rows, cols, pitch
+
+
+def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bool = False, dgelu_of=None, dgelu_total: bool = False,
+                window=None):
     """x (B, Ci, P) f32, w (Co, Ci) (or (Ci, Co) with transpose_w) -> y (B, Co, P) = Wm x + bias;
     out: accumulate into this (B, Co, P) tensor instead; act_in: x := gelu(x) as it is read; dgelu_of (B, Co, P): the
-    product is multiplied by gelu'(dgelu_of) - with dgelu_total (and out) the completed sum out + product is."""
+    product is multiplied by gelu'(dgelu_of) - with dgelu_total (and out) the completed sum out + product is.
+    window = (rows, cols, pitch): the call works on that window of planes of P elements (see channel_mix2)."""
+    if window is not None:
+        return channel_mix2(x, None, w, bias, transpose_w=transpose_w, out=out, act_in=act_in, dgelu_of=dgelu_of,
+                            accumulate=(2 if (dgelu_total and dgelu_of is not None) else 1) if out is not None else 0, window=window)
     bf16 = _act_dtype(x, "x")
     _require(w, torch.float32, "weight")
     if bias is not None:
@@ -520,12 +539,16 @@ def channel_mix2_ok(C1: int, Co1, Co: int, P: int) -> bool:
 
 
 def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2=None, split_out: int | None = None,
-                 act_in: bool = False, dgelu_of=None, y_act: bool = False, accumulate: bool = False, project=None):
+                 act_in: bool = False, dgelu_of=None, y_act: bool = False, accumulate: bool = False, project=None, window=None):
     """uno_channel_mix2: y = Wm . cat(x1, x2) + bias in one pass (x2 may be None).
     split_out = Co1: the output channels go to two tensors (B, Co1, P), (B, Co - Co1, P) -> returns (y1, y2);
     y_act: also return gelu(y) as a second tensor -> (y, act); act_in / dgelu_of act on x1 / y1 only;
     out (and out2): write (accumulate=True: add) into the given tensors instead of allocating;
-    project = (w2 (Co,), b2 (1,) or None): also return proj (B, P) = b2 + sum_o w2[o] gelu(y[:, o]) -> (y, proj)  (Co <= 64)."""
+    project = (w2 (Co,), b2 (1,) or None): also return proj (B, P) = b2 + sum_o w2[o] gelu(y[:, o]) -> (y, proj)  (Co <= 64).
+    window = (rows, cols, pitch): every tensor's last axis is a whole plane of P elements of which the call reads and writes only
+    the window - rows x cols points, row r at r * pitch (uno_channel_mix2_win; float32; fresh outputs are torch.empty planes whose
+    elements outside the window are left as they are).  accumulate = 2 (with out and dgelu_of, one destination): gelu' multiplies
+    the completed sum."""
     bf16 = _act_dtype(x1, "x1")
     _require(w, torch.float32, "weight")
     if x2 is not None:
@@ -565,11 +588,17 @@ def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2
         if pb is not None:
             _require(pb, torch.float32, "projection bias")
         proj = torch.empty((B, P), dtype=x1.dtype, device=x1.device)
+    acc_flag = int(accumulate) if out is not None else 0
+    if acc_flag == 2 and (dgelu_of is None or window is None):
+        raise RuntimeError("uno_amd: accumulate = 2 goes with dgelu_of (windowed one-destination calls)")
     with torch.cuda.device(x1.device):
-        fn = lib().uno_channel_mix2_bf16 if bf16 else lib().uno_channel_mix2
+        if window is not None:
+            fn, size = lib().uno_channel_mix2_win, (*_window_args(window, P, bf16), P)
+        else:
+            fn, size = (lib().uno_channel_mix2_bf16 if bf16 else lib().uno_channel_mix2), (P,)
         rc = fn(_ptr(x1), _ptr(x2) if x2 is not None else null, C1, _ptr(w), _ptr(bias) if bias is not None else null,
                 _ptr(y1), _ptr(y2) if y2 is not None else null, Co1, _ptr(act) if act is not None else null,
-                B, Ci, Co, P, 1 if transpose_w else 0, 1 if accumulate else 0, 1 if act_in else 0,
+                B, Ci, Co, *size, 1 if transpose_w else 0, acc_flag, 1 if act_in else 0,
                 _ptr(dgelu_of) if dgelu_of is not None else null,
                 _ptr(pw) if pw is not None else null, _ptr(pb) if pb is not None else null, _ptr(proj) if proj is not None else null,
                 _stream(x1))
@@ -610,15 +639,20 @@ def channel_wgrad_finish(parts, Ci: int, Co: int, need_bias: bool, out_w=None, o
 
 
 def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False, out_w=None, out_b=None, accumulate: bool = False,
-                   partials_out=None):
+                   partials_out=None, window=None):
     """gy (B, Co, P), x1 (B, C1, P), x2 (B, C2, P) or None -> gw (Co, C1 + C2), gb (Co) or None: the weight gradient of a
     (two-source) layer from one launch (act_x: x1 := gelu(x1) as it is read).  out_w / out_b: write (accumulate: add) into these
     float32 tensors of Co * Ci / Co elements instead of fresh ones (out_b is required with need_bias when out_w is given).
     partials_out: a dense float32 tensor of channel_wgrad_partial_floats() elements - the first stage only, its partial sums left
-    there for channel_wgrad_finish (-> None, None)."""
+    there for channel_wgrad_finish (-> None, None).
+    window = (rows, cols, pitch): the sums run over that window of the tensors' planes (uno_channel_wgrad2_win, see channel_mix2)."""
     bf16 = _act_dtype(gy, "grad_output")
     _require(x1, gy.dtype, "x1")
     B, Co, P = gy.shape
+    if window is not None:
+        if partials_out is not None:
+            raise RuntimeError("uno_amd: windowed weight gradients run both stages")
+        win = _window_args(window, P, bf16)
     C1 = x1.shape[1]
     C2 = 0
     if x2 is not None:
@@ -652,10 +686,13 @@ def channel_wgrad2(gy, x1, x2, need_bias: bool = True, act_x: bool = False, out_
         if gb is not None:
             _require(gb, torch.float32, "bias-gradient buffer")
     with torch.cuda.device(gy.device):
-        ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, P)), dtype=torch.uint8, device=gy.device)
-        fn = L.uno_channel_wgrad2_bf16 if bf16 else L.uno_channel_wgrad2
+        if window is not None:
+            fn, size, Pl = L.uno_channel_wgrad2_win, (*win, P), win[0] * win[1]
+        else:
+            fn, size, Pl = (L.uno_channel_wgrad2_bf16 if bf16 else L.uno_channel_wgrad2), (P,), P
+        ws = torch.empty(max(1, L.uno_channel_wgrad_ws_bytes(B, Ci, Co, Pl)), dtype=torch.uint8, device=gy.device)
         rc = fn(_ptr(gy), _ptr(x1), _ptr(x2) if x2 is not None else C.c_void_p(0), C1, _ptr(gw), _ptr(gb) if gb is not None else C.c_void_p(0),
-                _ptr(ws), B, Ci, Co, P, 1 if act_x else 0, 1 if accumulate else 0, _stream(gy))
+                _ptr(ws), B, Ci, Co, *size, 1 if act_x else 0, 1 if accumulate else 0, _stream(gy))
     _check(rc, "uno_channel_wgrad2")
     return gw, gb
 
@@ -712,8 +749,8 @@ def gelu_project_forward(pre, w, bias=None):
     return out
 
 
-def gelu_project_backward(pre, w, gout, need_bias=True):
-    """-> gpre (B, C, P), gw (C,), gb (1,) or None."""
+def gelu_project_backward(pre, w, gout, need_bias=True, window=None):
+    """-> gpre (B, C, P), gw (C,), gb (1,) or None.  window = (rows, cols, pitch): on that window of the planes (see channel_mix2)."""
     bf16 = _act_dtype(pre, "pre")
     _require(w, torch.float32, "weight")
     _require(gout, pre.dtype, "grad_output")
@@ -725,9 +762,14 @@ def gelu_project_backward(pre, w, gout, need_bias=True):
     gw = torch.empty((Cc,), dtype=torch.float32, device=pre.device)
     gb = torch.empty((1,), dtype=torch.float32, device=pre.device) if need_bias else None
     with torch.cuda.device(pre.device):
-        ws = torch.empty(max(1, L.uno_gelu_project_bwd_ws_bytes(B, Cc, P)), dtype=torch.uint8, device=pre.device)
-        rc = (L.uno_gelu_project_backward_bf16 if bf16 else L.uno_gelu_project_backward)(_ptr(pre), _ptr(w), _ptr(gout), _ptr(gpre), _ptr(gw),
-                                         _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws), B, Cc, P, _stream(pre))
+        if window is not None:
+            win = _window_args(window, P, bf16)
+            fn, size, Pl = L.uno_gelu_project_backward_win, (*win, P), win[0] * win[1]
+        else:
+            fn, size, Pl = (L.uno_gelu_project_backward_bf16 if bf16 else L.uno_gelu_project_backward), (P,), P
+        ws = torch.empty(max(1, L.uno_gelu_project_bwd_ws_bytes(B, Cc, Pl)), dtype=torch.uint8, device=pre.device)
+        rc = fn(_ptr(pre), _ptr(w), _ptr(gout), _ptr(gpre), _ptr(gw), _ptr(gb) if need_bias else C.c_void_p(0), _ptr(ws), B, Cc, *size,
+                _stream(pre))
     _check(rc, "uno_gelu_project_backward")
     return gpre, gw, gb
 

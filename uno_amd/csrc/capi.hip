@@ -406,7 +406,8 @@ int uno_channel_mix_bf16(const void* x, const float* w, const float* bias, void*
 
 static int channel_mix2_impl(const void* x1, const void* x2, int C1, const float* w, const float* bias, void* y1, void* y2, int Co1,
                              void* y_act, int B, int Ci, int Co, long long P, int transpose_w, int accumulate, int act_in,
-                             const void* dgelu_of, const float* proj_w, const float* proj_b, void* proj_out, int bf16, void* stream) {
+                             const void* dgelu_of, const float* proj_w, const float* proj_b, void* proj_out, int bf16, void* stream,
+                             const PixelWindow& win = PixelWindow()) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (B == 0 || P == 0) return 0;
     if (!x1 || !w || !y1) { set_error("uno_channel_mix2: null pointer"); return -1; }
@@ -415,6 +416,7 @@ static int channel_mix2_impl(const void* x1, const void* x2, int C1, const float
     a.B = B; a.Ci = Ci; a.Co = Co; a.C1 = x2 ? C1 : Ci; a.Co1 = y2 ? Co1 : Co; a.P = P;
     a.transpose_w = transpose_w; a.accumulate = accumulate; a.act_in = act_in; a.bf16 = bf16;
     a.proj_w = proj_w; a.proj_b = proj_b; a.proj_out = proj_out;
+    a.win = win;
     return launch_channel_mix2(a, (hipStream_t)stream);
 }
 
@@ -430,6 +432,24 @@ int uno_channel_mix2_bf16(const void* x1, const void* x2, int C1, const float* w
                           const void* dgelu_of, const float* proj_w, const float* proj_b, void* proj_out, void* stream) {
     return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of,
                              proj_w, proj_b, proj_out, 1, stream);
+}
+
+// the pixel axis of a *_win call: rows x cols logical pixels, row r at r * pitch of a channel plane, planes `plane` elements apart
+static bool make_window(const char* who, int rows, int cols, int pitch, long long plane, PixelWindow* win, long long* P) {
+    if (rows < 1 || cols < 1 || pitch < cols || plane < 1) { set_error("%s: bad window rows=%d cols=%d pitch=%d plane=%lld", who, rows, cols, pitch, plane); return false; }
+    win->plane = plane; win->cols = cols; win->pitch = pitch;
+    *P = (long long)rows * cols;
+    return true;
+}
+
+int uno_channel_mix2_win(const float* x1, const float* x2, int C1, const float* w, const float* bias, float* y1, float* y2, int Co1,
+                         float* y_act, int B, int Ci, int Co, int rows, int cols, int pitch, long long plane, int transpose_w,
+                         int accumulate, int act_in, const float* dgelu_of, const float* proj_w, const float* proj_b, float* proj_out,
+                         void* stream) {
+    PixelWindow win; long long P;
+    if (!make_window("uno_channel_mix2_win", rows, cols, pitch, plane, &win, &P)) return -1;
+    return channel_mix2_impl(x1, x2, C1, w, bias, y1, y2, Co1, y_act, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of,
+                             proj_w, proj_b, proj_out, 0, stream, win);
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
@@ -461,7 +481,7 @@ int uno_channel_wgrad_bf16(const void* gy, const void* x, float* gw, float* gb, 
 }
 
 static int channel_wgrad2_impl(const void* gy, const void* x1, const void* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci,
-                               int Co, long long P, int act_x, int accumulate, int bf16, void* stream) {
+                               int Co, long long P, int act_x, int accumulate, int bf16, void* stream, const PixelWindow& win = PixelWindow()) {
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_wgrad2: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (accumulate < 0 || accumulate > 3 || accumulate == 2) { set_error("uno_channel_wgrad2: accumulate is 0, 1 or 3 (got %d)", accumulate); return -1; }
     if (!gw && accumulate != 3) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
@@ -477,7 +497,14 @@ static int channel_wgrad2_impl(const void* gy, const void* x1, const void* x2, i
         return 0;
     }
     if (!gy || !x1 || !ws) { set_error("uno_channel_wgrad2: null pointer"); return -1; }
-    return launch_channel_wgrad2(gy, x1, x2, x2 ? C1 : Ci, gw, gb, (float*)ws, B, Ci, Co, P, act_x, accumulate, bf16, (hipStream_t)stream);
+    return launch_channel_wgrad2(gy, x1, x2, x2 ? C1 : Ci, gw, gb, (float*)ws, B, Ci, Co, P, act_x, accumulate, bf16, (hipStream_t)stream, win);
+}
+
+int uno_channel_wgrad2_win(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
+                           int rows, int cols, int pitch, long long plane, int act_x, int accumulate, void* stream) {
+    PixelWindow win; long long P;
+    if (!make_window("uno_channel_wgrad2_win", rows, cols, pitch, plane, &win, &P)) return -1;
+    return channel_wgrad2_impl(gy, x1, x2, C1, gw, gb, ws, B, Ci, Co, P, act_x, accumulate, 0, stream, win);
 }
 
 int uno_channel_wgrad2(const float* gy, const float* x1, const float* x2, int C1, float* gw, float* gb, void* ws, int B, int Ci, int Co,
@@ -563,7 +590,7 @@ long long uno_gelu_project_bwd_ws_bytes(int B, int C, long long P) {
 }
 
 static int gelu_project_backward_impl(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, void* ws, int B,
-                                      int C, long long P, int bf16, void* stream) {
+                                      int C, long long P, int bf16, void* stream, const PixelWindow& win = PixelWindow()) {
     if (B < 0 || C < 1 || P < 0) { set_error("uno_gelu_project_backward: bad sizes B=%d C=%d P=%lld", B, C, P); return -1; }
     if (!gw) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
     if (B == 0 || P == 0) {
@@ -572,7 +599,14 @@ static int gelu_project_backward_impl(const void* pre, const float* w, const voi
         return 0;
     }
     if (!pre || !w || !gout || !gpre || !ws) { set_error("uno_gelu_project_backward: null pointer"); return -1; }
-    return launch_gelu_project_bwd(pre, w, gout, gpre, gw, gb, (float*)ws, B, C, P, bf16, (hipStream_t)stream);
+    return launch_gelu_project_bwd(pre, w, gout, gpre, gw, gb, (float*)ws, B, C, P, bf16, (hipStream_t)stream, win);
+}
+
+int uno_gelu_project_backward_win(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws, int B,
+                                  int C, int rows, int cols, int pitch, long long plane, void* stream) {
+    PixelWindow win; long long P;
+    if (!make_window("uno_gelu_project_backward_win", rows, cols, pitch, plane, &win, &P)) return -1;
+    return gelu_project_backward_impl(pre, w, gout, gpre, gw, gb, ws, B, C, P, 0, stream, win);
 }
 
 int uno_gelu_project_backward(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws, int B,

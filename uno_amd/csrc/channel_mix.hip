@@ -25,9 +25,9 @@ constexpr int CM_WS = CM_MT + 16;   // LDS row stride of the W chunk  [KC][MT] (
 // one unconditional 16-byte load from a clamped address, then a select network (no branches -> the load
 // stays in flight across the MFMA block)
 template <typename T>
-__device__ __forceinline__ float4 load4_tail(const T* row, int px, int P) {
+__device__ __forceinline__ float4 load4_tail(const T* row, int px, int P, const PixRun& run = PixRun{0, 0x7fffffff, 0}) {
     const int pc = min(px, P - 4);
-    const float4 v = io_ld4(row + pc);
+    const float4 v = io_ld4(row + run(pc));
     const int sh = px - pc;
     float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
     if (sh & 1) { t0 = t1; t1 = t2; t2 = t3; t3 = 0.f; }
@@ -58,6 +58,7 @@ struct ChannelMixParams {
     const float* proj_b;    // models' final `fc2(F.gelu(fc1(x)))` with one output channel (darcy_flow_uno2d.py:128-131) without
     void* proj_out;         // re-reading y; needs all output channels in ONE 64-channel tile (Co <= 64)
     int B, Ci, Co, P;
+    PixMap pm;              // plane stride of every operand + the pixel window (dense: pm.PS == P); generic and split kernels only
     int C1, Co1;
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
@@ -74,8 +75,8 @@ template <typename T>
 struct CmDest { T* base; int ob; };
 template <typename T>
 __device__ __forceinline__ CmDest<T> cm_dest(const ChannelMixParams& p, int o0, int b) {
-    if (o0 >= p.Co1) return {reinterpret_cast<T*>(p.y2) + (size_t)b * (p.Co - p.Co1) * p.P, p.Co1};
-    return {reinterpret_cast<T*>(p.y) + (size_t)b * p.Co1 * p.P, 0};
+    if (o0 >= p.Co1) return {reinterpret_cast<T*>(p.y2) + (size_t)b * (p.Co - p.Co1) * p.pm.PS, p.Co1};
+    return {reinterpret_cast<T*>(p.y) + (size_t)b * p.Co1 * p.pm.PS, 0};
 }
 
 // MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
@@ -92,13 +93,15 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     using T = typename IoElem<BF>::type;                // float | unsigned short (bf16 bits)
     const int C1 = p.C1;
-    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;                        // channels [0, C1)
-    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;  // channels [C1, Ci), row ci - C1
+    const int PS = p.pm.PS;                      // elements between two channel planes (== P without a window)
+    const PixRun run = pix_run(p.pm, p0);        // logical pixel of this tile -> offset inside its plane
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * PS;                        // channels [0, C1)
+    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * PS : xb;  // channels [C1, Ci), row ci - C1
     const CmDest<T> dd = cm_dest<T>(p, o0, b);
     T* const ydst = dd.base;                     // row o of this tile: ydst + (o - dd.ob) * P
     const bool dg = DG && o0 < p.Co1;            // gelu' factor: first destination only
-    const T* const dall = DG ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * p.P : nullptr;
-    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
+    const T* const dall = DG ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * PS : nullptr;
+    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * PS : nullptr;
     bool act_ld = ACT;                           // the chunk in the staging registers comes from the activated source
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
@@ -115,7 +118,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                rx[u] = io_ld4(cb + (unsigned)((kb + (e / F4R)) * p.P + p0 + (e % F4R) * 4));
+                rx[u] = io_ld4(cb + (unsigned)((kb + (e / F4R)) * PS + run(p0 + (e % F4R) * 4)));
             }
             // W chunk as ONE 16-byte load per thread along whichever index is contiguous in memory (4 dword loads
             // per thread made W the most numerous vector-memory instruction of the tile; the address unit was the
@@ -133,7 +136,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
                 const int ci = k0 + (e / F4R), cc = min(ci, p.Ci - 1);
-                float4 v = load4_tail(cc < C1 ? xb + (size_t)cc * p.P : xb2 + (size_t)(cc - C1) * p.P, p0 + (e % F4R) * 4, p.P);
+                float4 v = load4_tail(cc < C1 ? xb + (size_t)cc * PS : xb2 + (size_t)(cc - C1) * PS, p0 + (e % F4R) * 4, p.P, run);
                 if (ci >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 rx[u] = v;
             }
@@ -144,7 +147,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             for (int u = 0; u < PT / 16; ++u) {
                 const int e = tid + 256 * u;
                 const int ci = k0 + e / PT, pp = p0 + e % PT;
-                r[u] = (ci < p.Ci && pp < p.P) ? io_widen(ci < C1 ? xb[(size_t)ci * p.P + pp] : xb2[(size_t)(ci - C1) * p.P + pp]) : 0.f;
+                r[u] = (ci < p.Ci && pp < p.P) ? io_widen(ci < C1 ? xb[(size_t)ci * PS + run(pp)] : xb2[(size_t)(ci - C1) * PS + run(pp)]) : 0.f;
             }
         }
 #pragma unroll
@@ -240,9 +243,9 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
-                const size_t off = (size_t)(o - dd.ob) * p.P + p0 + c4;
+                const size_t off = (size_t)(o - dd.ob) * PS + run(p0 + c4);
                 dst[it] = ydst + off;
-                aoff[it] = (size_t)o * p.P + p0 + c4;
+                aoff[it] = (size_t)o * PS + run(p0 + c4);
                 if (p.accumulate) old[it] = io_ld4(dst[it]);
                 else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (DG) { if (dg) pre[it] = io_ld4(dall + off); else pre[it] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -287,7 +290,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 float r4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) r4[i] = pb + (((sP[c4 + i] + sP[PT + c4 + i]) + sP[2 * PT + c4 + i]) + sP[3 * PT + c4 + i]);
-                io_store4(reinterpret_cast<T*>(p.proj_out) + (size_t)b * p.P + p0 + c4, r4[0], r4[1], r4[2], r4[3]);
+                io_store4(reinterpret_cast<T*>(p.proj_out) + (size_t)b * PS + run(p0 + c4), r4[0], r4[1], r4[2], r4[3]);
             }
         }
         return;
@@ -301,16 +304,16 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     if (MODE == 2 || o < p.Co) {
         const float bv = p.bias ? p.bias[o] : 0.f;
         const float pwv = p.proj_w ? p.proj_w[o] : 0.f;
-        T* yrow = ydst + (size_t)(o - dd.ob) * p.P;
-        T* arow = aall ? aall + (size_t)o * p.P : nullptr;
+        T* yrow = ydst + (size_t)(o - dd.ob) * PS;
+        T* arow = aall ? aall + (size_t)o * PS : nullptr;
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
-            const int px = p0 + 16 * mt + 4 * kk;
-            const T* drow = dg ? dall + (size_t)(o - dd.ob) * p.P : nullptr;
+            const int px = p0 + 16 * mt + 4 * kk, fx = run(px);        // logical pixel (guards), offset inside the plane
+            const T* drow = dg ? dall + (size_t)(o - dd.ob) * PS : nullptr;
             if (MODE == 2 || px + 3 < p.P) {
                 float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), pre = o4;
-                if (p.accumulate) o4 = io_ld4(yrow + px);
-                if constexpr (DG) { if (dg) pre = io_ld4(drow + px); }
+                if (p.accumulate) o4 = io_ld4(yrow + fx);
+                if constexpr (DG) { if (dg) pre = io_ld4(drow + fx); }
                 float w4[4] = {o4.x, o4.y, o4.z, o4.w};
                 const float pr4[4] = {pre.x, pre.y, pre.z, pre.w};
 #pragma unroll
@@ -318,8 +321,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     const float d = dg ? cm_dgelu(pr4[r]) : 1.f;
                     w4[r] = p.accumulate == 2 ? (w4[r] + (acc[mt][r] + bv)) * d : w4[r] + (acc[mt][r] + bv) * d;
                 }
-                io_store4(yrow + px, w4[0], w4[1], w4[2], w4[3]);
-                if (arow) io_store4(arow + px, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
+                io_store4(yrow + fx, w4[0], w4[1], w4[2], w4[3]);
+                if (arow) io_store4(arow + fx, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
                 if (p.proj_w) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pv[mt][r] = pwv * cm_gelu(w4[r]);
@@ -328,10 +331,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (px + r < p.P) {
-                        const float d = dg ? cm_dgelu(io_widen(drow[px + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[px + r]) : 0.f;
+                        const float d = dg ? cm_dgelu(io_widen(drow[fx + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[fx + r]) : 0.f;
                         const float v = p.accumulate == 2 ? (o1 + (acc[mt][r] + bv)) * d : o1 + (acc[mt][r] + bv) * d;
-                        io_store1(yrow + px + r, v);
-                        if (arow) io_store1(arow + px + r, cm_gelu(v));
+                        io_store1(yrow + fx + r, v);
+                        if (arow) io_store1(arow + fx + r, cm_gelu(v));
                         if (p.proj_w) pv[mt][r] = pwv * cm_gelu(v);
                     }
             }
@@ -353,7 +356,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         const float pb = p.proj_b ? p.proj_b[0] : 0.f;
         for (int e = tid; e < PT; e += 256)
             if (p0 + e < p.P)
-                io_store1(reinterpret_cast<T*>(p.proj_out) + (size_t)b * p.P + p0 + e, pb + (((sP[e] + sP[PT + e]) + sP[2 * PT + e]) + sP[3 * PT + e]));
+                io_store1(reinterpret_cast<T*>(p.proj_out) + (size_t)b * PS + run(p0 + e), pb + (((sP[e] + sP[PT + e]) + sP[2 * PT + e]) + sP[3 * PT + e]));
     }
 }
 
@@ -596,8 +599,13 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     const int wa = wave & 1, wb = wave >> 1;
     const int wpx = CT == 128 ? 64 * wa : 32 * wave, wch = CT == 128 ? 64 * wb : 0;      // this wave's first pixel / channel inside the tile
     const int C1 = p.C1;
-    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;
-    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;
+    const int PS = p.pm.PS;
+    const PixRun run = pix_run(p.pm, p0);
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * PS;
+    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * PS : xb;
+    unsigned xoff[4];                                    // a thread's four staged pieces: channel row e >> 5 of the chunk, pixels 4 (e & 31) ..
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; xoff[u] = (unsigned)((e >> 5) * PS + run(p0 + (e & 31) * 4)); }
 
     float4 rx[4], rw[4];
     bool act_ld = false;                                 // (uniform) the chunk in the registers belongs to the first source
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u;
-            if constexpr (!(XP & 4)) rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+            if constexpr (!(XP & 4)) rx[u] = io_ld4(cb + ((unsigned)(kb * PS) + xoff[u]));
             else rx[u] = make_float4(1.f, 2.f, 3.f, 4.f);
             if constexpr ((XP & 2) != 0) { rw[u] = make_float4(1.f, 2.f, 3.f, 4.f); continue; }
             if (CT == 64 && u >= 2) continue;             // 64 channels x 32 k = 512 float4: the first two rounds
@@ -750,12 +758,12 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     float* sO = reinterpret_cast<float*>(smem) + wave * (16 * OS);
     const int c4 = (lane & (LPR - 1)) * 4;
     const CmDest<T> dd = cm_dest<T>(p, o0, b);          // a tile lies in one destination (Co1 % CT == 0)
-    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
+    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * PS : nullptr;
     float bias_l[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bias_l[t] = p.bias ? p.bias[o0 + wch + 16 * t + r16] : 0.f;
     // gelu' of the saved pre-activation: first destination only (o0 < Co1: the whole tile or nothing)
-    const T* const dall = (p.dgelu_of && o0 < p.Co1) ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * p.P : nullptr;
+    const T* const dall = (p.dgelu_of && o0 < p.Co1) ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * PS : nullptr;
     if constexpr (CT == 64) {
         // fused projection fc2(gelu(y)) with one output channel (Co = 64: the wave holds all channels of its 32 pixels): per lane the
         // sum over its four channel tiles, then over the 16 lanes of a k-group (fixed butterfly order), four consecutive pixels per store
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
                     sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
                     ps[r] = sum + pb;
                 }
-                if (r16 == 0) io_store4(reinterpret_cast<T*>(p.proj_out) + (size_t)b * p.P + p0 + wpx + 16 * m + 4 * kk, ps[0], ps[1], ps[2], ps[3]);
+                if (r16 == 0) io_store4(reinterpret_cast<T*>(p.proj_out) + (size_t)b * PS + run(p0 + wpx + 16 * m + 4 * kk), ps[0], ps[1], ps[2], ps[3]);
             }
         }
     }
@@ -795,8 +803,8 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int o = ob + RPI * it + lane / LPR;
-            dst[it] = dd.base + (size_t)(o - dd.ob) * p.P + p0 + wpx + c4;
-            aoff[it] = (size_t)o * p.P + p0 + wpx + c4;
+            dst[it] = dd.base + (size_t)(o - dd.ob) * PS + run(p0 + wpx + c4);
+            aoff[it] = (size_t)o * PS + run(p0 + wpx + c4);
             if (p.accumulate) old[it] = io_ld4(dst[it]);
             else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (dall) pre[it] = io_ld4(dall + aoff[it]);        // (first destination: channel index o, Co1 rows per batch entry)
@@ -889,6 +897,10 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         return -2;
     }
     p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P;
+    const bool windowed = a.win.cols != 0;
+    if (const char* why = pix_window_error(a.win, P)) { set_error("channel_mix: %s", why); return -2; }
+    p.pm = pix_map(a.win, P);
+    const long long PSl = windowed ? a.win.plane : P;            // elements between two channel planes
     p.C1 = two_src ? a.C1 : Ci;
     p.Co1 = two_dst ? a.Co1 : Co;
     // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
@@ -898,7 +910,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const int act_in = a.act_in;
     const void* dgelu_of = a.dgelu_of;
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
-    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0);
+    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0) && !windowed;      // (the wide and few-input kernels are dense only)
     // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
 #ifdef UNO_CMS_DEV        // development build only (tools/dev/mkvariant.py): A/B switch, knock-outs, stamp buffer from the environment
     static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;
@@ -928,13 +940,13 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     }
     if (a.y_act && (two_dst || dgelu_of)) { set_error("channel_mix: the activated second output goes with a single destination and no dgelu_of"); return -2; }
     const long long npt = (P + PT - 1) / PT, ncot = (wide || split) ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
-    if ((long long)Ci * P >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
+    if ((long long)Ci * PSl >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
     const int accumulate = p.accumulate;
-    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024 && !two_src && !two_dst && !a.y_act && !a.proj_w) {
+    if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024 && !two_src && !two_dst && !a.y_act && !a.proj_w && !windowed) {
         ProfScope prof("uno::channel_mix_few_in_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
         const dim3 grid((unsigned)((P + 1023) / 1024), B);
 #define UNO_CMF(C) do { if (bf16) hipLaunchKernelGGL((channel_mix_few_in_kernel<C, true>), grid, dim3(256), 0, s, p); \
@@ -1009,6 +1021,7 @@ struct ChannelWgradParams {
     int C1;                 // == Ci without a second source
     float* part;            // (nsplit, Co, Ci + 1) partial sums; column Ci holds the bias gradient
     int B, Ci, Co, P, nsplit;
+    PixMap pm;              // plane stride + pixel window of gy, x and x2 (vector and split kernels; dense: pm.PS == P)
     int act_x;              // scalar kernel: x := gelu(x)
     long long span;         // pixels per split (informational)
 };
@@ -1136,22 +1149,24 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     const bool actx = ACTX && !src2;
     auto load_chunk = [&](int idx) {
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK;
-        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (size_t)b * Cs * p.P), 0, Cs * p.P * ES, 0x00020000);
-        const int px = pp + c4, pc = min(px, p.P - 4);
-        sh_cur = px - pc;
+        const int PS = p.pm.PS;
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * PS), 0, p.Co * PS * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (size_t)b * Cs * PS), 0, Cs * PS * ES, 0x00020000);
+        const int px = pp + c4, pl = min(px, p.P - 4);
+        sh_cur = px - pl;
+        const int pc = pix_run(p.pm, pp)(pl);            // offset of the piece inside its channel plane
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
             if constexpr (BF) {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 tg = __builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 2, 0, 0);
-                const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(il + row, Cs - 1) * p.P + pc) * 2, 0, 0);
+                const u32x2 tg = __builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row, p.Co - 1) * PS + pc) * 2, 0, 0);
+                const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(il + row, Cs - 1) * PS + pc) * 2, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x << 16), __uint_as_float(tg.x & 0xffff0000u), __uint_as_float(tg.y << 16), __uint_as_float(tg.y & 0xffff0000u));
                 rxv[u] = make_float4(__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u), __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u));
             } else {
-                const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * p.P + pc) * 4, 0, 0);
-                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(il + row, Cs - 1) * p.P + pc) * 4, 0, 0);
+                const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * PS + pc) * 4, 0, 0);
+                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(il + row, Cs - 1) * PS + pc) * 4, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
                 rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
             }
@@ -1304,21 +1319,23 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur, bool& tail) {     // half chunk it: 32 pixels of chunk it >> 1
         const int idx = it >> 1;
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
-        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * p.P), 0, p.Co * p.P * ES, 0x00020000);
+        const int PS = p.pm.PS;
+        const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.gy) + (size_t)b * p.Co * PS), 0, p.Co * PS * ES, 0x00020000);
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         auto raw2 = [](const u32x2& t) { return u32x4{t.x, t.y, 0u, 0u}; };
-        const int px = pp + c4, pc = min(px, p.P - 4);
-        sh_cur = px - pc;
+        const int px = pp + c4, pl = min(px, p.P - 4);
+        sh_cur = px - pl;
         tail = pp + CWS_PK > p.P;
+        const int pc = pix_run(p.pm, pp)(pl);            // offset of the piece inside its channel plane
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * p.P), 0, xcs[u] * p.P * ES, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * PS), 0, xcs[u] * PS * ES, 0x00020000);
             if constexpr (BF) {
-                if (u < MR) rg[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 2, 0, 0));
-                rxv[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * p.P + pc) * 2, 0, 0));
+                if (u < MR) rg[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * PS + pc) * 2, 0, 0));
+                rxv[u] = raw2(__builtin_amdgcn_raw_buffer_load_b64(rx_, (xrow[u] * PS + pc) * 2, 0, 0));
             } else {
-                if (u < MR) rg[u] = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * p.P + pc) * 4, 0, 0);
-                rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * p.P + pc) * 4, 0, 0);
+                if (u < MR) rg[u] = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row0 + 32 * u, p.Co - 1) * PS + pc) * 4, 0, 0);
+                rxv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (xrow[u] * PS + pc) * 4, 0, 0);
             }
         }
     };
@@ -1611,8 +1628,11 @@ int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, fl
 }
 
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
-                          long long P, int act_x, int accumulate, int bf16, hipStream_t s) {
-    if ((long long)(Ci > Co ? Ci : Co) * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
+                          long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win) {
+    const bool windowed = win.cols != 0;
+    if (const char* why = pix_window_error(win, P)) { set_error("channel_wgrad: %s", why); return -2; }
+    const long long PSl = windowed ? win.plane : P;
+    if ((long long)(Ci > Co ? Ci : Co) * PSl >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
         set_error("channel_wgrad: tensor too large (channels * pixels must stay below 2^29)");
         return -2;
     }
@@ -1622,8 +1642,10 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
     }
     ChannelWgradParams p;
     p.gy = gy; p.x = x; p.x2 = x2; p.C1 = x2 ? C1 : Ci; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = act_x ? 1 : 0;
+    p.pm = pix_map(win, P);
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
+    if (windowed && (pk != CWV_PK || (Ci <= 4 && !act_x))) { set_error("channel_wgrad: the pixel window goes with the vector / split kernels (>= 64 pixels, > 4 input channels)"); return -2; }
     p.span = (long long)cps * pk;
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
     if (Ci <= 4 && !act_x && P >= 1024) {

@@ -298,9 +298,13 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
                         void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, int bf16, hipStream_t s) {
     typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
-    // with the GELU derivative (erf + exp per element) the compiler keeps the held values in registers only up to 8 quads per
-    // thread (13: 40 spilled registers, 25: 344): longer rows take the sweep kernel there
-    if (const int rq = (N >= 4 ? instnorm_reg_quads(N, gelu ? 8 : 25) : 0)) {
+    // (rounds 3-4 kept the GELU form to 8 quads per thread: with the library erff - a branching piecewise form - the compiler
+    // spilled 40 registers at 13 quads and 344 at 25; with the branch-free uno_erf every size fits: 255 registers, no spills, at 25.
+    // The 128-channel 223^2 level of the Darcy model - rows of 49 729 floats - left the sweep kernel, which read x and gy twice.)
+#ifndef UNO_IN_GELU_Q
+#define UNO_IN_GELU_Q 25
+#endif
+    if (const int rq = (N >= 4 ? instnorm_reg_quads(N, gelu ? UNO_IN_GELU_Q : 25) : 0)) {
         ProfScope prof("uno::instnorm_bwd_reg_kernel", (bf16 ? 6.0 : 12.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
 #define UNO_IN_BWD(G, TT, Q) hipLaunchKernelGGL((instnorm_bwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, (const TT*)gy, gamma, beta, mean, rstd, (TT*)gx, s1, s2, C, (int)N)

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restrict__ pre, const float* __restrict__ w,
                                                                const T* __restrict__ gout, T* __restrict__ gpre,
-                                                               float* __restrict__ part, int C, int P, int Cs) {
+                                                               float* __restrict__ part, int C, int P, int Cs, PixMap pm) {
+    // pm: pixel window (uno_common.h) - pre, gout (one plane per batch entry) and gpre on one window; dense: pm.PS == P
     // blockIdx.z = channel split: channels [z Cs, min(C, (z + 1) Cs)); small tensors (one-wave workgroups) are split over
     // channels as well, so that the chip sees 4x the waves (a 64 x 64 grid at batch 32 gave 512 waves walking 128 channels each)
     __shared__ float sw[GP_MAXC];
@@ -126,9 +127,12 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = px < P;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) load4_guard(gout + (size_t)b * P, px, P, g);
-    const T* src = pre + (size_t)b * C * P;
-    T* dst = gpre + (size_t)b * C * P;
+    // a windowed call has whole quads only (P = rows * cols, cols % 4 == 0): shifting the row pointer by (offset in the plane - px)
+    // leaves the guards in logical pixels
+    const int PS = pm.PS, fx = live ? pix_phys(pm, px) - px : 0;
+    if (live) load4_guard(gout + (size_t)b * PS + fx, px, P, g);
+    const T* src = pre + (size_t)b * C * PS + fx;
+    T* dst = gpre + (size_t)b * C * PS + fx;
     float* mine = swave + wave * (C + 1);
     auto wave_sum = [&](float s, int slot) {
 #pragma unroll
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restri
         float s = 0.f;
         if (live) {
             float v[4], o[4];
-            load4_guard(src + (size_t)c * P, px, P, v);
+            load4_guard(src + (size_t)c * PS, px, P, v);
             const float wc = sw[c];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restri
                 o[i] = fmaf(v[i], pdf, cdf) * (wc * g[i]);
                 s = fmaf(g[i], v[i] * cdf, s);              // g is zero past the row end
             }
-            store4_guard(dst + (size_t)c * P, px, P, o);
+            store4_guard(dst + (size_t)c * PS, px, P, o);
         }
         wave_sum(s, c);
     }
@@ -217,17 +221,20 @@ long long gelu_project_ws_floats(int B, int C, long long P) {
 }
 
 int launch_gelu_project_bwd(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, float* ws, int B,
-                            int C, long long P, int bf16, hipStream_t s) {
+                            int C, long long P, int bf16, hipStream_t s, const PixelWindow& win) {
     typedef unsigned short bf_t;
     if (C > GP_MAXC || P > 0x7fffffffLL || B > 65535) { set_error("gelu_project: C <= %d, pixels < 2^31, batch < 65536", GP_MAXC); return -2; }
+    if (const char* why = pix_window_error(win, P)) { set_error("gelu_project: %s", why); return -2; }
+    if (win.cols && (long long)C * win.plane > 0x7fffffffLL) { set_error("gelu_project: window planes too large"); return -2; }
+    const PixMap pm = pix_map(win, P);
     const int threads = gelu_project_threads(B, P);
     const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     const int nsplit = gelu_project_splits(B, C, P), Cs = (C + nsplit - 1) / nsplit;
     {
         ProfScope prof("uno::gelu_project_bwd_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (2 * C + 1), s);
         const size_t lds = (threads / 64) * (C + 1) * sizeof(float);
-        if (bf16) hipLaunchKernelGGL(gelu_project_bwd_kernel<bf_t>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const bf_t*)pre, w, (const bf_t*)gout, (bf_t*)gpre, ws, C, (int)P, Cs);
-        else hipLaunchKernelGGL(gelu_project_bwd_kernel<float>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const float*)pre, w, (const float*)gout, (float*)gpre, ws, C, (int)P, Cs);
+        if (bf16) hipLaunchKernelGGL(gelu_project_bwd_kernel<bf_t>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const bf_t*)pre, w, (const bf_t*)gout, (bf_t*)gpre, ws, C, (int)P, Cs, pm);
+        else hipLaunchKernelGGL(gelu_project_bwd_kernel<float>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const float*)pre, w, (const float*)gout, (float*)gpre, ws, C, (int)P, Cs, pm);
     }
     hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B), Cs);
     const hipError_t e = hipGetLastError();

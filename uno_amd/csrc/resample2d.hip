@@ -108,7 +108,13 @@ constexpr int RS_PD = 2;
 // wave's 64 columns): one load instruction (4 rows x 256 contiguous bytes) feeds four MFMAs.  The VALU form spent 16 v_fmac and
 // four LDS broadcast reads of the weights per loaded element - rocprofv3 on 446^2 -> 334^2: LDS 61 % busy, most of it those reads.
 template <bool ACCUM, int KT, typename T, bool MF>      // KT: compiled tap count of the column operator (>= KW; weights past KW are zero)
-__global__ __launch_bounds__(512) void resample_fused_kernel(const T* __restrict__ in, T* __restrict__ out,
+// Occupancy (round 5): at ~84 registers the plain form ran 5 waves per SIMD = TWO 7-wave workgroups per CU, each alternating between a
+// loading phase and a storing phase with 2 KB per wave in flight - 28 KB per CU, 3.0-3.3 TB/s on the down-sampling shapes.  Held to 64
+// registers (no spills in the plain forms with up to 12 taps) four workgroups fit: tools/rsbench.py 446 -> 223 306 -> 281 us,
+// 223 -> 111 160 -> 144, 334 -> 223 456 -> 410, the adjoints -5 .. -13 %.  The accumulating forms (16 old values per thread) spill at
+// 64 registers and lose 5-12 %: with up to 5 taps (the up-sampling calls) they fit 72 registers - 7 waves - without spills (-1 .. -6 %),
+// beyond that they keep the default, as does the plain form with 16 taps (11 spilled registers at 64).
+__global__ __launch_bounds__(512, (ACCUM ? (KT <= 5 ? 7 : 1) : (KT <= 12 ? 8 : 1))) void resample_fused_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
                                                              int H, int W, int Ho, int Wo, int n_img, int ntiles) {

@@ -49,6 +49,44 @@ __device__ __forceinline__ float uno_dgelu(float x) {
     return fmaf(x, pdf, cdf);
 }
 
+// ---- pixel windows (round 5).  The channel-mix / weight-gradient / GELU-projection calls see a (B, C, P) tensor whose pixel axis is
+// dense.  With a WINDOW the P = rows x cols logical pixels of a call are the top-left corner of a wider plane: logical pixel q lives
+// at element (q / cols) * pitch + q % cols of its channel plane and channel planes are `plane` elements apart (the 421 x 421 domain
+// inside the 446 x 446 padded grid of the Darcy model: fc1, its GELU and fc2 work on the domain only, reference
+// darcy_flow_uno2d.py:126-131 crops first).  cols is a multiple of 4 - a lane's four pixels never straddle a row; the columns
+// between the domain and the next multiple of 4 are processed like domain pixels (they exist: pitch >= cols) - and 260 <= cols,
+// rows * cols < 2^24: q / cols = (q * ceil(2^40 / cols)) >> 40 exactly, and any run of up to 256 pixels touches two rows at most.
+struct PixelWindow { long long plane = 0; int cols = 0, pitch = 0; };       // cols == 0: dense
+struct PixMap {             // kernel-side form: plane stride + the window (rl == 0: dense, PS == P)
+    int PS; int rl, skip; unsigned magic;
+};
+inline PixMap pix_map(const PixelWindow& w, long long P) {
+    if (!w.cols) return PixMap{(int)P, 0, 0, 0u};
+    return PixMap{(int)w.plane, w.cols, w.pitch - w.cols, (unsigned)(((1ULL << 40) + w.cols - 1) / (unsigned long long)w.cols)};
+}
+// nullptr, or why the window cannot be used with P logical pixels
+inline const char* pix_window_error(const PixelWindow& w, long long P) {
+    if (!w.cols) return nullptr;
+    if (w.cols % 4 || w.cols < 260 || w.pitch < w.cols) return "window: cols must be a multiple of 4, >= 260 and <= pitch";
+    if (P % w.cols || P >= (1LL << 24)) return "window: the pixel count must be rows * cols, below 2^24";
+    if (w.plane < (P / w.cols - 1) * (long long)w.pitch + w.cols || w.plane > 0x7fffffffLL) return "window: the plane does not hold rows * pitch elements";
+    return nullptr;
+}
+// physical offsets of a run of <= 256 logical pixels starting at the (wave-uniform) pixel q0
+struct PixRun {
+    int base, bound, skip;
+    __device__ __forceinline__ int operator()(int q) const { return q + base + (q >= bound ? skip : 0); }
+};
+__device__ __forceinline__ PixRun pix_run(const PixMap& m, int q0) {
+    if (m.rl == 0) return PixRun{0, 0x7fffffff, 0};
+    const int r = (int)(((unsigned long long)(unsigned)q0 * m.magic) >> 40);
+    return PixRun{r * m.skip, (r + 1) * m.rl, m.skip};
+}
+__device__ __forceinline__ int pix_phys(const PixMap& m, int q) {           // any lane-varying pixel
+    if (m.rl == 0) return q;
+    return q + (int)(((unsigned long long)(unsigned)q * m.magic) >> 40) * m.skip;
+}
+
 // idx, inc and lim are byte offsets into a float2 table of lim/8 entries; idx < lim, inc < lim.
 __device__ __forceinline__ unsigned wrap_add(unsigned idx, unsigned inc, unsigned lim) {
     unsigned t = idx + inc;
@@ -245,6 +283,7 @@ struct ChannelMixArgs {
     const void* x; const void* x2; const float* w; const float* bias; void* y; void* y2; void* y_act; const void* dgelu_of;
     const float* proj_w; const float* proj_b; void* proj_out;       // fused one-channel projection of gelu(y) (Co <= 64), or nullptr
     int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
+    PixelWindow win;                                                // all operands on one window (proj_out: one plane per batch entry)
 };
 int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s);
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
@@ -259,7 +298,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, int i
 int launch_gelu_project_fwd(const void* pre, const float* w, const float* bias, void* out, int B, int C, long long P, int bf16, hipStream_t s);
 long long gelu_project_ws_floats(int B, int C, long long P);
 int launch_gelu_project_bwd(const void* pre, const float* w, const void* gout, void* gpre, float* gw, float* gb, float* ws, int B,
-                            int C, long long P, int bf16, hipStream_t s);
+                            int C, long long P, int bf16, hipStream_t s, const PixelWindow& win = PixelWindow());
 int launch_gelu_pad(const void* s, const void* gy, void* out, int n_img, int H, int W, int Hp, int Wp, int backward, int bf16, hipStream_t st);
 int launch_transpose_batched(const float* in, float* out, int B, long long R, int C, long long ld_in, long long sb_in, long long ld_out,
                              long long sb_out, hipStream_t st);
@@ -271,7 +310,7 @@ long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nspli
 int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          int act_x, int bf16, hipStream_t s);
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
-                          long long P, int act_x, int accumulate, int bf16, hipStream_t s);
+                          long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win = PixelWindow());
 int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s);
 
 }  // namespace uno

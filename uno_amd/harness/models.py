@@ -78,8 +78,9 @@ class UNO_9(nn.Module):
             # reading the pre-activation tensor
             skip5 = [self.conv4(c2, d1 // 2, d2 // 2, join=j2), c0]
             # fc2(gelu(fc1(cat([gelu(conv5 pre), lifted])))): one forward kernel (the fc1 pass also reduces its 64 channels to the output)
+            # ... on the S1 x S2 domain only (the padding is cropped from the result: its points are never computed)
             out = channel_mix_cat_project([self.conv5.forward_cat(skip5, d1, d2, defer_gelu=True, defer_grad=jc), lifted], self.fc1.weight,
-                                          self.fc1.bias, self.fc2.weight, self.fc2.bias, gelu_first=True, defer_grad=jl)
+                                          self.fc1.bias, self.fc2.weight, self.fc2.bias, gelu_first=True, defer_grad=jl, crop=(S1, S2))
             return out[:, :, :S1, :S2].permute(0, 2, 3, 1).contiguous()
         else:
             c0 = self.conv0(lifted, d1 // 2, d2 // 2)

@@ -314,16 +314,20 @@ def _grad_targets(params):
     return out
 
 
-def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False, stack=None):
+def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False, stack=None, window=None):
     """Weight / bias gradient of a channel-mix layer (K9), written in place where the layer's leaf parameters allow it.
     leaves = (weight leaf, bias leaf or None) or None.  -> (gw or None shaped (Co, Ci), gb or None) to return to autograd.
     stack = (stack, slot) of the block's spectral layer when that is batching its weight gradient over the uses of the pass: the
-    second stage of this gradient is deferred to the last use as well (_stack_pointwise)."""
+    second stage of this gradient is deferred to the last use as well (_stack_pointwise).  window: see _native.channel_mix2."""
     if not (need_w or need_b):
         return None, None
     has_bias = need_b
     tg = None
     fused = x2 is None or (x1.shape[1] % 64 == 0 and gy.shape[2] >= 64)
+    if window is not None:
+        if not fused:
+            raise RuntimeError("uno_amd: a windowed two-source layer splits its sources at a multiple of 64 channels")
+        stack = None
     if stack is not None and fused and leaves is not None and need_w and (leaves[1] is not None) == has_bias and gy.dtype == torch.float32 \
             and all(isinstance(t, torch.Tensor) and t.is_leaf for t in leaves if t is not None):
         out = _stack_pointwise(stack, leaves, gy, x1, x2, has_bias, act_x)
@@ -333,10 +337,12 @@ def _wgrad_into(leaves, gy, x1, x2, need_w, need_b, act_x=False, stack=None):
         tg = _grad_targets([leaves[0]] + ([leaves[1]] if has_bias else []))        # committed: the call below writes them
     if tg is not None:
         _native.channel_wgrad2(gy, x1, x2, need_bias=has_bias, act_x=act_x, out_w=tg[0][0], out_b=tg[1][0] if has_bias else None,
-                               accumulate=tg[0][1])
+                               accumulate=tg[0][1], window=window)
         Co, Ci = gy.shape[1], x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
         gw = None if tg[0][2] is None else tg[0][2].view(Co, Ci)
         return gw, (tg[1][2] if has_bias else None)
+    if window is not None:
+        return _native.channel_wgrad2(gy, x1, x2, need_bias=has_bias, act_x=act_x, window=window)
     if x2 is None:
         return _native.channel_wgrad(gy, x1, need_bias=has_bias, act_x=act_x)
     return _mix2_wgrad(gy, x1, x2, has_bias, act_x=act_x)
@@ -704,7 +710,12 @@ class _ChannelMixCatFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, x1, x2, w, gy):
-        """(g1, g2, gw, gb) of y = W . cat([gelu](x1), x2) + b for the output gradient gy (shared with the fused-projection form)"""
+        """(g1, g2, gw, gb) of y = W . cat([gelu](x1), x2) + b for the output gradient gy (shared with the fused-projection form).
+        ctx.window (fused-projection form): gy is valid on that window of its planes only; the gradients come out as whole planes
+        with a cleared border."""
+        window = getattr(ctx, "window", None)
+        if window is not None:
+            return _ChannelMixCatFn._backward_window(ctx, x1, x2, w, gy, window)
         C1 = x1.shape[1]
         g1 = g2 = None
         if ctx.defer is not None and ctx.defer.owner and ctx.needs_input_grad[1]:     # owner still pending: its backward has not run yet
@@ -727,6 +738,43 @@ class _ChannelMixCatFn(torch.autograd.Function):
         gw, gb = _wgrad_into(ctx.leaves, gy, x1, x2, ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3], act_x=ctx.gelu_first)
         return g1, g2, gw, gb
 
+    @staticmethod
+    def _backward_window(ctx, x1, x2, w, gy, window):
+        rows, cols, pitch = window
+        C1 = x1.shape[1]
+        B, C2 = x2.shape[0], x2.shape[1]
+        dg = x1 if ctx.gelu_first else None
+
+        def cleared(g):
+            # what the windowed kernel did not write: the columns right of the window, the rows below it (a gradient's consumers -
+            # the transforms and resampling of the producing block - read whole planes)
+            v = g.view(g.shape[0], g.shape[1], -1, pitch)
+            if cols < pitch:
+                v[:, :, :rows, cols:].zero_()
+            v[:, :, rows:].zero_()
+            return g
+
+        g1 = g2 = None
+        deferred = ctx.defer is not None and ctx.defer.owner and ctx.needs_input_grad[1]
+        if deferred:
+            if ctx.needs_input_grad[0]:
+                g1 = cleared(_native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=dg, window=window))
+            w2 = w[:, C1:].contiguous()
+            # accumulates into the window of the other consumer's (whole-plane) gradient: nothing to clear
+            ctx.defer.pending.append((lambda out, dgo=None: _native.channel_mix(
+                gy, w2, None, transpose_w=True, out=out.view(B, C2, -1), dgelu_of=None if dgo is None else dgo.view(B, C2, -1),
+                dgelu_total=dgo is not None, window=window), True))
+        else:
+            if ctx.needs_input_grad[0]:
+                g1 = cleared(_native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=dg, window=window))
+            if ctx.needs_input_grad[1]:
+                g2 = cleared(_native.channel_mix(gy, w[:, C1:].contiguous(), None, transpose_w=True, window=window))
+                if ctx.defer is not None:        # the owner's backward came first after all
+                    g2 = ctx.defer.late(g2)
+        gw, gb = _wgrad_into(ctx.leaves, gy, x1, x2, ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3], act_x=ctx.gelu_first,
+                             window=window)
+        return g1, g2, gw, gb
+
 
 class _ChannelMixCatProjectFn(torch.autograd.Function):
     """out[b, p] = b2 + sum_o w2[o] gelu(y[b, o, p]),  y = W . cat([gelu](x1), x2) + b: the end of the models, `fc2(F.gelu(fc1(cat)))`
@@ -734,11 +782,12 @@ class _ChannelMixCatProjectFn(torch.autograd.Function):
     its GELU derivative is needed backward) also reduces its 64-channel tile to the projected value, so y is not read again."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, w2, b2, gelu_first, defer=None, leaves=None):
+    def forward(ctx, x1, x2, w, bias, w2, b2, gelu_first, defer=None, leaves=None, window=None):
         ctx.leaves = leaves
+        ctx.window = window
         x1, x2, w, w2 = _plain(x1), _plain(x2), _plain(w), _plain(w2)
         y, out = _native.channel_mix2(x1, x2, w, None if bias is None else _plain(bias), act_in=gelu_first,
-                                      project=(w2, None if b2 is None else _plain(b2)))
+                                      project=(w2, None if b2 is None else _plain(b2)), window=window)
         ctx.save_for_backward(x1, x2, w, y, w2)
         ctx.has_bias, ctx.has_b2 = bias is not None, b2 is not None
         ctx.gelu_first = gelu_first
@@ -749,23 +798,32 @@ class _ChannelMixCatProjectFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gout):
         x1, x2, w, y, w2 = ctx.saved_tensors
-        gy, gw2, gb2 = _native.gelu_project_backward(y, w2, _plain(gout), need_bias=ctx.has_b2)
+        gy, gw2, gb2 = _native.gelu_project_backward(y, w2, _plain(gout), need_bias=ctx.has_b2, window=ctx.window)
         g1, g2, gw, gb = _ChannelMixCatFn._backward(ctx, x1, x2, w, gy)
-        return g1, g2, gw, gb, gw2, gb2, None, None, None
+        return g1, g2, gw, gb, gw2, gb2, None, None, None, None
 
 
-def channel_mix_cat_project(xs, weight, bias, weight2, bias2, gelu_first: bool = False, defer_grad=None):
+def channel_mix_cat_project(xs, weight, bias, weight2, bias2, gelu_first: bool = False, defer_grad=None, crop=None):
     """gelu_project(channel_mix_cat(xs, weight, bias, gelu_first), weight2, bias2) - `fc2(F.gelu(fc1(torch.cat(xs, 1))))` of the
     models - as one forward kernel where the shapes allow (two device tensors split at a multiple of 16 channels, at most 64
-    channels between the two layers, ONE output channel)."""
+    channels between the two layers, ONE output channel).
+    crop = (S1, S2): the caller keeps only out[..., :S1, :S2] (the reference removes the domain padding BEFORE these layers,
+    darcy_flow_uno2d.py:125): the kernels then work on that window of the padded tensors - forward and backward - and the rest of
+    the returned (B, 1, H, W) tensor is undefined.  Ignored where the windowed kernels do not apply."""
     Co = weight.shape[0]
     if (len(xs) == 2 and all(_dev_act(x) for x in xs) and xs[0].dtype == xs[1].dtype and weight.dtype == torch.float32
             and weight2.shape[0] == 1 and Co <= 64 and xs[0].shape[1] % 16 == 0 and weight2.dtype == torch.float32):
         x1, x2 = xs
         B = x1.shape[0]
         w = weight.reshape(Co, -1)
+        window = None
+        if crop is not None and x1.dim() == 4 and x1.dtype == torch.float32 and x1.shape[1] % 64 == 0:
+            H, W = x1.shape[2:]
+            rows, cols = int(crop[0]), (int(crop[1]) + 3) & ~3
+            if 0 < rows <= H and 260 <= cols <= W and rows * cols < (1 << 24) and (rows < H or cols < W) and tuple(x2.shape[2:]) == (H, W):
+                window = (rows, cols, W)
         out = _ChannelMixCatProjectFn.apply(x1.reshape(B, x1.shape[1], -1), x2.reshape(B, x2.shape[1], -1), w, bias,
-                                            weight2.reshape(Co), bias2, bool(gelu_first), defer_grad, (weight, bias))
+                                            weight2.reshape(Co), bias2, bool(gelu_first), defer_grad, (weight, bias), window)
         return out.view(B, 1, *x1.shape[2:])
     return gelu_project(channel_mix_cat(xs, weight, bias, gelu_first=gelu_first, defer_grad=defer_grad), weight2, bias2)
 
