@@ -151,7 +151,10 @@ __global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const T* __restrict_
 // per thread forward, 25 backward where x and gy are both held): each element is loaded once, the statistics and the output come
 // out of registers.  Same arithmetic and the same fixed-order reductions as the sweep kernels (bit-identical results).
 template <bool GELU, typename T, int NQ>
-__global__ __launch_bounds__(IN_T) void instnorm_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+#ifndef UNO_IN_FWD25_WPE
+#define UNO_IN_FWD25_WPE 4
+#endif
+__global__ __launch_bounds__(IN_T, (NQ == 25 ? UNO_IN_FWD25_WPE : 1)) void instnorm_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, T* __restrict__ y,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps) {
     __shared__ float red[IN_T / 64];
