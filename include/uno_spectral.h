@@ -249,6 +249,15 @@ int uno_channel_wgrad2_win(const float* gy, const float* x1, const float* x2, in
                            int Co, int rows, int cols, int pitch, long long plane, int act_x, int accumulate, void* stream);
 int uno_gelu_project_backward_win(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws,
                                   int B, int C, int rows, int cols, int pitch, long long plane, void* stream);
+/* Everything outside the top-left rows x cols corner of n_planes contiguous (Hp, Wp) float32 planes := 0 (the border a windowed
+ * call leaves untouched in a fresh gradient tensor). */
+int uno_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, void* stream);
+/* The end of the lift with the domain padding (reference darcy_flow_uno2d.py:100-107: `x_fc0 = self.fc0(x_fc); x_fc0 = F.gelu(x_fc0)`,
+ * permute, `F.pad(x_fc0, [0, padding, 0, padding])`) in one pass: y (B, Co, H, W) = Wm [gelu](x (B, Ci, H, W)) + bias - kept, its GELU
+ * derivative is needed backward - and y_act (B, Co, Hp, Wp) = zero-pad(gelu(y)) at the end of both axes, written by the layer's own
+ * store epilogue (no second pass over y).  260 <= W <= Wp, H * W < 2^24, float32. */
+int uno_channel_mix_act_padded(const float* x, const float* w, const float* bias, float* y, float* y_act, int B, int Ci, int Co, int H,
+                               int W, int Hp, int Wp, int act_in, void* stream);
 
 /* GELU followed by zero padding at the end of both axes (the lift's last activation + domain padding, reference
  * darcy_flow_uno2d.py:103-107): backward = 0: out (n_img, Hp, Wp) = pad(gelu(s (n_img, H, W))), gy ignored;

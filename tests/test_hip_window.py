@@ -162,3 +162,47 @@ def test_window_argument_errors():
         _native.channel_mix2(x.bfloat16(), None, w, None, window=(20, 260, 300))
     with pytest.raises(RuntimeError):                                           # few input channels: dense only
         _native.channel_wgrad2(torch.randn(1, 8, 20 * 300).cuda(), torch.randn(1, 3, 20 * 300).cuda(), None, window=(20, 260, 300))
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ph,pw", [(2, 32, 64, 30, 261, 3, 7), (1, 32, 64, 421, 421, 25, 25), (2, 16, 40, 9, 300, 0, 5), (2, 32, 64, 5, 264, 2, 0)])
+def test_lift_with_padded_activation(B, Ci, Co, H, W, ph, pw):
+    """uno_channel_mix_act_padded: y = W gelu(x) + b kept, act = zero-pad(gelu(y)) from the same kernel (odd widths: a lane's four
+    pixels straddle row ends; partial last pixel tile; partial channel tile)"""
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(H + W + Co)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w, b = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    y, act = _native.channel_mix_act_padded(x, w, b, H + ph, W + pw, act_in=True)
+    yr = torch.matmul(w.double(), torch.nn.functional.gelu(x.double()).view(B, Ci, -1)).view(B, Co, H, W) + b.double().view(1, -1, 1, 1)
+    ar = torch.nn.functional.pad(torch.nn.functional.gelu(yr), [0, pw, 0, ph])
+    assert rel(y, yr) < 2e-6 and act.shape == ar.shape and rel(act, ar) < 2e-6
+    assert float(act[:, :, H:].abs().max() if ph else 0) == 0.0 and float(act[:, :, :, W:].abs().max() if pw else 0) == 0.0
+
+
+def test_gelu_channel_mix_pad_autograd_matches_the_two_step_form():
+    from uno_amd.integral_operators import gelu_channel_mix, gelu_channel_mix_pad, gelu_pad2d
+    torch.manual_seed(5)
+    B, Ci, Co, H, W, pad = 2, 32, 64, 37, 283, 6
+    base = [torch.randn(B, Ci, H, W), torch.randn(Co, Ci) / 6, torch.randn(Co)]
+    gout = torch.randn(B, Co, H + pad, W + pad).cuda()
+    res = []
+    for fused in (True, False):
+        t = [v.clone().cuda().requires_grad_(True) for v in base]
+        out = gelu_channel_mix_pad(t[0], t[1], t[2], pad, pad) if fused else gelu_pad2d(gelu_channel_mix(t[0], t[1], t[2]), pad, pad)
+        out.backward(gout)
+        res.append((out.detach(), [v.grad for v in t]))
+    (o1, g1), (o0, g0) = res
+    assert rel(o1, o0) < 1e-6
+    for a, b, tol in zip(g1, g0, (2e-6, 2e-5, 2e-5)):
+        assert rel(a, b) < tol
+
+
+def test_clear_border():
+    from uno_amd import _native
+    t = torch.randn(3, 5, 23, 31).cuda()
+    ref = t.clone()
+    ref[..., 17:, :] = 0
+    ref[..., :, 29:] = 0
+    assert torch.equal(_native.clear_border(t, 17, 29), ref)
+    t2 = torch.randn(2, 7, 9).cuda()
+    assert torch.equal(_native.clear_border(t2.clone(), 7, 9), t2)

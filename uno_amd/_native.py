@@ -55,6 +55,8 @@ _SIGNATURES = {
     "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_channel_mix2_win": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    "uno_clear_border": (C.c_int, [_fp, C.c_longlong, _i, _i, _i, _i, _fp]),
+    "uno_channel_mix_act_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "uno_channel_wgrad2_win": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_backward_win": (C.c_int, [_fp] * 7 + [_i, _i, _i, _i, _i, C.c_longlong, _fp]),
     "uno_channel_wgrad_finish": (C.c_int, [_fp, _fp, _fp, _i, _i, C.c_longlong, _i, _fp]),
@@ -527,6 +529,42 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
                                    _ptr(dgelu_of) if dgelu_of is not None else C.c_void_p(0), _stream(x))
     _check(rc, "uno_channel_mix")
     return y
+
+
+def clear_border(t, rows: int, cols: int):
+    """t (..., Hp, Wp) float32 contiguous: everything outside t[..., :rows, :cols] := 0, in place (-> t)."""
+    _require(t, torch.float32, "tensor")
+    Hp, Wp = t.shape[-2:]
+    n = t.numel() // max(1, Hp * Wp)
+    with torch.cuda.device(t.device):
+        rc = lib().uno_clear_border(_ptr(t), n, Hp, Wp, int(rows), int(cols), _stream(t))
+    _check(rc, "uno_clear_border")
+    return t
+
+
+def channel_mix_act_padded_ok(x, Hp: int, Wp: int) -> bool:
+    """shape rules of uno_channel_mix_act_padded for x (B, Ci, H, W)"""
+    H, W = x.shape[-2:]
+    return x.dtype == torch.float32 and 260 <= W <= Wp and H <= Hp and H * W < (1 << 24)
+
+
+def channel_mix_act_padded(x, w, bias, Hp: int, Wp: int, act_in: bool = False):
+    """x (B, Ci, H, W) f32, w (Co, Ci) -> y (B, Co, H, W) = w . [gelu](x) + bias and act (B, Co, Hp, Wp) = zero-pad(gelu(y))."""
+    _require(x, torch.float32, "x")
+    _require(w, torch.float32, "weight")
+    if bias is not None:
+        _require(bias, torch.float32, "bias")
+    B, Ci, H, W = x.shape
+    Co = w.shape[0]
+    if w.shape[1] != Ci:
+        raise RuntimeError(f"uno_amd: weight {tuple(w.shape)} does not match {Ci} input channels")
+    y = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device)
+    act = torch.empty((B, Co, Hp, Wp), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().uno_channel_mix_act_padded(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y), _ptr(act),
+                                              B, Ci, Co, H, W, int(Hp), int(Wp), 1 if act_in else 0, _stream(x))
+    _check(rc, "uno_channel_mix_act_padded")
+    return y, act
 
 
 def channel_mix2_ok(C1: int, Co1, Co: int, P: int) -> bool:

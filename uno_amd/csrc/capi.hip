@@ -452,6 +452,32 @@ int uno_channel_mix2_win(const float* x1, const float* x2, int C1, const float* 
                              proj_w, proj_b, proj_out, 0, stream, win);
 }
 
+int uno_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, void* stream) {
+    if (n_planes < 0 || Hp < 1 || Wp < 1 || rows < 0 || rows > Hp || cols < 0 || cols > Wp) {
+        set_error("uno_clear_border: bad sizes planes=%lld (%d, %d) keep (%d, %d)", n_planes, Hp, Wp, rows, cols);
+        return -1;
+    }
+    if (n_planes == 0) return 0;
+    if (!t) { set_error("uno_clear_border: null pointer"); return -1; }
+    return launch_clear_border(t, n_planes, Hp, Wp, rows, cols, (hipStream_t)stream);
+}
+
+int uno_channel_mix_act_padded(const float* x, const float* w, const float* bias, float* y, float* y_act, int B, int Ci, int Co, int H, int W,
+                               int Hp, int Wp, int act_in, void* stream) {
+    if (B < 0 || Ci < 1 || Co < 1 || H < 1 || W < 1 || Hp < H || Wp < W) {
+        set_error("uno_channel_mix_act_padded: bad sizes B=%d Ci=%d Co=%d (%d, %d) -> (%d, %d)", B, Ci, Co, H, W, Hp, Wp);
+        return -1;
+    }
+    if (B == 0) return 0;
+    if (!x || !w || !y || !y_act) { set_error("uno_channel_mix_act_padded: null pointer"); return -1; }
+    ChannelMixArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.y_act = y_act;
+    a.B = B; a.Ci = Ci; a.Co = Co; a.C1 = Ci; a.Co1 = Co; a.P = (long long)H * W; a.act_in = act_in;
+    a.act_cols = W; a.act_pitch = Wp; a.act_plane = (long long)Hp * Wp;
+    if (int rc = launch_channel_mix2(a, (hipStream_t)stream)) return rc;
+    return launch_clear_border(y_act, (long long)B * Co, Hp, Wp, H, W, (hipStream_t)stream);
+}
+
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
     if (B < 1 || Ci < 1 || Co < 1 || P < 1) return 0;
     return 4LL * channel_wgrad_ws_floats(B, Ci, Co, P, nullptr);

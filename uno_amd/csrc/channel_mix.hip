@@ -42,6 +42,13 @@ __device__ __forceinline__ float4 load4_tail(const T* row, int px, int P, const 
 __device__ __forceinline__ float cm_gelu(float x) { return uno_gelu(x); }
 __device__ __forceinline__ float cm_dgelu(float x) { return uno_dgelu(x); }
 __device__ __forceinline__ float4 cm_gelu4(float4 v) { return make_float4(cm_gelu(v.x), cm_gelu(v.y), cm_gelu(v.z), cm_gelu(v.w)); }
+// four consecutive logical pixels px .. px + 3 through a run map whose rows need not be a multiple of 4 long
+template <typename T>
+__device__ __forceinline__ void store4_run(T* plane, const PixRun& run, int px, float a, float b, float c, float d) {
+    const int f0 = run(px), f3 = run(px + 3);
+    if (f3 - f0 == 3) { io_store4(plane + f0, a, b, c, d); return; }
+    io_store1(plane + f0, a); io_store1(plane + run(px + 1), b); io_store1(plane + run(px + 2), c); io_store1(plane + f3, d);
+}
 
 struct ChannelMixParams {
     const void* x;          // (B, C1, P) f32 | bf16 (BF instantiations: activations bfloat16, weights / accumulation f32)
@@ -59,6 +66,8 @@ struct ChannelMixParams {
     void* proj_out;         // re-reading y; needs all output channels in ONE 64-channel tile (Co <= 64)
     int B, Ci, Co, P;
     PixMap pm;              // plane stride of every operand + the pixel window (dense: pm.PS == P); generic and split kernels only
+    PixMap pm_act;          // y_act's OWN map when pm_act.rl != 0 (generic kernel): the dense pixels of an H x W grid go to the top-left
+                            // corner of (Hp, Wp) planes - rl = W (any width: a lane's four pixels may straddle a row end), skip = Wp - W
     int C1, Co1;
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
@@ -101,7 +110,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     T* const ydst = dd.base;                     // row o of this tile: ydst + (o - dd.ob) * P
     const bool dg = DG && o0 < p.Co1;            // gelu' factor: first destination only
     const T* const dall = DG ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * PS : nullptr;
-    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * PS : nullptr;
+    const bool act_map = p.pm_act.rl != 0;       // y_act on its own (padded) planes
+    const int APS = act_map ? p.pm_act.PS : PS;
+    const PixRun arun = act_map ? pix_run(p.pm_act, p0) : run;
+    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * APS : nullptr;
     bool act_ld = ACT;                           // the chunk in the staging registers comes from the activated source
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
@@ -245,7 +257,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 const int o = o0 + 16 * wave + 8 * h + 2 * it + (lane >> 5);
                 const size_t off = (size_t)(o - dd.ob) * PS + run(p0 + c4);
                 dst[it] = ydst + off;
-                aoff[it] = (size_t)o * PS + run(p0 + c4);
+                aoff[it] = (size_t)o * APS;
                 if (p.accumulate) old[it] = io_ld4(dst[it]);
                 else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (DG) { if (dg) pre[it] = io_ld4(dall + off); else pre[it] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -267,7 +279,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     }
                 }
                 io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
-                if (aall) io_store4(aall + aoff[it], cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
+                if (aall) store4_run(aall + aoff[it], arun, p0 + c4, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
                 if (p.proj_w) {
                     const float pwv = __shfl(pw_l, 8 * h + row);
 #pragma unroll
@@ -305,7 +317,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         const float bv = p.bias ? p.bias[o] : 0.f;
         const float pwv = p.proj_w ? p.proj_w[o] : 0.f;
         T* yrow = ydst + (size_t)(o - dd.ob) * PS;
-        T* arow = aall ? aall + (size_t)o * PS : nullptr;
+        T* arow = aall ? aall + (size_t)o * APS : nullptr;
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk, fx = run(px);        // logical pixel (guards), offset inside the plane
@@ -322,7 +334,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     w4[r] = p.accumulate == 2 ? (w4[r] + (acc[mt][r] + bv)) * d : w4[r] + (acc[mt][r] + bv) * d;
                 }
                 io_store4(yrow + fx, w4[0], w4[1], w4[2], w4[3]);
-                if (arow) io_store4(arow + fx, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
+                if (arow) store4_run(arow, arun, px, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
                 if (p.proj_w) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pv[mt][r] = pwv * cm_gelu(w4[r]);
@@ -334,7 +346,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                         const float d = dg ? cm_dgelu(io_widen(drow[fx + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[fx + r]) : 0.f;
                         const float v = p.accumulate == 2 ? (o1 + (acc[mt][r] + bv)) * d : o1 + (acc[mt][r] + bv) * d;
                         io_store1(yrow + fx + r, v);
-                        if (arow) io_store1(arow + fx + r, cm_gelu(v));
+                        if (arow) io_store1(arow + arun(px + r), cm_gelu(v));
                         if (p.proj_w) pv[mt][r] = pwv * cm_gelu(v);
                     }
             }
@@ -901,6 +913,17 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     if (const char* why = pix_window_error(a.win, P)) { set_error("channel_mix: %s", why); return -2; }
     p.pm = pix_map(a.win, P);
     const long long PSl = windowed ? a.win.plane : P;            // elements between two channel planes
+    // y_act on padded planes: P = H x W dense pixels -> the top-left corner of (act_plane / act_pitch) x act_pitch planes
+    const bool act_pad = a.act_cols != 0;
+    p.pm_act = PixMap{0, 0, 0, 0u};
+    if (act_pad) {
+        if (!a.y_act || windowed || bf16 || a.act_cols < 260 || a.act_pitch < a.act_cols || P % a.act_cols || P >= (1LL << 24) ||
+            a.act_plane < (P / a.act_cols) * (long long)a.act_pitch || (long long)Co * a.act_plane >= (1LL << 31)) {
+            set_error("channel_mix: the padded activation needs y_act, float32, dense operands, 260 <= W <= Wp, H * W < 2^24 pixels");
+            return -2;
+        }
+        p.pm_act = PixMap{(int)a.act_plane, a.act_cols, a.act_pitch - a.act_cols, (unsigned)(((1ULL << 40) + a.act_cols - 1) / (unsigned long long)a.act_cols)};
+    }
     p.C1 = two_src ? a.C1 : Ci;
     p.Co1 = two_dst ? a.Co1 : Co;
     // forward: Wm(o, i) = W[o][i] of a (Co, Ci) matrix; transposed: Wm(o, i) = W[i][o] of an (Ci, Co) matrix
@@ -910,7 +933,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const int act_in = a.act_in;
     const void* dgelu_of = a.dgelu_of;
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
-    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0) && !windowed;      // (the wide and few-input kernels are dense only)
+    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0) && !windowed && !act_pad;      // (the wide and few-input kernels are dense only)
     // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
 #ifdef UNO_CMS_DEV        // development build only (tools/dev/mkvariant.py): A/B switch, knock-outs, stamp buffer from the environment
     static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;
@@ -924,7 +947,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     // f32 activations: from 128 input channels on; bf16 activations move half the bytes, there the f32 MFMA is the ceiling from 32 on
     // (profiles/r04_c5_mixed_kernel_stats.csv: the generic forms on bf16 were 4.8 of the mixed C5 step's 16 ms)
     const bool trw_ = a.transpose_w != 0;
-    const bool s_common = !split_off && P >= PT && Ci >= (bf16 ? 32 : 128) && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0) && !(act_in && trw_);
+    const bool s_common = !split_off && !act_pad && P >= PT && Ci >= (bf16 ? 32 : 128) && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0) && !(act_in && trw_);
     const bool split = s_common && Co % 128 == 0 && !a.proj_w && (!two_dst || p.Co1 % 128 == 0);
     // the same on 64-channel tiles: layers with Co % 64 == 0 that are not a multiple of 128 wide (conv5's 256 -> 64, fc1 with its fused
     // projection, the input gradients of the 64-channel levels) - f32-MFMA-bound in the generic kernel (256 -> 64 at 223^2: 26 GFLOP =

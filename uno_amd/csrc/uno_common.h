@@ -284,7 +284,10 @@ struct ChannelMixArgs {
     const float* proj_w; const float* proj_b; void* proj_out;       // fused one-channel projection of gelu(y) (Co <= 64), or nullptr
     int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
     PixelWindow win;                                                // all operands on one window (proj_out: one plane per batch entry)
+    int act_cols = 0, act_pitch = 0; long long act_plane = 0;       // y_act on padded planes (generic kernel): the P = H * act_cols dense
+                                                                    // pixels land in the top-left corner of act_plane / act_pitch rows
 };
+int launch_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, hipStream_t s);       // pointwise_fused.hip
 int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s);
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
                        int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s);

@@ -748,10 +748,7 @@ class _ChannelMixCatFn(torch.autograd.Function):
         def cleared(g):
             # what the windowed kernel did not write: the columns right of the window, the rows below it (a gradient's consumers -
             # the transforms and resampling of the producing block - read whole planes)
-            v = g.view(g.shape[0], g.shape[1], -1, pitch)
-            if cols < pitch:
-                v[:, :, :rows, cols:].zero_()
-            v[:, :, rows:].zero_()
+            _native.clear_border(g.view(g.shape[0], g.shape[1], -1, pitch), rows, cols)
             return g
 
         g1 = g2 = None
@@ -880,6 +877,43 @@ def gelu_channel_mix(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
         y = _GeluChannelMixFn.apply(pre.reshape(B, Ci, -1), w, bias, (weight, bias))
         return y.view(B, w.shape[0], *pre.shape[2:])
     return channel_mix(F.gelu(pre), weight, bias)
+
+
+class _GeluChannelMixPadFn(torch.autograd.Function):
+    """zero-pad(gelu(W . gelu(pre) + bias)): the second lift layer, its activation and the domain padding (reference
+    darcy_flow_uno2d.py:100-107) from ONE forward kernel - the layer's store epilogue writes the padded activation next to the
+    pre-activation result it keeps for the backward pass (uno_channel_mix_act_padded); backward: K12 (gelu' x cropped gradient), then
+    the layer's two gradient kernels as in _GeluChannelMixFn."""
+
+    @staticmethod
+    def forward(ctx, pre, w, bias, Hp, Wp, leaves=None):
+        pre, w = _plain(pre), _plain(w)
+        z, act = _native.channel_mix_act_padded(pre, w, None if bias is None else _plain(bias), Hp, Wp, act_in=True)
+        ctx.save_for_backward(pre, w, z)
+        ctx.has_bias = bias is not None
+        ctx.leaves = leaves
+        return act
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gact):
+        pre, w, z = ctx.saved_tensors
+        B, Ci, Co = pre.shape[0], pre.shape[1], z.shape[1]
+        gz = _native.gelu_pad_backward(z, _plain(gact)).view(B, Co, -1)
+        pre3 = pre.view(B, Ci, -1)
+        g_pre = _native.channel_mix(gz, w, None, transpose_w=True, dgelu_of=pre3).view(pre.shape) if ctx.needs_input_grad[0] else None
+        gw, gb = _wgrad_into(ctx.leaves, gz, pre3, None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], act_x=True)
+        return g_pre, gw, gb, None, None, None
+
+
+def gelu_channel_mix_pad(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, pad_h: int, pad_w: int) -> torch.Tensor:
+    """gelu_pad2d(gelu_channel_mix(pre, weight, bias), pad_h, pad_w) - `F.pad(F.gelu(fc0(F.gelu(pre))), [0, pad_w, 0, pad_h])` - with the
+    activation and the padding written by fc0's own kernel where the shapes allow (4-D float32 device tensor, width >= 260)."""
+    if pre.dim() == 4 and _dev_act(pre) and weight.dtype == torch.float32 and pad_h >= 0 and pad_w >= 0:
+        Hp, Wp = pre.shape[2] + int(pad_h), pre.shape[3] + int(pad_w)
+        if _native.channel_mix_act_padded_ok(pre, Hp, Wp):
+            return _GeluChannelMixPadFn.apply(pre, weight.reshape(weight.shape[0], pre.shape[1]), bias, Hp, Wp, (weight, bias))
+    return gelu_pad2d(gelu_channel_mix(pre, weight, bias), pad_h, pad_w)
 
 
 class _GeluProjectFn(torch.autograd.Function):
