@@ -356,6 +356,11 @@ int uno_instnorm_backward_bf16(const void* x, const void* gy, const float* gamma
  * free it on the same stream).  A call that needs more than was provided fails with -6 and a message naming the size. */
 long long uno_dft2d_any_ws_bytes(int n_img, int H, int W, int m1, int m2);
 int uno_scratch_provide(void* ptr, long long bytes);
+/* ABI 10: the channel-mix entry points (uno_channel_mix*, uno_channel_mix2*) also look at the registered scratch.  Their wide layers
+ * (>= 128 input channels; 32 on bfloat16 activations) run on three-piece bf16 operands; with uno_channel_mix_ws_bytes(Ci, Co, P, bf16)
+ * = 6 Ci Co bytes of 16-byte aligned scratch (0: the shape never takes that form) the weights are split ONCE per call by a small
+ * launch instead of by every workgroup.  Optional: without (enough) scratch the call runs as before, with identical results. */
+long long uno_channel_mix_ws_bytes(int Ci, int Co, long long P, int bf16);
 
 /* Batched transposing copy between the channels-last and the channels-first layout of an activation (ABI 8):
  *   out[b][c][r] = in[b][r][c],   b < B, r < R, c < C

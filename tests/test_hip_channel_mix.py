@@ -624,3 +624,59 @@ def test_wide_wgrad_red_zone():
     assert bool((raw[:1024] == 3.25).all()) and bool((raw[1024 + nf:] == 3.25).all())
     gw, gb = _native.channel_wgrad_finish(parts.view(1, -1), Ci, Co, True)
     assert rel(gw, torch.einsum("bop,bip->oi", gy.double(), x.double())) < 2e-6 and rel(gb, gy.double().sum(dim=(0, 2))) < 2e-6
+
+
+# ---- K8-S on PRE-SPLIT weights (round 5): with uno_channel_mix_ws_bytes() of scratch registered the weights are split once per call
+# (channel_mix_wsplit_kernel) into the kernel's LDS images - the binding always provides it, so every K8-S test above runs that form.
+# Here the same calls run WITHOUT scratch as well (the weights split by every workgroup, rounds 3-4): same arithmetic on the same
+# pairs, so the results must be bit-identical.
+def _without_scratch(fn):
+    from uno_amd import _native
+    init = _native._mix_scratch.__init__
+
+    def none(self, device, *a):
+        self.bytes, self.device, self.buf = 0, device, None
+    _native._mix_scratch.__init__ = none
+    try:
+        return fn()
+    finally:
+        _native._mix_scratch.__init__ = init
+
+
+@pytest.mark.parametrize("B,C1,C2,Co,P", SPLIT + SPLIT64 + [(2, 128, 0, 128, 5 * 128)])
+@pytest.mark.parametrize("bf", [False, True])
+def test_presplit_weights_equal_the_per_workgroup_split(B, C1, C2, Co, P, bf):
+    from uno_amd import _native
+    g = torch.Generator().manual_seed(3 * C1 + C2 + Co + P)
+    dt = torch.bfloat16 if bf else torch.float32
+    x1 = torch.randn(B, C1, P, generator=g).cuda().to(dt)
+    x2 = torch.randn(B, C2, P, generator=g).cuda().to(dt) if C2 else None
+    w, b = (torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    assert _native.lib().uno_channel_mix_ws_bytes(C1 + C2, Co, P, 1 if bf else 0) == 6 * (C1 + C2) * Co
+    calls = [lambda: _native.channel_mix2(x1, x2, w, b), lambda: _native.channel_mix2(x1, x2, w, b, act_in=True)]
+    if not C2:
+        wt = (torch.randn(C1, Co, generator=g) / C1 ** 0.5).cuda()
+        pre = torch.randn(B, Co, P, generator=g).cuda().to(dt)
+        calls += [lambda: _native.channel_mix(x1, wt, None, transpose_w=True), lambda: _native.channel_mix(x1, wt, None, transpose_w=True, dgelu_of=pre)]
+    for call in calls:
+        (got, names) = _launched(call)
+        assert names == ["uno::channel_mix_split_kernel"], names
+        assert torch.equal(got, _without_scratch(call))
+
+
+def test_channel_mix_scratch_is_optional_and_sized_by_the_library():
+    from uno_amd import _native
+    L = _native.lib()
+    assert L.uno_channel_mix_ws_bytes(64, 64, 4096, 0) == 0 and L.uno_channel_mix_ws_bytes(128, 100, 4096, 0) == 0
+    assert L.uno_channel_mix_ws_bytes(128, 64, 100, 0) == 0 and L.uno_channel_mix_ws_bytes(64, 64, 4096, 1) == 6 * 64 * 64
+    x, w = torch.randn(2, 128, 640).cuda(), torch.randn(128, 128).cuda()
+    ref = _without_scratch(lambda: _native.channel_mix(x, w, None))
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")               # too small: ignored, not an error
+    L.uno_scratch_provide(small.data_ptr(), small.numel())
+    try:
+        y = torch.empty_like(ref)
+        rc = L.uno_channel_mix(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 2, 128, 128, 640, 0, 0, 0, None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    finally:
+        L.uno_scratch_provide(None, 0)
+    assert torch.equal(y, ref)

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "uno_channel_mix2": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_channel_wgrad2": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_channel_mix2_win": (C.c_int, [_fp, _fp, _i, _fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    "uno_channel_mix_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong, _i]),
     "uno_clear_border": (C.c_int, [_fp, C.c_longlong, _i, _i, _i, _i, _fp]),
     "uno_channel_mix_act_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "uno_channel_wgrad2_win": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
@@ -140,6 +141,27 @@ class _any_mode_scratch:
     def __init__(self, device, *needs):
         L = lib()
         self.bytes = max((int(L.uno_dft2d_any_ws_bytes(*[int(v) for v in n])) for n in needs), default=0)
+        self.device = device
+        self.buf = None
+
+    def __enter__(self):
+        if self.bytes > 0:
+            self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=self.device)
+            _check(lib().uno_scratch_provide(_ptr(self.buf), self.bytes), "uno_scratch_provide")
+        return self
+
+    def __exit__(self, *exc):
+        if self.bytes > 0:
+            lib().uno_scratch_provide(None, 0)
+        return False
+
+
+class _mix_scratch:
+    """Scratch of the wide channel-mix layers (uno_channel_mix_ws_bytes: the weights pre-split for the bf16 matrix pipe), taken from
+    torch's caching allocator and registered for this thread for the duration of the call - like _any_mode_scratch."""
+
+    def __init__(self, device, Ci, Co, P, bf16):
+        self.bytes = int(lib().uno_channel_mix_ws_bytes(int(Ci), int(Co), int(P), 1 if bf16 else 0))
         self.device = device
         self.buf = None
 
@@ -517,7 +539,7 @@ def channel_mix(x, w, bias=None, transpose_w: bool = False, out=None, act_in: bo
         y = out
     else:
         y = torch.empty((B, Co, P), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _mix_scratch(x.device, Ci, Co, P, bf16):
         if dgelu_of is not None:
             _require(dgelu_of, x.dtype, "dgelu_of")
             if tuple(dgelu_of.shape) != (B, Co, P):
@@ -629,7 +651,7 @@ def channel_mix2(x1, x2, w, bias=None, transpose_w: bool = False, out=None, out2
     acc_flag = int(accumulate) if out is not None else 0
     if acc_flag == 2 and (dgelu_of is None or window is None):
         raise RuntimeError("uno_amd: accumulate = 2 goes with dgelu_of (windowed one-destination calls)")
-    with torch.cuda.device(x1.device):
+    with torch.cuda.device(x1.device), _mix_scratch(x1.device, Ci, Co, P if window is None else window[0] * window[1], bf16):
         if window is not None:
             fn, size = lib().uno_channel_mix2_win, (*_window_args(window, P, bf16), P)
         else:

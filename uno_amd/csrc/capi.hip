@@ -391,7 +391,13 @@ static int channel_mix_impl(const void* x, const float* w, const float* bias, vo
     if (B < 0 || Ci < 1 || Co < 1 || P < 0) { set_error("uno_channel_mix: bad sizes B=%d Ci=%d Co=%d P=%lld", B, Ci, Co, P); return -1; }
     if (B == 0 || P == 0) return 0;
     if (!x || !w || !y) { set_error("uno_channel_mix: null pointer"); return -1; }
-    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, bf16, (hipStream_t)stream);
+    return launch_channel_mix(x, w, bias, y, B, Ci, Co, P, transpose_w, accumulate, act_in, dgelu_of, bf16, (hipStream_t)stream,
+                              t_scratch.ptr, t_scratch.bytes);
+}
+
+long long uno_channel_mix_ws_bytes(int Ci, int Co, long long P, int bf16) {
+    if (Ci < 1 || Co < 1 || P < 1) return 0;
+    return channel_mix_ws_bytes(Ci, Co, P, bf16);
 }
 
 int uno_channel_mix(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int Co, long long P,
@@ -417,6 +423,7 @@ static int channel_mix2_impl(const void* x1, const void* x2, int C1, const float
     a.transpose_w = transpose_w; a.accumulate = accumulate; a.act_in = act_in; a.bf16 = bf16;
     a.proj_w = proj_w; a.proj_b = proj_b; a.proj_out = proj_out;
     a.win = win;
+    a.ws = t_scratch.ptr; a.ws_bytes = t_scratch.bytes;
     return launch_channel_mix2(a, (hipStream_t)stream);
 }
 

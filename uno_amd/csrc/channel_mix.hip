@@ -72,6 +72,7 @@ struct ChannelMixParams {
     int w_so, w_si;
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
+    const void* wsplit;     // K8-S with WM = 2: the weights as bf16 pieces in the kernel's own LDS layout (channel_mix_wsplit_kernel)
     int exp;                // development knock-outs of K8-S (timing only; UNO_CMS_EXP)
     int accumulate;         // 1: y += instead of y =;  2 (with dgelu_of): y = (y + product) * gelu'(dgelu_of) - the LAST contribution to a
                             // gradient that must still pass through a GELU: the factor multiplies the completed sum
@@ -574,14 +575,45 @@ constexpr int CMS_XPLANE = CMS_KC * CMS_XRS;            // 9 216
 constexpr int CMS_WPLANE = 4 * 128 * 16;                // bytes per W plane: [k-group 4][o 128] atoms of 8 bf16
 constexpr int CMS_FALLBACK = 2 * CM_KC * (CM_PT + 16) * 4 + 2 * CM_KC * CM_WS * 4;      // staging buffers of the guarded fallback path
 
+// the weights of one call as K8-S's W operand: per (channel tile of CT, chunk of 32 input channels) the three bf16 planes
+// [k-group g 0..3][o 0..CT-1] of 16-byte atoms holding k = 4 g .. 4 g + 3 (slots 0..3) and 16 + 4 g .. + 3 (slots 4..7) of the chunk -
+// the same arithmetic (cms_split3 on the same pairs) and the same bytes the staging threads of the WM = 0 / 1 forms produce.
+__global__ __launch_bounds__(256) void channel_mix_wsplit_kernel(const float* __restrict__ w, int w_so, int w_si, int Ci, int Co, int CT,
+                                                               cms_u32x4* __restrict__ out) {
+    const int nchunk = Ci / CMS_KC;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= (Co / CT) * nchunk * 4 * CT) return;
+    const int ol = a % CT, g = (a / CT) & 3, c = (a / (4 * CT)) % nchunk, ot = a / (4 * CT * nchunk);
+    const float* wr = w + (size_t)(ot * CT + ol) * w_so;
+    const int klo = CMS_KC * c + 4 * g, khi = klo + 16;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = wr[(size_t)(klo + j) * w_si]; v[4 + j] = wr[(size_t)(khi + j) * w_si]; }
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cms_split3(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+    cms_u32x4* img = out + (size_t)(ot * nchunk + c) * (3 * 4 * CT) + g * CT + ol;
+    img[0] = cms_u32x4{h[0], h[1], h[2], h[3]};
+    img[4 * CT] = cms_u32x4{m[0], m[1], m[2], m[3]};
+    img[8 * CT] = cms_u32x4{l[0], l[1], l[2], l[3]};
+}
+
 // CT: output channels per tile, 128 or 64 (layers with Co % 64 == 0 only: conv5's 256 -> 64, the input gradients of the 64-channel
 // levels).  CT = 64: the four waves are four pixel quarters (32 pixels x 64 channels = 2 x 4 accumulator tiles each).
 // ACT: x := gelu(x) for the channels of the first source as they are staged (the layer's input is kept pre-activation: fc1 behind conv5,
 // darcy_flow_uno2d.py:126-129); gelu(x) is an f32 value, so bf16 activations take three pieces as well.  Epilogues as in the generic
 // kernel: `dgelu_of` (gelu' of the saved pre-activation on the first destination), the fused one-channel projection (CT = 64, Co = 64).
-template <bool BF, bool TR, int XP = 0, int CT = 128, bool ACT = false>      // TR: W contiguous along the output channel (input-gradient call); XP: development knock-outs / stamps
+// WM: where the W operand comes from - 0: the (Co, Ci) matrix, 1: its transpose (input-gradient call; both split by the threads that
+// stage them), 2 (round 5): a SHADOW of the weights already split into the three bf16 planes and stored as the LDS images of the
+// (channel tile, chunk) pairs (channel_mix_wsplit_kernel, one tiny launch per call into caller-provided scratch).  W is the same for
+// every pixel tile, yet each of the ~1 400 workgroups per batch entry split it again: 88 of the ~190 VALU instructions a thread spends
+// per chunk, in a kernel whose MFMA and VALU time add up.  With the shadow a chunk of W is six (CT = 64: three)
+// 16-byte copies per thread and no arithmetic.
+template <bool BF, int WM, int XP = 0, int CT = 128, bool ACT = false>      // XP: development knock-outs / stamps
 __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixParams p) {
-    constexpr bool tr = TR;
+    constexpr bool tr = WM == 1;
+    constexpr bool WSH = WM == 2;
+    constexpr int NWS = 3 * 4 * CT / 256;                // 16-byte atoms of a W image per thread: 6 | 3
     constexpr int MW = CT == 128 ? 4 : 2;               // pixel tiles (of 16) per wave
     using T = typename IoElem<BF>::type;
     constexpr int PT = CM_PT;
@@ -619,17 +651,40 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; xoff[u] = (unsigned)((e >> 5) * PS + run(p0 + (e & 31) * 4)); }
 
-    float4 rx[4], rw[4];
+    float4 rx[4], rw[WSH ? 1 : 4];
+    cms_u32x4 rws[WSH ? NWS : 1];
+    const cms_u32x4* const wimg = reinterpret_cast<const cms_u32x4*>(p.wsplit) + (size_t)(o0 / CT) * (p.Ci / CMS_KC) * (3 * 4 * CT);
     bool act_ld = false;                                 // (uniform) the chunk in the registers belongs to the first source
+    // WM = 2: TWO chunks of X in flight (register sets rx / rx2).  With one, a chunk's loads had the 96 MFMAs of the previous chunk -
+    // 0.64 us - to arrive in, less than the memory latency under load: the wave waited at every store (the same finding as K9-S, round 4).
+    // The registers come from the W operand, which no longer passes through 16 f32 registers and a split.
+    float4 rx2[WSH ? 4 : 1];
+    bool act_ld2 = false;
+    auto load_x = [&](int k0, float4* r, bool& act) {
+        act = ACT && k0 < C1;
+        const T* cb = k0 < C1 ? xb : xb2;
+        const int kb = k0 < C1 ? k0 : k0 - C1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = io_ld4(cb + ((unsigned)(kb * PS) + xoff[u]));
+    };
+    auto load_w = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NWS; ++u) rws[u] = wimg[(size_t)(k0 / CMS_KC) * (3 * 4 * CT) + tid + 256 * u];
+    };
     auto load_chunk = [&](int k0) {
         act_ld = ACT && k0 < C1;
         const T* cb = k0 < C1 ? xb : xb2;                // a 32-channel chunk lies in one source (C1 % 32 == 0)
         const int kb = k0 < C1 ? k0 : k0 - C1;
+        if constexpr (WSH) {
+#pragma unroll
+            for (int u = 0; u < NWS; ++u) rws[u] = wimg[(size_t)(k0 / CMS_KC) * (3 * 4 * CT) + tid + 256 * u];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 256 * u;
             if constexpr (!(XP & 4)) rx[u] = io_ld4(cb + ((unsigned)(kb * PS) + xoff[u]));
             else rx[u] = make_float4(1.f, 2.f, 3.f, 4.f);
+            if constexpr (WSH) continue;
             if constexpr ((XP & 2) != 0) { rw[u] = make_float4(1.f, 2.f, 3.f, 4.f); continue; }
             if (CT == 64 && u >= 2) continue;             // 64 channels x 32 k = 512 float4: the first two rounds
             if constexpr (CT == 64) {
@@ -655,6 +710,34 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
             }
         }
     };
+    auto store_x = [&](float4* r, bool act) {           // WM = 2: the X part of store_chunk on a given register set
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            char* d = sXb + (e >> 5) * CMS_XRS + (e & 31) * 8;
+            float4 v = r[u];
+            if constexpr (ACT) { if (act) v = cm_gelu4(v); }
+            if constexpr (NPX == 1) {
+                *reinterpret_cast<uint2*>(d) = make_uint2(bf16_pack2(v.x, v.y), bf16_pack2(v.z, v.w));
+            } else {
+                unsigned h0, m0, l0, h1, m1, l1;
+                cms_split3(v.x, v.y, h0, m0, l0);
+                cms_split3(v.z, v.w, h1, m1, l1);
+                *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(d + (NPX > 1 ? 1 : 0) * CMS_XPLANE) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(d + (NPX > 2 ? 2 : 0) * CMS_XPLANE) = make_uint2(l0, l1);
+            }
+        }
+    };
+    auto store_w = [&]() {
+        // the image of this (channel tile, chunk): [plane 3][k-group 4][o CT] atoms - for CT = 128 the LDS layout itself
+#pragma unroll
+        for (int u = 0; u < NWS; ++u) {
+            const int e = tid + 256 * u;
+            const int off = CT == 128 ? 16 * e : (e >> 8) * CMS_WPLANE + ((((e & 255) >> 6) * 128) + (e & 63)) * 16;
+            *reinterpret_cast<cms_u32x4*>(sWb + off) = rws[u];
+        }
+    };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -673,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
                     *reinterpret_cast<uint2*>(d + (NPX > 2 ? 2 : 0) * CMS_XPLANE) = make_uint2(l0, l1);
                 }
             }
-            if constexpr ((XP & 16) != 0) continue;
+            if constexpr ((XP & 16) != 0 || WSH) continue;
             if (CT == 64 && u >= 2) continue;
             const int o = tr ? (CT == 64 ? (e & 63) : (e & 127)) : ((e & 15) | ((e >> 7) << 4));
             const int k4 = tr ? (CT == 64 ? (e >> 6) * 4 : (e >> 7) * 4) : ((e >> 4) & 7) * 4;
@@ -686,6 +769,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
             *reinterpret_cast<uint2*>(d + CMS_WPLANE) = make_uint2(m0, m1);
             *reinterpret_cast<uint2*>(d + 2 * CMS_WPLANE) = make_uint2(l0, l1);
         }
+        if constexpr (WSH) store_w();
     };
 
     f32x4 acc[MW][4];                   // [pixel tile m][channel tile t]
@@ -743,6 +827,26 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     unsigned long long tS = 0, tB1 = 0, tC = 0, tB2 = 0, t_prev = __builtin_readcyclecounter();
     const unsigned long long t_begin = t_prev;
 #define CMS_STAMP(acc_) do { if constexpr (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); (acc_) += t_ - t_prev; t_prev = t_; } } while (0)
+    if constexpr (WSH) {
+        auto half_step = [&](int c, float4* r, bool& act) {      // chunk c sits in register set r; r is refilled with chunk c + 2
+            store_x(r, act);
+            store_w();
+            __syncthreads();
+            if (c + 1 < nchunk) load_w((c + 1) * CMS_KC);
+            if (c + 2 < nchunk) load_x((c + 2) * CMS_KC, r, act);
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        load_x(0, rx, act_ld);
+        load_w(0);
+        if (nchunk > 1) load_x(CMS_KC, rx2, act_ld2);
+        for (int c = 0; c < nchunk; c += 2) {
+            half_step(c, rx, act_ld);
+            if (c + 1 < nchunk) half_step(c + 1, rx2, act_ld2);
+        }
+    } else {
     load_chunk(0);
     for (int c = 0; c < nchunk; ++c) {
         store_chunk();                  // (waits for the chunk's loads)
@@ -756,6 +860,7 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
         CMS_STAMP(tC);
         __syncthreads();                // every wave is done with the chunk: the buffers may be overwritten
         CMS_STAMP(tB2);
+    }
     }
     const unsigned long long t_loop_end = t_prev;
 
@@ -900,6 +1005,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const bool two_src = a.x2 != nullptr, two_dst = a.y2 != nullptr;
     ChannelMixParams p;
     p.accumulate = a.accumulate == 2 ? 2 : (a.accumulate ? 1 : 0);
+    p.wsplit = nullptr;
     if (p.accumulate == 2 && !a.dgelu_of) { set_error("channel_mix: accumulate = 2 (gelu' on the completed sum) needs dgelu_of"); return -2; }
     p.dgelu_of = a.dgelu_of;
     p.x = a.x; p.x2 = a.x2; p.w = a.w; p.bias = a.bias; p.y = a.y; p.y2 = a.y2; p.y_act = a.y_act;
@@ -948,7 +1054,12 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     // (profiles/r04_c5_mixed_kernel_stats.csv: the generic forms on bf16 were 4.8 of the mixed C5 step's 16 ms)
     const bool trw_ = a.transpose_w != 0;
     const bool s_common = !split_off && !act_pad && P >= PT && Ci >= (bf16 ? 32 : 128) && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0) && !(act_in && trw_);
-    const bool split = s_common && Co % 128 == 0 && !a.proj_w && (!two_dst || p.Co1 % 128 == 0);
+#ifdef UNO_CMS_DEV
+    static const bool force64 = getenv("UNO_CMS_FORCE64") != nullptr;
+#else
+    constexpr bool force64 = false;
+#endif
+    const bool split = s_common && !force64 && Co % 128 == 0 && !a.proj_w && (!two_dst || p.Co1 % 128 == 0);
     // the same on 64-channel tiles: layers with Co % 64 == 0 that are not a multiple of 128 wide (conv5's 256 -> 64, fc1 with its fused
     // projection, the input gradients of the 64-channel levels) - f32-MFMA-bound in the generic kernel (256 -> 64 at 223^2: 26 GFLOP =
     // 166 us of f32 MFMA peak for 1.02 GB)
@@ -962,7 +1073,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         return -2;
     }
     if (a.y_act && (two_dst || dgelu_of)) { set_error("channel_mix: the activated second output goes with a single destination and no dgelu_of"); return -2; }
-    const long long npt = (P + PT - 1) / PT, ncot = (wide || split) ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
+    const long long npt = (P + PT - 1) / PT, ncot = (split || (wide && !split64)) ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * PSl >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
@@ -987,10 +1098,18 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         if (split64 || split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
             const bool trw = p.w_so == 1 && p.w_si != 1;
+            // the weights pre-split into the kernel's LDS images when the caller provided room for them (6 bytes per weight)
+            const int ct = split ? 128 : 64;
+            const bool shadow = a.ws && a.ws_bytes >= (size_t)6 * Ci * Co && (reinterpret_cast<uintptr_t>(a.ws) & 15) == 0;
+            p.wsplit = shadow ? a.ws : nullptr;
+            if (shadow)
+                hipLaunchKernelGGL(channel_mix_wsplit_kernel, dim3((unsigned)((Ci / 8 * Co + 255) / 256)), dim3(256), 0, s, p.w, p.w_so, p.w_si, Ci, Co, ct,
+                                   reinterpret_cast<cms_u32x4*>(a.ws));
 #define UNO_CMS(BF_, TR_, XP_, CT_, ACT_) hipLaunchKernelGGL((channel_mix_split_kernel<BF_, TR_, XP_, CT_, ACT_>), grid, dim3(256), 0, s, p)
-#define UNO_CMS_T(BF_, CT_) do { if (act_in) UNO_CMS(BF_, false, 0, CT_, true); else if (trw) UNO_CMS(BF_, true, 0, CT_, false); else UNO_CMS(BF_, false, 0, CT_, false); } while (0)
+#define UNO_CMS_T(BF_, CT_) do { if (shadow) { if (act_in) UNO_CMS(BF_, 2, 0, CT_, true); else UNO_CMS(BF_, 2, 0, CT_, false); } \
+                                 else if (act_in) UNO_CMS(BF_, 0, 0, CT_, true); else if (trw) UNO_CMS(BF_, 1, 0, CT_, false); else UNO_CMS(BF_, 0, 0, CT_, false); } while (0)
 #ifdef UNO_CMS_DEV          // development build: knock-out / stamp instantiations (f32 activations, 128-channel tiles) selected by UNO_CMS_EXP
-#define UNO_CMS_X(XP_) case XP_: if (trw) UNO_CMS(false, true, XP_, 128, false); else UNO_CMS(false, false, XP_, 128, false); break;
+#define UNO_CMS_X(XP_) case XP_: if (trw) UNO_CMS(false, 1, XP_, 128, false); else UNO_CMS(false, 0, XP_, 128, false); break;
             if (!bf16 && cms_exp && split && !act_in) {
                 switch (cms_exp) {
                     UNO_CMS_X(1) UNO_CMS_X(2) UNO_CMS_X(4) UNO_CMS_X(6) UNO_CMS_X(8) UNO_CMS_X(16) UNO_CMS_X(31) UNO_CMS_X(64) UNO_CMS_X(70)
@@ -1024,11 +1143,18 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     return 0;
 }
 
+long long channel_mix_ws_bytes(int Ci, int Co, long long P, int bf16) {
+    // (the shapes launch_channel_mix2 can give to K8-S; it decides with the full argument list and ignores the scratch otherwise)
+    if (P < CM_PT || Ci < (bf16 ? 32 : 128) || Ci % CMS_KC || Co % 64) return 0;
+    return 6LL * Ci * Co;
+}
+
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s) {
+                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s, void* ws, size_t ws_bytes) {
     ChannelMixArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.Ci = Ci; a.Co = Co; a.P = P; a.C1 = Ci; a.Co1 = Co;
     a.transpose_w = transpose_w; a.accumulate = accumulate; a.act_in = act_in; a.dgelu_of = dgelu_of; a.bf16 = bf16;
+    a.ws = ws; a.ws_bytes = ws_bytes;
     return launch_channel_mix2(a, s);
 }
 

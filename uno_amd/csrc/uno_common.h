@@ -284,13 +284,16 @@ struct ChannelMixArgs {
     const float* proj_w; const float* proj_b; void* proj_out;       // fused one-channel projection of gelu(y) (Co <= 64), or nullptr
     int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
     PixelWindow win;                                                // all operands on one window (proj_out: one plane per batch entry)
+    void* ws = nullptr; size_t ws_bytes = 0;                       // optional scratch (uno_scratch_provide): 6 Ci Co bytes let K8-S run on pre-split weights
     int act_cols = 0, act_pitch = 0; long long act_plane = 0;       // y_act on padded planes (generic kernel): the P = H * act_cols dense
                                                                     // pixels land in the top-left corner of act_plane / act_pitch rows
 };
 int launch_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, hipStream_t s);       // pointwise_fused.hip
 int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s);
 int launch_channel_mix(const void* x, const float* w, const float* bias, void* y, int B, int Ci, int Co, long long P,
-                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s);
+                       int transpose_w, int accumulate, int act_in, const void* dgelu_of, int bf16, hipStream_t s, void* ws = nullptr,
+                       size_t ws_bytes = 0);
+long long channel_mix_ws_bytes(int Ci, int Co, long long P, int bf16);       // scratch that lets a call of this shape use pre-split weights (0: none)
 int launch_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n,
                       const int* is_complex, double lr, double beta1, double beta2, double eps, double wd, int step, hipStream_t s,
                       const float* dev_scalars = nullptr);
