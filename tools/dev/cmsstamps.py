@@ -1,4 +1,4 @@
-"""Per-phase cycle stamps of K8-S (CT = 128, f32, weights split per workgroup) for one layer shape, from a -DUNO_CMS_DEV variant:
+"""Per-phase cycle stamps of K8-S (CT = 128, f32; NO_SHADOW=1: weights split per workgroup) for one layer shape, from a -DUNO_CMS_DEV variant:
 python tools/dev/cmsstamps.py <variant.so> Ci Co P [B]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -13,7 +13,8 @@ os.environ["UNO_CMS_EXP"] = "64"
 os.environ["UNO_CMS_STAMPS"] = hex(buf.data_ptr())
 from uno_amd import _native
 _native.LIB_PATH = os.path.abspath(lib)
-_native._mix_scratch.__init__ = lambda self, device, *a: (setattr(self, "bytes", 0), setattr(self, "device", device), setattr(self, "buf", None))[0]
+if os.environ.get("NO_SHADOW"):          # weights split per workgroup (WM = 0) instead of the pre-split form
+    _native._mix_scratch.__init__ = lambda self, device, *a: (setattr(self, "bytes", 0), setattr(self, "device", device), setattr(self, "buf", None))[0]
 x = torch.randn(B, Ci, P, device=dev)
 w = (torch.randn(Co, Ci, device=dev) / Ci ** 0.5)
 bias = torch.randn(Co, device=dev)

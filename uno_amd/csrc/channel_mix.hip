@@ -831,13 +831,17 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
         auto half_step = [&](int c, float4* r, bool& act) {      // chunk c sits in register set r; r is refilled with chunk c + 2
             store_x(r, act);
             store_w();
+            CMS_STAMP(tS);
             __syncthreads();
+            CMS_STAMP(tB1);
             if (c + 1 < nchunk) load_w((c + 1) * CMS_KC);
             if (c + 2 < nchunk) load_x((c + 2) * CMS_KC, r, act);
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __builtin_amdgcn_sched_barrier(0);
+            CMS_STAMP(tC);
             __syncthreads();
+            CMS_STAMP(tB2);
         };
         load_x(0, rx, act_ld);
         load_w(0);
@@ -1109,7 +1113,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
 #define UNO_CMS_T(BF_, CT_) do { if (shadow) { if (act_in) UNO_CMS(BF_, 2, 0, CT_, true); else UNO_CMS(BF_, 2, 0, CT_, false); } \
                                  else if (act_in) UNO_CMS(BF_, 0, 0, CT_, true); else if (trw) UNO_CMS(BF_, 1, 0, CT_, false); else UNO_CMS(BF_, 0, 0, CT_, false); } while (0)
 #ifdef UNO_CMS_DEV          // development build: knock-out / stamp instantiations (f32 activations, 128-channel tiles) selected by UNO_CMS_EXP
-#define UNO_CMS_X(XP_) case XP_: if (trw) UNO_CMS(false, 1, XP_, 128, false); else UNO_CMS(false, 0, XP_, 128, false); break;
+#define UNO_CMS_X(XP_) case XP_: if (shadow && XP_ == 64) UNO_CMS(false, 2, 64, 128, false); else if (trw) UNO_CMS(false, 1, XP_, 128, false); else UNO_CMS(false, 0, XP_, 128, false); break;
             if (!bf16 && cms_exp && split && !act_in) {
                 switch (cms_exp) {
                     UNO_CMS_X(1) UNO_CMS_X(2) UNO_CMS_X(4) UNO_CMS_X(6) UNO_CMS_X(8) UNO_CMS_X(16) UNO_CMS_X(31) UNO_CMS_X(64) UNO_CMS_X(70)
