@@ -1264,7 +1264,9 @@ constexpr int CWV_PK = 64;
 constexpr int CWV_S = CWV_PK + 4;       // 272-byte rows: 16-byte aligned for ds_write_b128; fragment reads hit banks 4 r16 + kk,
                                         // distinct over all 64 lanes (gfx950 LDS: 64 banks; a stride of 66 cost one conflict cycle per read)
 
-template <bool ACTX, bool BF>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
+// NI: 16-channel tiles of the INPUT side per workgroup, 4 or - layers with at most 32 input channels (the lift's fc0: 32 -> 64 at full
+// resolution) - 2: the 64-wide tile spent half of its MFMAs, X loads, GELUs and LDS writes on channels that do not exist.
+template <bool ACTX, bool BF, int NI = 4>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
 __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
     using T = typename IoElem<BF>::type;
     constexpr int ES = BF ? 2 : 4;          // bytes per element
@@ -1314,14 +1316,18 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
             if constexpr (BF) {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 tg = __builtin_amdgcn_raw_buffer_load_b64(rg_, (min(o0 + row, p.Co - 1) * PS + pc) * 2, 0, 0);
-                const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(il + row, Cs - 1) * PS + pc) * 2, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x << 16), __uint_as_float(tg.x & 0xffff0000u), __uint_as_float(tg.y << 16), __uint_as_float(tg.y & 0xffff0000u));
-                rxv[u] = make_float4(__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u), __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u));
+                if (u < NI) {
+                    const u32x2 tx = __builtin_amdgcn_raw_buffer_load_b64(rx_, (min(il + row, Cs - 1) * PS + pc) * 2, 0, 0);
+                    rxv[u] = make_float4(__uint_as_float(tx.x << 16), __uint_as_float(tx.x & 0xffff0000u), __uint_as_float(tx.y << 16), __uint_as_float(tx.y & 0xffff0000u));
+                }
             } else {
                 const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * PS + pc) * 4, 0, 0);
-                const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(il + row, Cs - 1) * PS + pc) * 4, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
-                rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
+                if (u < NI) {
+                    const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(il + row, Cs - 1) * PS + pc) * 4, 0, 0);
+                    rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
+                }
             }
         }
     };
@@ -1337,17 +1343,19 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
             const float4 g = shifted(rg[u], o0 + row < p.Co);
-            float4 v = shifted(rxv[u], il + row < Cs);
-            if constexpr (ACTX) { if (actx) v = cm_gelu4(v); }             // gelu(0) = 0: the zero fill survives
             *reinterpret_cast<float4*>(sG + row * CWV_S + c4) = g;
-            *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = v;
             bs[u] += (g.x + g.y) + (g.z + g.w);
+            if (u < NI) {
+                float4 v = shifted(rxv[u], il + row < Cs);
+                if constexpr (ACTX) { if (actx) v = cm_gelu4(v); }             // gelu(0) = 0: the zero fill survives
+                *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = v;
+            }
         }
     };
 
-    f32x4 acc[4];
+    f32x4 acc[NI];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+    for (int nt = 0; nt < NI; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
 
     if (c_begin < c_end) load_chunk(c_begin);
     for (int c = c_begin; c < c_end; ++c) {
@@ -1359,7 +1367,7 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
         for (int ks = 0; ks < CWV_PK / 4; ++ks) {
             const float a = sG[(16 * wave + r16) * CWV_S + 4 * ks + kk];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NI; ++nt)
                 acc[nt] = mfma16(a, sXc[(16 * nt + r16) * CWV_S + 4 * ks + kk], acc[nt]);
         }
         __syncthreads();
@@ -1371,7 +1379,7 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
         const int o = o0 + 16 * wave + 4 * kk + r;
         if (o < p.Co) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NI; ++nt) {
                 const int i = i0 + 16 * nt + r16;
                 if (i < p.Ci) part[(size_t)o * (p.Ci + 1) + i] = acc[nt][r];
             }
@@ -1832,6 +1840,11 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
             if (to == CWS_T) { if (act_x) UNO_CWS(true, 4); else UNO_CWS(false, 4); }
             else { if (act_x) UNO_CWS(true, 2); else UNO_CWS(false, 2); }
 #undef UNO_CWS
+        } else if (pk == CWV_PK && Ci <= 32) {           // (one tile of input channels: the narrow form)
+            if (act_x) { if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, true, 2>), gv, dim3(256), 0, s, p, npc, cps);
+                         else hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false, 2>), gv, dim3(256), 0, s, p, npc, cps); }
+            else { if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<false, true, 2>), gv, dim3(256), 0, s, p, npc, cps);
+                   else hipLaunchKernelGGL((channel_wgrad_vec_kernel<false, false, 2>), gv, dim3(256), 0, s, p, npc, cps); }
         } else if (pk == CWV_PK && act_x) {
             if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, true>), gv, dim3(256), 0, s, p, npc, cps);
             else hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false>), gv, dim3(256), 0, s, p, npc, cps);
