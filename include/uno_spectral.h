@@ -253,11 +253,16 @@ int uno_gelu_project_backward_win(const float* pre, const float* w, const float*
  * call leaves untouched in a fresh gradient tensor). */
 int uno_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, void* stream);
 /* The end of the lift with the domain padding (reference darcy_flow_uno2d.py:100-107: `x_fc0 = self.fc0(x_fc); x_fc0 = F.gelu(x_fc0)`,
- * permute, `F.pad(x_fc0, [0, padding, 0, padding])`) in one pass: y (B, Co, H, W) = Wm [gelu](x (B, Ci, H, W)) + bias - kept, its GELU
- * derivative is needed backward - and y_act (B, Co, Hp, Wp) = zero-pad(gelu(y)) at the end of both axes, written by the layer's own
- * store epilogue (no second pass over y).  260 <= W <= Wp, H * W < 2^24, float32. */
+ * permute, `F.pad(x_fc0, [0, padding, 0, padding])`) in one pass: y_act (B, Co, Hp, Wp) = zero-pad(gelu(Wm [gelu](x (B, Ci, H, W)) + bias))
+ * at the end of both axes, written by the layer's own store epilogue; y (B, Co, H, W) or NULL: the pre-activation result, kept only
+ * if the caller wants it.  Backward without it: uno_channel_mix_dgelu_padded RECOMPUTES the layer (Ci << Co: reading x again is
+ * half of what storing and re-reading y costs) and returns gz (B, Co, H, W) = gelu'(Wm [gelu](x) + bias) * g_padded[..., :H, :W] -
+ * the gradient at the layer's output, ready for uno_channel_mix (transposed) / uno_channel_wgrad.
+ * 260 <= W <= Wp, H * W < 2^24, float32. */
 int uno_channel_mix_act_padded(const float* x, const float* w, const float* bias, float* y, float* y_act, int B, int Ci, int Co, int H,
                                int W, int Hp, int Wp, int act_in, void* stream);
+int uno_channel_mix_dgelu_padded(const float* x, const float* w, const float* bias, const float* g_padded, float* gz, int B, int Ci,
+                                 int Co, int H, int W, int Hp, int Wp, int act_in, void* stream);
 
 /* GELU followed by zero padding at the end of both axes (the lift's last activation + domain padding, reference
  * darcy_flow_uno2d.py:103-107): backward = 0: out (n_img, Hp, Wp) = pad(gelu(s (n_img, H, W))), gy ignored;

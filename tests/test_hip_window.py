@@ -177,6 +177,14 @@ def test_lift_with_padded_activation(B, Ci, Co, H, W, ph, pw):
     ar = torch.nn.functional.pad(torch.nn.functional.gelu(yr), [0, pw, 0, ph])
     assert rel(y, yr) < 2e-6 and act.shape == ar.shape and rel(act, ar) < 2e-6
     assert float(act[:, :, H:].abs().max() if ph else 0) == 0.0 and float(act[:, :, :, W:].abs().max() if pw else 0) == 0.0
+    # without the pre-activation result: the same activation, and the backward kernel that recomputes it
+    none, act2 = _native.channel_mix_act_padded(x, w, b, H + ph, W + pw, act_in=True, keep_y=False)
+    assert none is None and torch.equal(act2, act)
+    gp = torch.randn(B, Co, H + ph, W + pw, generator=g).cuda()
+    gz = _native.channel_mix_dgelu_padded(x, w, b, gp, act_in=True)
+    yd = yr.clone().requires_grad_(True)
+    torch.nn.functional.gelu(yd).backward(gp[:, :, :H, :W].double())
+    assert gz.shape == (B, Co, H, W) and rel(gz, yd.grad) < 3e-6
 
 
 def test_gelu_channel_mix_pad_autograd_matches_the_two_step_form():

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "uno_channel_mix_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong, _i]),
     "uno_clear_border": (C.c_int, [_fp, C.c_longlong, _i, _i, _i, _i, _fp]),
     "uno_channel_mix_act_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
+    "uno_channel_mix_dgelu_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "uno_channel_wgrad2_win": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_backward_win": (C.c_int, [_fp] * 7 + [_i, _i, _i, _i, _i, C.c_longlong, _fp]),
     "uno_channel_wgrad_finish": (C.c_int, [_fp, _fp, _fp, _i, _i, C.c_longlong, _i, _fp]),
@@ -570,8 +571,9 @@ def channel_mix_act_padded_ok(x, Hp: int, Wp: int) -> bool:
     return x.dtype == torch.float32 and 260 <= W <= Wp and H <= Hp and H * W < (1 << 24)
 
 
-def channel_mix_act_padded(x, w, bias, Hp: int, Wp: int, act_in: bool = False):
-    """x (B, Ci, H, W) f32, w (Co, Ci) -> y (B, Co, H, W) = w . [gelu](x) + bias and act (B, Co, Hp, Wp) = zero-pad(gelu(y))."""
+def channel_mix_act_padded(x, w, bias, Hp: int, Wp: int, act_in: bool = False, keep_y: bool = True):
+    """x (B, Ci, H, W) f32, w (Co, Ci) -> y (B, Co, H, W) = w . [gelu](x) + bias (None with keep_y=False: not stored) and
+    act (B, Co, Hp, Wp) = zero-pad(gelu(y))."""
     _require(x, torch.float32, "x")
     _require(w, torch.float32, "weight")
     if bias is not None:
@@ -580,13 +582,34 @@ def channel_mix_act_padded(x, w, bias, Hp: int, Wp: int, act_in: bool = False):
     Co = w.shape[0]
     if w.shape[1] != Ci:
         raise RuntimeError(f"uno_amd: weight {tuple(w.shape)} does not match {Ci} input channels")
-    y = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device)
+    y = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device) if keep_y else None
     act = torch.empty((B, Co, Hp, Wp), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib().uno_channel_mix_act_padded(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(y), _ptr(act),
+        rc = lib().uno_channel_mix_act_padded(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0),
+                                              _ptr(y) if keep_y else C.c_void_p(0), _ptr(act),
                                               B, Ci, Co, H, W, int(Hp), int(Wp), 1 if act_in else 0, _stream(x))
     _check(rc, "uno_channel_mix_act_padded")
     return y, act
+
+
+def channel_mix_dgelu_padded(x, w, bias, g_padded, act_in: bool = False):
+    """gz (B, Co, H, W) = gelu'(w . [gelu](x) + bias) * g_padded[..., :H, :W]: the layer recomputed from its input x (B, Ci, H, W)."""
+    _require(x, torch.float32, "x")
+    _require(w, torch.float32, "weight")
+    _require(g_padded, torch.float32, "grad_output")
+    if bias is not None:
+        _require(bias, torch.float32, "bias")
+    B, Ci, H, W = x.shape
+    Co = w.shape[0]
+    if w.shape[1] != Ci or g_padded.dim() != 4 or g_padded.shape[:2] != (B, Co) or g_padded.shape[2] < H or g_padded.shape[3] < W:
+        raise RuntimeError("uno_amd: weight / grad_output do not match the layer")
+    Hp, Wp = g_padded.shape[2:]
+    gz = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().uno_channel_mix_dgelu_padded(_ptr(x), _ptr(w), _ptr(bias) if bias is not None else C.c_void_p(0), _ptr(g_padded), _ptr(gz),
+                                                B, Ci, Co, H, W, int(Hp), int(Wp), 1 if act_in else 0, _stream(x))
+    _check(rc, "uno_channel_mix_dgelu_padded")
+    return gz
 
 
 def channel_mix2_ok(C1: int, Co1, Co: int, P: int) -> bool:

@@ -469,20 +469,32 @@ int uno_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int
     return launch_clear_border(t, n_planes, Hp, Wp, rows, cols, (hipStream_t)stream);
 }
 
-int uno_channel_mix_act_padded(const float* x, const float* w, const float* bias, float* y, float* y_act, int B, int Ci, int Co, int H, int W,
-                               int Hp, int Wp, int act_in, void* stream) {
+static int lift_padded(const char* who, const float* x, const float* w, const float* bias, float* y, float* y_act, const float* gmul, int B,
+                       int Ci, int Co, int H, int W, int Hp, int Wp, int act_in, void* stream) {
     if (B < 0 || Ci < 1 || Co < 1 || H < 1 || W < 1 || Hp < H || Wp < W) {
-        set_error("uno_channel_mix_act_padded: bad sizes B=%d Ci=%d Co=%d (%d, %d) -> (%d, %d)", B, Ci, Co, H, W, Hp, Wp);
+        set_error("%s: bad sizes B=%d Ci=%d Co=%d (%d, %d) -> (%d, %d)", who, B, Ci, Co, H, W, Hp, Wp);
         return -1;
     }
     if (B == 0) return 0;
-    if (!x || !w || !y || !y_act) { set_error("uno_channel_mix_act_padded: null pointer"); return -1; }
+    if (!x || !w || (!y && !y_act) || (gmul && !y)) { set_error("%s: null pointer", who); return -1; }
     ChannelMixArgs a{};
-    a.x = x; a.w = w; a.bias = bias; a.y = y; a.y_act = y_act;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.y_act = y_act; a.gmul = gmul;
     a.B = B; a.Ci = Ci; a.Co = Co; a.C1 = Ci; a.Co1 = Co; a.P = (long long)H * W; a.act_in = act_in;
     a.act_cols = W; a.act_pitch = Wp; a.act_plane = (long long)Hp * Wp;
     if (int rc = launch_channel_mix2(a, (hipStream_t)stream)) return rc;
-    return launch_clear_border(y_act, (long long)B * Co, Hp, Wp, H, W, (hipStream_t)stream);
+    return y_act ? launch_clear_border(y_act, (long long)B * Co, Hp, Wp, H, W, (hipStream_t)stream) : 0;
+}
+
+int uno_channel_mix_act_padded(const float* x, const float* w, const float* bias, float* y, float* y_act, int B, int Ci, int Co, int H, int W,
+                               int Hp, int Wp, int act_in, void* stream) {
+    if (!y_act) { set_error("uno_channel_mix_act_padded: null pointer"); return -1; }
+    return lift_padded("uno_channel_mix_act_padded", x, w, bias, y, y_act, nullptr, B, Ci, Co, H, W, Hp, Wp, act_in, stream);
+}
+
+int uno_channel_mix_dgelu_padded(const float* x, const float* w, const float* bias, const float* g_padded, float* gz, int B, int Ci, int Co,
+                                 int H, int W, int Hp, int Wp, int act_in, void* stream) {
+    if (!g_padded || !gz) { set_error("uno_channel_mix_dgelu_padded: null pointer"); return -1; }
+    return lift_padded("uno_channel_mix_dgelu_padded", x, w, bias, gz, nullptr, g_padded, B, Ci, Co, H, W, Hp, Wp, act_in, stream);
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {

@@ -44,6 +44,12 @@ __device__ __forceinline__ float cm_dgelu(float x) { return uno_dgelu(x); }
 __device__ __forceinline__ float4 cm_gelu4(float4 v) { return make_float4(cm_gelu(v.x), cm_gelu(v.y), cm_gelu(v.z), cm_gelu(v.w)); }
 // four consecutive logical pixels px .. px + 3 through a run map whose rows need not be a multiple of 4 long
 template <typename T>
+__device__ __forceinline__ float4 load4_run(const T* plane, const PixRun& run, int px) {
+    const int f0 = run(px), f3 = run(px + 3);
+    if (f3 - f0 == 3) return io_ld4(plane + f0);
+    return make_float4(io_widen(plane[f0]), io_widen(plane[run(px + 1)]), io_widen(plane[run(px + 2)]), io_widen(plane[f3]));
+}
+template <typename T>
 __device__ __forceinline__ void store4_run(T* plane, const PixRun& run, int px, float a, float b, float c, float d) {
     const int f0 = run(px), f3 = run(px + 3);
     if (f3 - f0 == 3) { io_store4(plane + f0, a, b, c, d); return; }
@@ -66,6 +72,9 @@ struct ChannelMixParams {
     void* proj_out;         // re-reading y; needs all output channels in ONE 64-channel tile (Co <= 64)
     int B, Ci, Co, P;
     PixMap pm;              // plane stride of every operand + the pixel window (dense: pm.PS == P); generic and split kernels only
+    const void* gmul;       // nullptr, or (B, Co, padded plane) read through pm_act: y = gelu'(product + bias) * gmul - the gradient of the lift's
+                            // last pre-activation RECOMPUTED from the layer's input instead of stored (generic kernel, one destination)
+    int store_y;            // 0: only y_act is written (the padded-activation call that does not keep the pre-activation result)
     PixMap pm_act;          // y_act's OWN map when pm_act.rl != 0 (generic kernel): the dense pixels of an H x W grid go to the top-left
                             // corner of (Hp, Wp) planes - rl = W (any width: a lane's four pixels may straddle a row end), skip = Wp - W
     int C1, Co1;
@@ -115,6 +124,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     const int APS = act_map ? p.pm_act.PS : PS;
     const PixRun arun = act_map ? pix_run(p.pm_act, p0) : run;
     T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * APS : nullptr;
+    const T* const gall = p.gmul ? reinterpret_cast<const T*>(p.gmul) + (size_t)b * p.Co * APS : nullptr;
+    const bool store_y = p.store_y != 0;
     bool act_ld = ACT;                           // the chunk in the staging registers comes from the activated source
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
@@ -279,7 +290,11 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                         if (dg) { const float d = cm_dgelu(pr4[i]); w4[i] = p.accumulate == 2 ? w4[i] * d : fmaf(r4[i], d, o4[i]); }
                     }
                 }
-                io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
+                if (gall) {
+                    const float4 g4 = load4_run(gall + aoff[it], arun, p0 + c4);
+                    w4[0] = cm_dgelu(w4[0]) * g4.x; w4[1] = cm_dgelu(w4[1]) * g4.y; w4[2] = cm_dgelu(w4[2]) * g4.z; w4[3] = cm_dgelu(w4[3]) * g4.w;
+                }
+                if (store_y) io_store4(dst[it], w4[0], w4[1], w4[2], w4[3]);
                 if (aall) store4_run(aall + aoff[it], arun, p0 + c4, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
                 if (p.proj_w) {
                     const float pwv = __shfl(pw_l, 8 * h + row);
@@ -319,6 +334,7 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
         const float pwv = p.proj_w ? p.proj_w[o] : 0.f;
         T* yrow = ydst + (size_t)(o - dd.ob) * PS;
         T* arow = aall ? aall + (size_t)o * APS : nullptr;
+        const T* grow = gall ? gall + (size_t)o * APS : nullptr;
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk, fx = run(px);        // logical pixel (guards), offset inside the plane
@@ -334,7 +350,11 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                     const float d = dg ? cm_dgelu(pr4[r]) : 1.f;
                     w4[r] = p.accumulate == 2 ? (w4[r] + (acc[mt][r] + bv)) * d : w4[r] + (acc[mt][r] + bv) * d;
                 }
-                io_store4(yrow + fx, w4[0], w4[1], w4[2], w4[3]);
+                if (grow) {
+                    const float4 g4 = load4_run(grow, arun, px);
+                    w4[0] = cm_dgelu(w4[0]) * g4.x; w4[1] = cm_dgelu(w4[1]) * g4.y; w4[2] = cm_dgelu(w4[2]) * g4.z; w4[3] = cm_dgelu(w4[3]) * g4.w;
+                }
+                if (store_y) io_store4(yrow + fx, w4[0], w4[1], w4[2], w4[3]);
                 if (arow) store4_run(arow, arun, px, cm_gelu(w4[0]), cm_gelu(w4[1]), cm_gelu(w4[2]), cm_gelu(w4[3]));
                 if (p.proj_w) {
 #pragma unroll
@@ -345,8 +365,9 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 for (int r = 0; r < 4; ++r)
                     if (px + r < p.P) {
                         const float d = dg ? cm_dgelu(io_widen(drow[fx + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[fx + r]) : 0.f;
-                        const float v = p.accumulate == 2 ? (o1 + (acc[mt][r] + bv)) * d : o1 + (acc[mt][r] + bv) * d;
-                        io_store1(yrow + fx + r, v);
+                        float v = p.accumulate == 2 ? (o1 + (acc[mt][r] + bv)) * d : o1 + (acc[mt][r] + bv) * d;
+                        if (grow) v = cm_dgelu(v) * io_widen(grow[arun(px + r)]);
+                        if (store_y) io_store1(yrow + fx + r, v);
                         if (arow) io_store1(arow + arun(px + r), cm_gelu(v));
                         if (p.proj_w) pv[mt][r] = pwv * cm_gelu(v);
                     }
@@ -1013,6 +1034,8 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     if (p.accumulate == 2 && !a.dgelu_of) { set_error("channel_mix: accumulate = 2 (gelu' on the completed sum) needs dgelu_of"); return -2; }
     p.dgelu_of = a.dgelu_of;
     p.x = a.x; p.x2 = a.x2; p.w = a.w; p.bias = a.bias; p.y = a.y; p.y2 = a.y2; p.y_act = a.y_act;
+    p.gmul = a.gmul; p.store_y = a.y ? 1 : 0;
+    if (!a.y) p.y = a.y_act;            // (never stored through: address arithmetic only)
     p.proj_w = a.proj_w; p.proj_b = a.proj_b; p.proj_out = a.proj_out;
     if (a.proj_w && (!a.proj_out || Co > CM_MT || two_dst || a.dgelu_of)) {
         set_error("channel_mix: the fused projection needs proj_out, Co <= %d, one destination and no dgelu_of", CM_MT);
@@ -1027,9 +1050,9 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const bool act_pad = a.act_cols != 0;
     p.pm_act = PixMap{0, 0, 0, 0u};
     if (act_pad) {
-        if (!a.y_act || windowed || bf16 || a.act_cols < 260 || a.act_pitch < a.act_cols || P % a.act_cols || P >= (1LL << 24) ||
+        if ((!a.y_act && !a.gmul) || (a.y_act && a.gmul) || (!a.y && !a.y_act) || a.accumulate || two_dst || a.dgelu_of || a.proj_w || windowed || bf16 || a.act_cols < 260 || a.act_pitch < a.act_cols || P % a.act_cols || P >= (1LL << 24) ||
             a.act_plane < (P / a.act_cols) * (long long)a.act_pitch || (long long)Co * a.act_plane >= (1LL << 31)) {
-            set_error("channel_mix: the padded activation needs y_act, float32, dense operands, 260 <= W <= Wp, H * W < 2^24 pixels");
+            set_error("channel_mix: the padded forms take y_act OR gmul, one plain destination, float32, dense operands, 260 <= W <= Wp, H * W < 2^24 pixels");
             return -2;
         }
         p.pm_act = PixMap{(int)a.act_plane, a.act_cols, a.act_pitch - a.act_cols, (unsigned)(((1ULL << 40) + a.act_cols - 1) / (unsigned long long)a.act_cols)};
@@ -1098,7 +1121,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
         ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
-                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + (a.y ? Co : 0) + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.gmul ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
         if (split64 || split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
             const bool trw = p.w_so == 1 && p.w_si != 1;

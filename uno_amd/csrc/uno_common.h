@@ -285,6 +285,7 @@ struct ChannelMixArgs {
     int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
     PixelWindow win;                                                // all operands on one window (proj_out: one plane per batch entry)
     void* ws = nullptr; size_t ws_bytes = 0;                       // optional scratch (uno_scratch_provide): 6 Ci Co bytes let K8-S run on pre-split weights
+    const void* gmul = nullptr;                                     // y = gelu'(product + bias) * gmul, gmul on the padded planes described below
     int act_cols = 0, act_pitch = 0; long long act_plane = 0;       // y_act on padded planes (generic kernel): the P = H * act_cols dense
                                                                     // pixels land in the top-left corner of act_plane / act_pitch rows
 };

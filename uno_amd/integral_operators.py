@@ -881,15 +881,17 @@ def gelu_channel_mix(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
 
 class _GeluChannelMixPadFn(torch.autograd.Function):
     """zero-pad(gelu(W . gelu(pre) + bias)): the second lift layer, its activation and the domain padding (reference
-    darcy_flow_uno2d.py:100-107) from ONE forward kernel - the layer's store epilogue writes the padded activation next to the
-    pre-activation result it keeps for the backward pass (uno_channel_mix_act_padded); backward: K12 (gelu' x cropped gradient), then
-    the layer's two gradient kernels as in _GeluChannelMixFn."""
+    darcy_flow_uno2d.py:100-107) from ONE forward kernel - the layer's store epilogue writes the padded activation and nothing else
+    (uno_channel_mix_act_padded without y).  The pre-activation result is not kept: the backward pass RECOMPUTES it from the layer's
+    input (32 channels against the 64 it would store and re-read) inside the kernel that multiplies gelu' into the cropped
+    gradient (uno_channel_mix_dgelu_padded), then runs the layer's two gradient kernels as in _GeluChannelMixFn."""
 
     @staticmethod
     def forward(ctx, pre, w, bias, Hp, Wp, leaves=None):
         pre, w = _plain(pre), _plain(w)
-        z, act = _native.channel_mix_act_padded(pre, w, None if bias is None else _plain(bias), Hp, Wp, act_in=True)
-        ctx.save_for_backward(pre, w, z)
+        bias = None if bias is None else _plain(bias)
+        _, act = _native.channel_mix_act_padded(pre, w, bias, Hp, Wp, act_in=True, keep_y=False)
+        ctx.save_for_backward(pre, w, bias)
         ctx.has_bias = bias is not None
         ctx.leaves = leaves
         return act
@@ -897,9 +899,9 @@ class _GeluChannelMixPadFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gact):
-        pre, w, z = ctx.saved_tensors
-        B, Ci, Co = pre.shape[0], pre.shape[1], z.shape[1]
-        gz = _native.gelu_pad_backward(z, _plain(gact)).view(B, Co, -1)
+        pre, w, bias = ctx.saved_tensors
+        B, Ci, Co = pre.shape[0], pre.shape[1], w.shape[0]
+        gz = _native.channel_mix_dgelu_padded(pre, w, bias, _plain(gact), act_in=True).view(B, Co, -1)
         pre3 = pre.view(B, Ci, -1)
         g_pre = _native.channel_mix(gz, w, None, transpose_w=True, dgelu_of=pre3).view(pre.shape) if ctx.needs_input_grad[0] else None
         gw, gb = _wgrad_into(ctx.leaves, gz, pre3, None, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], act_x=True)
