@@ -263,6 +263,19 @@ int uno_channel_mix_act_padded(const float* x, const float* w, const float* bias
                                int W, int Hp, int Wp, int act_in, void* stream);
 int uno_channel_mix_dgelu_padded(const float* x, const float* w, const float* bias, const float* g_padded, float* gz, int B, int Ci,
                                  int Co, int H, int W, int Hp, int Wp, int act_in, void* stream);
+/* The whole lift of the 2-D models (reference darcy_flow_uno2d.py:98-107): x (B, Cin <= 3, H, W) = [a(x, y), x, y] channels-first,
+ *   h = fc_n1(x) (Cm = 16 or 32 channels; w1 (Cm, Cin), b1 (Cm) or NULL),  z = fc0(gelu(h)) (w0 (Co, Cm), b0 or NULL),
+ *   act (B, Co, Hp, Wp) = zero-pad(gelu(z))
+ * with NEITHER h nor z stored: h is 12 bytes per pixel of input against 128 of output, so every kernel that needs it - fc0's forward,
+ * the recomputation in the backward pass, gelu'(h) of the input gradient, gelu(h) of the weight gradient - evaluates it from x.
+ * uno_lift_backward: g_act (B, Co, Hp, Wp) -> gw1 (Cm, Cin), gb1 (Cm) or NULL, gw0 (Co, Cm), gb0 (Co) or NULL (written, not
+ * accumulated; no gradient for x - it is data); ws: uno_lift_bwd_ws_bytes() bytes.  260 <= W <= Wp, H * W < 2^24, float32. */
+int uno_lift_forward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin,
+                     int Cm, int Co, int H, int W, int Hp, int Wp, void* stream);
+long long uno_lift_bwd_ws_bytes(int B, int Cin, int Cm, int Co, int H, int W);
+int uno_lift_backward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g_act, float* gw1,
+                      float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp,
+                      void* stream);
 
 /* GELU followed by zero padding at the end of both axes (the lift's last activation + domain padding, reference
  * darcy_flow_uno2d.py:103-107): backward = 0: out (n_img, Hp, Wp) = pad(gelu(s (n_img, H, W))), gy ignored;

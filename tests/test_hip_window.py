@@ -214,3 +214,49 @@ def test_clear_border():
     assert torch.equal(_native.clear_border(t, 17, 29), ref)
     t2 = torch.randn(2, 7, 9).cuda()
     assert torch.equal(_native.clear_border(t2.clone(), 7, 9), t2)
+
+
+@pytest.mark.parametrize("B,Cin,Cm,Co,H,W,ph,pw,bias", [(2, 3, 32, 64, 37, 283, 6, 6, True), (1, 3, 32, 64, 421, 421, 25, 25, True), (2, 1, 16, 24, 9, 300, 0, 5, True),
+                                                       (2, 2, 32, 40, 5, 264, 2, 0, False), (3, 3, 16, 128, 4, 260, 1, 1, True)])
+def test_whole_lift_without_stored_intermediates(B, Cin, Cm, Co, H, W, ph, pw, bias):
+    """uno_lift_forward / uno_lift_backward against float64 torch: F.pad(gelu(fc0(gelu(fc_n1(x))))) and the four parameter gradients, with
+    the first layer's output virtual in every kernel (interior and edge pixel tiles, partial channel tiles, 1 - 3 real channels)"""
+    from uno_amd import _native
+    gen = torch.Generator().manual_seed(B + Cin + Cm + Co + H + W)
+    x = torch.randn(B, Cin, H, W, generator=gen).cuda()
+    w1, w0 = torch.randn(Cm, Cin, generator=gen).cuda(), (torch.randn(Co, Cm, generator=gen) / Cm ** 0.5).cuda()
+    b1, b0 = (torch.randn(Cm, generator=gen).cuda(), torch.randn(Co, generator=gen).cuda()) if bias else (None, None)
+    act = _native.lift_forward(x, w1, b1, w0, b0, H + ph, W + pw)
+    d = [t.double().requires_grad_(True) if t is not None else None for t in (w1, b1, w0, b0)]
+    F = torch.nn.functional
+    h = torch.einsum("mk,bkhw->bmhw", d[0], x.double()) + (d[1].view(1, -1, 1, 1) if bias else 0)
+    z = torch.einsum("om,bmhw->bohw", d[2], F.gelu(h)) + (d[3].view(1, -1, 1, 1) if bias else 0)
+    ref = F.pad(F.gelu(z), [0, pw, 0, ph])
+    assert act.shape == ref.shape and rel(act, ref.detach()) < 3e-6
+    assert float(act[:, :, H:].abs().max() if ph else 0) == 0.0 and float(act[:, :, :, W:].abs().max() if pw else 0) == 0.0
+    g = torch.randn(act.shape, generator=gen).cuda()
+    ref.backward(g.double())
+    got = _native.lift_backward(x, w1, b1, w0, b0, g)
+    for a, r in zip(got, d):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert rel(a, r.grad) < 3e-5
+
+
+def test_lift_gelu_pad_autograd_matches_layer_by_layer():
+    from uno_amd.integral_operators import channel_mix, gelu_channel_mix, gelu_pad2d, lift_gelu_pad
+    torch.manual_seed(9)
+    B, H, W, pad = 2, 33, 270, 7
+    x = torch.randn(B, 3, H, W).cuda()
+    gout = torch.randn(B, 64, H + pad, W + pad).cuda()
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(1)
+        f1, f0 = torch.nn.Linear(3, 32).cuda(), torch.nn.Linear(32, 64).cuda()
+        out = lift_gelu_pad(x, f1, f0, pad, pad) if fused else gelu_pad2d(gelu_channel_mix(channel_mix(x, f1.weight, f1.bias), f0.weight, f0.bias), pad, pad)
+        out.backward(gout)
+        res.append((out.detach(), [p.grad for p in (f1.weight, f1.bias, f0.weight, f0.bias)]))
+    (o1, g1), (o0, g0) = res
+    assert rel(o1, o0) < 2e-6
+    for a, b in zip(g1, g0):
+        assert rel(a, b) < 3e-5

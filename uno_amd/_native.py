@@ -58,6 +58,9 @@ _SIGNATURES = {
     "uno_channel_mix_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong, _i]),
     "uno_clear_border": (C.c_int, [_fp, C.c_longlong, _i, _i, _i, _i, _fp]),
     "uno_channel_mix_act_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
+    "uno_lift_forward": (C.c_int, [_fp] * 6 + [_i] * 8 + [_fp]),
+    "uno_lift_bwd_ws_bytes": (C.c_longlong, [_i] * 6),
+    "uno_lift_backward": (C.c_int, [_fp] * 11 + [_i] * 8 + [_fp]),
     "uno_channel_mix_dgelu_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "uno_channel_wgrad2_win": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_backward_win": (C.c_int, [_fp] * 7 + [_i, _i, _i, _i, _i, C.c_longlong, _fp]),
@@ -590,6 +593,53 @@ def channel_mix_act_padded(x, w, bias, Hp: int, Wp: int, act_in: bool = False, k
                                               B, Ci, Co, H, W, int(Hp), int(Wp), 1 if act_in else 0, _stream(x))
     _check(rc, "uno_channel_mix_act_padded")
     return y, act
+
+
+def lift_ok(x, w1, w0, Hp: int, Wp: int) -> bool:
+    """shape rules of uno_lift_forward / uno_lift_backward for x (B, Cin, H, W)"""
+    if x.dim() != 4 or x.dtype != torch.float32:
+        return False
+    H, W = x.shape[-2:]
+    return (1 <= x.shape[1] <= 3 and w1.shape[0] in (16, 32) and w1.shape[1] == x.shape[1] and w0.shape[1] == w1.shape[0]
+            and 260 <= W <= Wp and H <= Hp and H * W < (1 << 24))
+
+
+def lift_forward(x, w1, b1, w0, b0, Hp: int, Wp: int):
+    """act (B, Co, Hp, Wp) = zero-pad(gelu(w0 . gelu(w1 . x + b1) + b0)) - nothing else is stored (uno_lift_forward)."""
+    for t, n in ((x, "x"), (w1, "weight 1"), (w0, "weight 0")) + tuple((t, "bias") for t in (b1, b0) if t is not None):
+        _require(t, torch.float32, n)
+    B, Cin, H, W = x.shape
+    Cm, Co = w1.shape[0], w0.shape[0]
+    act = torch.empty((B, Co, Hp, Wp), dtype=x.dtype, device=x.device)
+    null = C.c_void_p(0)
+    with torch.cuda.device(x.device):
+        rc = lib().uno_lift_forward(_ptr(x), _ptr(w1), _ptr(b1) if b1 is not None else null, _ptr(w0), _ptr(b0) if b0 is not None else null,
+                                    _ptr(act), B, Cin, Cm, Co, H, W, int(Hp), int(Wp), _stream(x))
+    _check(rc, "uno_lift_forward")
+    return act
+
+
+def lift_backward(x, w1, b1, w0, b0, g_act):
+    """-> gw1 (Cm, Cin), gb1 (Cm) or None, gw0 (Co, Cm), gb0 (Co) or None (uno_lift_backward)."""
+    _require(g_act, torch.float32, "grad_output")
+    B, Cin, H, W = x.shape
+    Cm, Co = w1.shape[0], w0.shape[0]
+    Hp, Wp = g_act.shape[-2:]
+    if tuple(g_act.shape[:2]) != (B, Co):
+        raise RuntimeError("uno_amd: grad_output does not match the lift")
+    dev = x.device
+    gw1 = torch.empty((Cm, Cin), dtype=torch.float32, device=dev)
+    gw0 = torch.empty((Co, Cm), dtype=torch.float32, device=dev)
+    gb1 = torch.empty((Cm,), dtype=torch.float32, device=dev) if b1 is not None else None
+    gb0 = torch.empty((Co,), dtype=torch.float32, device=dev) if b0 is not None else None
+    null = C.c_void_p(0)
+    with torch.cuda.device(dev):
+        ws = torch.empty(max(1, lib().uno_lift_bwd_ws_bytes(B, Cin, Cm, Co, H, W)), dtype=torch.uint8, device=dev)
+        rc = lib().uno_lift_backward(_ptr(x), _ptr(w1), _ptr(b1) if b1 is not None else null, _ptr(w0), _ptr(b0) if b0 is not None else null,
+                                     _ptr(g_act), _ptr(gw1), _ptr(gb1) if gb1 is not None else null, _ptr(gw0),
+                                     _ptr(gb0) if gb0 is not None else null, _ptr(ws), B, Cin, Cm, Co, H, W, int(Hp), int(Wp), _stream(x))
+    _check(rc, "uno_lift_backward")
+    return gw1, gb1, gw0, gb0
 
 
 def channel_mix_dgelu_padded(x, w, bias, g_padded, act_in: bool = False):

@@ -497,6 +497,80 @@ int uno_channel_mix_dgelu_padded(const float* x, const float* w, const float* bi
     return lift_padded("uno_channel_mix_dgelu_padded", x, w, bias, gz, nullptr, g_padded, B, Ci, Co, H, W, Hp, Wp, act_in, stream);
 }
 
+// ---- the whole lift (reference darcy_flow_uno2d.py:98-107) with its first layer's output never stored
+static int lift_check(const char* who, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp) {
+    if (B < 0 || Cin < 1 || Cin > 3 || Cm < 5 || Cm > 32 || Cm % 16 || Co < 1 || H < 1 || W < 260 || Hp < H || Wp < W || (long long)H * W >= (1LL << 24)) {
+        set_error("%s: needs 1 .. 3 input channels, 16 or 32 middle channels, 260 <= W <= Wp, H <= Hp, H * W < 2^24 (got B=%d %d -> %d -> %d, (%d, %d) -> (%d, %d))",
+                  who, B, Cin, Cm, Co, H, W, Hp, Wp);
+        return -1;
+    }
+    return 0;
+}
+
+int uno_lift_forward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin, int Cm,
+                     int Co, int H, int W, int Hp, int Wp, void* stream) {
+    if (int rc = lift_check("uno_lift_forward", B, Cin, Cm, Co, H, W, Hp, Wp)) return rc;
+    if (B == 0) return 0;
+    if (!x || !w1 || !w0 || !act) { set_error("uno_lift_forward: null pointer"); return -1; }
+    ChannelMixArgs a{};
+    a.x = x; a.w = w0; a.bias = b0; a.y = nullptr; a.y_act = act;
+    a.B = B; a.Ci = Cm; a.Co = Co; a.C1 = Cm; a.Co1 = Co; a.P = (long long)H * W; a.act_in = 1;
+    a.act_cols = W; a.act_pitch = Wp; a.act_plane = (long long)Hp * Wp;
+    a.vh_x = x; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 1;
+    if (int rc = launch_channel_mix2(a, (hipStream_t)stream)) return rc;
+    return launch_clear_border(act, (long long)B * Co, Hp, Wp, H, W, (hipStream_t)stream);
+}
+
+// scratch of uno_lift_backward: gz (B, Co, H, W), g_h (B, Cm, H, W), then the larger of the two weight-gradient scratches
+static long long lift_wgrad_ws(int B, int Cin, int Cm, int Co, long long P) {
+    const long long a = 4LL * channel_wgrad_ws_floats(B, Cm, Co, P, nullptr), b = 4LL * channel_wgrad_ws_floats(B, Cin, Cm, P, nullptr);
+    return a > b ? a : b;
+}
+long long uno_lift_bwd_ws_bytes(int B, int Cin, int Cm, int Co, int H, int W) {
+    if (B < 1 || Cin < 1 || Cm < 1 || Co < 1 || H < 1 || W < 1) return 0;
+    const long long P = (long long)H * W;
+    return 4LL * B * P * (Co + Cm) + lift_wgrad_ws(B, Cin, Cm, Co, P);
+}
+
+int uno_lift_backward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g_act, float* gw1,
+                      float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp, void* stream) {
+    if (int rc = lift_check("uno_lift_backward", B, Cin, Cm, Co, H, W, Hp, Wp)) return rc;
+    if (!gw1 || !gw0) { set_error("uno_lift_backward: null pointer"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        if (hipMemsetAsync(gw1, 0, sizeof(float) * Cm * Cin, s) != hipSuccess || hipMemsetAsync(gw0, 0, sizeof(float) * Co * Cm, s) != hipSuccess ||
+            (gb1 && hipMemsetAsync(gb1, 0, sizeof(float) * Cm, s) != hipSuccess) || (gb0 && hipMemsetAsync(gb0, 0, sizeof(float) * Co, s) != hipSuccess)) {
+            set_error("uno_lift_backward: memset failed");
+            return -5;
+        }
+        return 0;
+    }
+    if (!x || !w1 || !w0 || !g_act || !ws) { set_error("uno_lift_backward: null pointer"); return -1; }
+    const long long P = (long long)H * W;
+    float* gz = static_cast<float*>(ws);
+    float* gh = gz + (size_t)B * Co * P;
+    float* wws = gh + (size_t)B * Cm * P;
+    // 1. gz = gelu'(fc0(gelu(h))) * g_act[..., :H, :W], the layer recomputed from the virtual h = fc_n1(x)
+    {
+        ChannelMixArgs a{};
+        a.x = x; a.w = w0; a.bias = b0; a.y = gz; a.gmul = g_act;
+        a.B = B; a.Ci = Cm; a.Co = Co; a.C1 = Cm; a.Co1 = Co; a.P = P; a.act_in = 1;
+        a.act_cols = W; a.act_pitch = Wp; a.act_plane = (long long)Hp * Wp;
+        a.vh_x = x; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 1;
+        if (int rc = launch_channel_mix2(a, s)) return rc;
+    }
+    // 2. g_h = (w0^T gz) * gelu'(h)
+    {
+        ChannelMixArgs a{};
+        a.x = gz; a.w = w0; a.y = gh; a.B = B; a.Ci = Co; a.Co = Cm; a.C1 = Co; a.Co1 = Cm; a.P = P; a.transpose_w = 1;
+        a.vh_x = x; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 2;
+        if (int rc = launch_channel_mix2(a, s)) return rc;
+    }
+    // 3. fc0's weight / bias gradient: gz x gelu(h)^T;  4. fc_n1's: g_h x x^T
+    if (int rc = launch_channel_wgrad_vh(gz, x, w1, b1, Cin, gw0, gb0, wws, B, Cm, Co, P, 1, s)) return rc;
+    return launch_channel_wgrad(gh, x, gw1, gb1, wws, B, Cin, Cm, P, 0, 0, s);
+}
+
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {
     if (B < 1 || Ci < 1 || Co < 1 || P < 1) return 0;
     return 4LL * channel_wgrad_ws_floats(B, Ci, Co, P, nullptr);

@@ -74,6 +74,10 @@ struct ChannelMixParams {
     PixMap pm;              // plane stride of every operand + the pixel window (dense: pm.PS == P); generic and split kernels only
     const void* gmul;       // nullptr, or (B, Co, padded plane) read through pm_act: y = gelu'(product + bias) * gmul - the gradient of the lift's
                             // last pre-activation RECOMPUTED from the layer's input instead of stored (generic kernel, one destination)
+    // VIRTUAL operand (generic kernel, template VH): a (B, nvh <= 64, P) tensor that is never stored - channel c at pixel q is
+    // vh_b[c] + sum_k vh_w[c][k] vh_x[b][k][q] with vh_ci <= 3 real channels (the lift's first layer, reference darcy_flow_uno2d.py:98:
+    // `fc_n1` on [a(x, y), x, y]; 12 bytes per pixel instead of 128).  VH = 1: it is the X operand (Ci channels); VH = 2: it is dgelu_of
+    const float* vh_x; const float* vh_w; const float* vh_b; int vh_ci;
     int store_y;            // 0: only y_act is written (the padded-activation call that does not keep the pre-activation result)
     PixMap pm_act;          // y_act's OWN map when pm_act.rl != 0 (generic kernel): the dense pixels of an H x W grid go to the top-left
                             // corner of (Hp, Wp) planes - rl = W (any width: a lane's four pixels may straddle a row end), skip = Wp - W
@@ -101,9 +105,10 @@ __device__ __forceinline__ CmDest<T> cm_dest(const ChannelMixParams& p, int o0, 
 // MODE 2: interior tile (128 whole pixels, 64 whole output channels, input channels a multiple of 16): no guards,
 //         32-bit offsets from a uniform base - the per-element clamps and selects of the guarded path cost more
 //         VALU issue slots than the tile has MFMAs;  MODE 1: guarded 16-byte loads (P >= 4);  MODE 0: guarded scalars.
-template <int MODE, int PT, bool ACT = false, bool DG = false, bool BF = false>
+template <int MODE, int PT, bool ACT = false, bool DG = false, bool BF = false, int VH = 0>
 __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, float (*sX)[CM_KC * (PT + 16)], float (*sW)[CM_KC * CM_WS],
-                                                 int p0, int o0, int b) {
+                                                 int p0, int o0, int b, const float4* sVH = nullptr) {
+    static_assert(VH == 0 || (MODE != 0 && !BF), "virtual operands: vector modes, float32");
     constexpr int XS = PT + 16;         // LDS row stride of the X chunk [KC][PT]: 4 consecutive rows hit disjoint bank groups
     constexpr int F4R = PT / 4;         // 16-byte pieces per row
     constexpr int NV = PT / 64;         // 16-byte pieces per thread per chunk
@@ -127,6 +132,33 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     const T* const gall = p.gmul ? reinterpret_cast<const T*>(p.gmul) + (size_t)b * p.Co * APS : nullptr;
     const bool store_y = p.store_y != 0;
     bool act_ld = ACT;                           // the chunk in the staging registers comes from the activated source
+    // virtual operand: this thread's four pixels (tile pixel 4 (tid % 32): the staging pixel AND the interior epilogue's) of the real channels
+    float4 vx[3];
+    if constexpr (VH != 0) {
+        const float* vb = p.vh_x + (size_t)b * p.vh_ci * p.P;
+        const int vpx = p0 + (tid & (F4R - 1)) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* row = vb + (size_t)min(k, p.vh_ci - 1) * p.P;
+            vx[k] = MODE == 2 ? io_ld4(row + vpx) : load4_tail(row, vpx, p.P);
+            if (k >= p.vh_ci) vx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    auto vh_of = [&](int c, const float4* q) {  // channel c of the virtual tensor at the four pixels whose real channels are q[0..2]
+        const float4 t = sVH[c];                 // (w[c][0], w[c][1], w[c][2], b[c])
+        return make_float4(fmaf(t.z, q[2].x, fmaf(t.y, q[1].x, fmaf(t.x, q[0].x, t.w))), fmaf(t.z, q[2].y, fmaf(t.y, q[1].y, fmaf(t.x, q[0].y, t.w))),
+                           fmaf(t.z, q[2].z, fmaf(t.y, q[1].z, fmaf(t.x, q[0].z, t.w))), fmaf(t.z, q[2].w, fmaf(t.y, q[1].w, fmaf(t.x, q[0].w, t.w))));
+    };
+    auto vh_at = [&](int c, int px) {            // ... at any pixel quad of the tile (guarded loads; the edge tile's epilogue)
+        const float* vb = p.vh_x + (size_t)b * p.vh_ci * p.P;
+        float4 q[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            q[k] = load4_tail(vb + (size_t)min(k, p.vh_ci - 1) * p.P, px, p.P);
+            if (k >= p.vh_ci) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return vh_of(c, q);
+    };
 
     // staging maps: X chunk = 16 rows x 128 px -> two 16-byte pieces per thread (row e / 32, px 4 (e % 32)) or, MODE 0,
     //               8 single elements (row e / 128, px e % 128);  W chunk = 16 k x 64 o -> 4 elements (k e % 16, o e / 16)
@@ -142,7 +174,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
-                rx[u] = io_ld4(cb + (unsigned)((kb + (e / F4R)) * PS + run(p0 + (e % F4R) * 4)));
+                if constexpr (VH == 1) rx[u] = vh_of(k0 + e / F4R, vx);
+                else rx[u] = io_ld4(cb + (unsigned)((kb + (e / F4R)) * PS + run(p0 + (e % F4R) * 4)));
             }
             // W chunk as ONE 16-byte load per thread along whichever index is contiguous in memory (4 dword loads
             // per thread made W the most numerous vector-memory instruction of the tile; the address unit was the
@@ -160,7 +193,9 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
             for (int u = 0; u < NV; ++u) {
                 const int e = tid + 256 * u;
                 const int ci = k0 + (e / F4R), cc = min(ci, p.Ci - 1);
-                float4 v = load4_tail(cc < C1 ? xb + (size_t)cc * PS : xb2 + (size_t)(cc - C1) * PS, p0 + (e % F4R) * 4, p.P, run);
+                float4 v;
+                if constexpr (VH == 1) v = vh_of(cc, vx);
+                else v = load4_tail(cc < C1 ? xb + (size_t)cc * PS : xb2 + (size_t)(cc - C1) * PS, p0 + (e % F4R) * 4, p.P, run);
                 if (ci >= p.Ci) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 rx[u] = v;
             }
@@ -272,7 +307,10 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
                 aoff[it] = (size_t)o * APS;
                 if (p.accumulate) old[it] = io_ld4(dst[it]);
                 else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (DG) { if (dg) pre[it] = io_ld4(dall + off); else pre[it] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if constexpr (DG) {
+                    if constexpr (VH == 2) pre[it] = dg ? vh_of(o - dd.ob, vx) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    else { if (dg) pre[it] = io_ld4(dall + off); else pre[it] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                }
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -338,11 +376,13 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
         for (int mt = 0; mt < NM; ++mt) {
             const int px = p0 + 16 * mt + 4 * kk, fx = run(px);        // logical pixel (guards), offset inside the plane
-            const T* drow = dg ? dall + (size_t)(o - dd.ob) * PS : nullptr;
+            const T* drow = (dg && VH != 2) ? dall + (size_t)(o - dd.ob) * PS : nullptr;
+            float4 vpre = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (DG && VH == 2) { if (dg) vpre = vh_at(o - dd.ob, px); }
             if (MODE == 2 || px + 3 < p.P) {
                 float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), pre = o4;
                 if (p.accumulate) o4 = io_ld4(yrow + fx);
-                if constexpr (DG) { if (dg) pre = io_ld4(drow + fx); }
+                if constexpr (DG) { if constexpr (VH == 2) pre = vpre; else if (dg) pre = io_ld4(drow + fx); }
                 float w4[4] = {o4.x, o4.y, o4.z, o4.w};
                 const float pr4[4] = {pre.x, pre.y, pre.z, pre.w};
 #pragma unroll
@@ -364,7 +404,8 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (px + r < p.P) {
-                        const float d = dg ? cm_dgelu(io_widen(drow[fx + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[fx + r]) : 0.f;
+                        const float vp4[4] = {vpre.x, vpre.y, vpre.z, vpre.w};
+                        const float d = dg ? cm_dgelu(VH == 2 ? vp4[r] : io_widen(drow[fx + r])) : 1.f, o1 = p.accumulate ? io_widen(yrow[fx + r]) : 0.f;
                         float v = p.accumulate == 2 ? (o1 + (acc[mt][r] + bv)) * d : o1 + (acc[mt][r] + bv) * d;
                         if (grow) v = cm_dgelu(v) * io_widen(grow[arun(px + r)]);
                         if (store_y) io_store1(yrow + fx + r, v);
@@ -402,10 +443,19 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
 // stores) - the address unit (TA) was the busiest block of the CU at 63 %.
 // TINY: rows shorter than 4 pixels (scalar guarded path) - a kernel of its own so that its register needs do not set
 // the occupancy of the real one.  Also measured and dropped: two chunks in flight per workgroup (same time).
-template <int PT, bool TINY, bool ACT = false, bool DG = false, bool BF = false>
+template <int PT, bool TINY, bool ACT = false, bool DG = false, bool BF = false, int VH = 0>
 __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(ChannelMixParams p) {
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * (PT + 16)];
     __shared__ float sW[2][CM_KC * CM_WS];
+    __shared__ float4 sVH[VH != 0 ? 64 : 1];            // virtual operand: (w[c][0..2], b[c]) per channel
+    if constexpr (VH != 0) {
+        const int nvh = VH == 1 ? p.Ci : p.Co1;
+        if ((int)threadIdx.x < nvh) {
+            const float* wr = p.vh_w + threadIdx.x * p.vh_ci;
+            sVH[threadIdx.x] = make_float4(wr[0], p.vh_ci > 1 ? wr[1] : 0.f, p.vh_ci > 2 ? wr[2] : 0.f, p.vh_b ? p.vh_b[threadIdx.x] : 0.f);
+        }
+        __syncthreads();
+    }
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
     // the k-th contiguous eighth of the tile list.  Neighbouring pixel tiles share the 128-byte lines at their
     // boundary in every row (rows are only 4-byte aligned); on the same XCD they meet in one L2.
@@ -419,8 +469,8 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
         // (a last tile with 16 / 32 / 48 valid channels - the 32-channel input gradient of the lift - keeps its whole waves and
         // idles the others instead of falling back to the guarded path)
         if (p0 + PT <= p.P && (p.Ci & (CM_KC - 1)) == 0 && (o0 + CM_MT <= p.Co || ((p.Co - o0) & 15) == 0))
-            channel_mix_tile<2, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
-        else channel_mix_tile<1, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
+            channel_mix_tile<2, PT, ACT, DG, BF, VH>(p, sX, sW, p0, o0, b, sVH);
+        else channel_mix_tile<1, PT, ACT, DG, BF, VH>(p, sX, sW, p0, o0, b, sVH);
     }
 }
 
@@ -1035,6 +1085,16 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     p.dgelu_of = a.dgelu_of;
     p.x = a.x; p.x2 = a.x2; p.w = a.w; p.bias = a.bias; p.y = a.y; p.y2 = a.y2; p.y_act = a.y_act;
     p.gmul = a.gmul; p.store_y = a.y ? 1 : 0;
+    p.vh_x = a.vh_x; p.vh_w = a.vh_w; p.vh_b = a.vh_b; p.vh_ci = a.vh_ci;
+    const int vh = a.vh_x ? a.vh_mode : 0;
+    if (vh) {
+        const int nvh = vh == 1 ? Ci : (a.y2 ? a.Co1 : Co);
+        if ((vh != 1 && vh != 2) || !a.vh_w || a.vh_ci < 1 || a.vh_ci > 3 || nvh > 64 || bf16 || a.win.cols || a.x2 || P < CM_PT ||
+            (vh == 1 && !a.act_in) || (vh == 2 && (a.dgelu_of || a.act_in))) {
+            set_error("channel_mix: a virtual operand has <= 3 real and <= 64 virtual channels, float32, dense, >= %d pixels; as the input it is read through the GELU, as dgelu_of it replaces that argument", CM_PT);
+            return -2;
+        }
+    }
     if (!a.y) p.y = a.y_act;            // (never stored through: address arithmetic only)
     p.proj_w = a.proj_w; p.proj_b = a.proj_b; p.proj_out = a.proj_out;
     if (a.proj_w && (!a.proj_out || Co > CM_MT || two_dst || a.dgelu_of)) {
@@ -1066,7 +1126,8 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     const int act_in = a.act_in;
     const void* dgelu_of = a.dgelu_of;
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
-    const bool wide = Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0) && !windowed && !act_pad;      // (the wide and few-input kernels are dense only)
+    if (vh == 2) p.dgelu_of = a.vh_x;             // (non-null marks the gelu' epilogue; never read)
+    const bool wide = !vh && Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0) && !windowed && !act_pad;      // (the wide and few-input kernels are dense only)
     // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
 #ifdef UNO_CMS_DEV        // development build only (tools/dev/mkvariant.py): A/B switch, knock-outs, stamp buffer from the environment
     static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;
@@ -1080,7 +1141,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     // f32 activations: from 128 input channels on; bf16 activations move half the bytes, there the f32 MFMA is the ceiling from 32 on
     // (profiles/r04_c5_mixed_kernel_stats.csv: the generic forms on bf16 were 4.8 of the mixed C5 step's 16 ms)
     const bool trw_ = a.transpose_w != 0;
-    const bool s_common = !split_off && !act_pad && P >= PT && Ci >= (bf16 ? 32 : 128) && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0) && !(act_in && trw_);
+    const bool s_common = !split_off && !act_pad && !vh && P >= PT && Ci >= (bf16 ? 32 : 128) && Ci % CMS_KC == 0 && (!two_src || a.C1 % CMS_KC == 0) && !(act_in && trw_);
 #ifdef UNO_CMS_DEV
     static const bool force64 = getenv("UNO_CMS_FORCE64") != nullptr;
 #else
@@ -1160,7 +1221,9 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
                 else if (dgelu_of) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, true, BF>), grid, dim3(256), 0, s, p); \
                 else hipLaunchKernelGGL((channel_mix_kernel<CM_PT, T, false, false, BF>), grid, dim3(256), 0, s, p); \
             } while (0)
-            if (bf16) { if (P >= 4) UNO_CM_LAUNCH(false, true); else UNO_CM_LAUNCH(true, true); }
+            if (vh == 1) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false, true, false, false, 1>), grid, dim3(256), 0, s, p);
+            else if (vh == 2) hipLaunchKernelGGL((channel_mix_kernel<CM_PT, false, false, true, false, 2>), grid, dim3(256), 0, s, p);
+            else if (bf16) { if (P >= 4) UNO_CM_LAUNCH(false, true); else UNO_CM_LAUNCH(true, true); }
             else { if (P >= 4) UNO_CM_LAUNCH(false, false); else UNO_CM_LAUNCH(true, false); }
 #undef UNO_CM_LAUNCH
         }
@@ -1198,6 +1261,7 @@ struct ChannelWgradParams {
     float* part;            // (nsplit, Co, Ci + 1) partial sums; column Ci holds the bias gradient
     int B, Ci, Co, P, nsplit;
     PixMap pm;              // plane stride + pixel window of gy, x and x2 (vector and split kernels; dense: pm.PS == P)
+    const float* vh_x; const float* vh_w; const float* vh_b; int vh_ci;     // vector kernel, VHX: x is VIRTUAL (see ChannelMixParams)
     int act_x;              // scalar kernel: x := gelu(x)
     long long span;         // pixels per split (informational)
 };
@@ -1289,12 +1353,20 @@ constexpr int CWV_S = CWV_PK + 4;       // 272-byte rows: 16-byte aligned for ds
 
 // NI: 16-channel tiles of the INPUT side per workgroup, 4 or - layers with at most 32 input channels (the lift's fc0: 32 -> 64 at full
 // resolution) - 2: the 64-wide tile spent half of its MFMAs, X loads, GELUs and LDS writes on channels that do not exist.
-template <bool ACTX, bool BF, int NI = 4>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
+template <bool ACTX, bool BF, int NI = 4, bool VHX = false>          // ACTX: x := gelu(x) on its way to LDS (the layer's input is kept pre-activation)
 __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
     using T = typename IoElem<BF>::type;
     constexpr int ES = BF ? 2 : 4;          // bytes per element
     __shared__ __attribute__((aligned(16))) float sG[CW_T * CWV_S];
     __shared__ __attribute__((aligned(16))) float sXc[CW_T * CWV_S];
+    __shared__ float4 sVH[VHX ? 64 : 1];
+    if constexpr (VHX) {
+        if ((int)threadIdx.x < p.Ci) {
+            const float* wr = p.vh_w + threadIdx.x * p.vh_ci;
+            sVH[threadIdx.x] = make_float4(wr[0], p.vh_ci > 1 ? wr[1] : 0.f, p.vh_ci > 2 ? wr[2] : 0.f, p.vh_b ? p.vh_b[threadIdx.x] : 0.f);
+        }
+        __syncthreads();
+    }
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile_i = (p.Ci + CW_T - 1) / CW_T;
@@ -1312,6 +1384,7 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     // the channel count is applied when the chunk goes to LDS, AFTER the MFMA block - applied at load time it consumed the
     // loaded registers at once and the wave waited for its loads (s_waitcnt vmcnt(0)) before every MFMA block.
     float4 rg[4], rxv[4];
+    float4 rvx[3];          // VHX: the raw pieces of the real channels at this thread's four pixels
     int sh_cur = 0;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     const int c4 = (tid & 15) * 4, row0 = tid >> 4;
@@ -1333,6 +1406,14 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
         const int px = pp + c4, pl = min(px, p.P - 4);
         sh_cur = px - pl;
         const int pc = pix_run(p.pm, pp)(pl);            // offset of the piece inside its channel plane
+        if constexpr (VHX) {
+            const __amdgpu_buffer_rsrc_t rv_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vh_x + (size_t)b * p.vh_ci * p.P), 0, p.vh_ci * p.P * 4, 0x00020000);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rv_, (min(kx, p.vh_ci - 1) * p.P + pl) * 4, 0, 0);
+                rvx[kx] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
@@ -1347,7 +1428,7 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
             } else {
                 const u32x4 tg = __builtin_amdgcn_raw_buffer_load_b128(rg_, (min(o0 + row, p.Co - 1) * PS + pc) * 4, 0, 0);
                 rg[u] = make_float4(__uint_as_float(tg.x), __uint_as_float(tg.y), __uint_as_float(tg.z), __uint_as_float(tg.w));
-                if (u < NI) {
+                if (u < NI && !VHX) {
                     const u32x4 tx = __builtin_amdgcn_raw_buffer_load_b128(rx_, (min(il + row, Cs - 1) * PS + pc) * 4, 0, 0);
                     rxv[u] = make_float4(__uint_as_float(tx.x), __uint_as_float(tx.y), __uint_as_float(tx.z), __uint_as_float(tx.w));
                 }
@@ -1362,6 +1443,11 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
         return make_float4(t0, t1, t2, t3);
     };
     auto store_chunk = [&]() {
+        float4 q[3];
+        if constexpr (VHX) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) { q[kx] = shifted(rvx[kx], kx < p.vh_ci); }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 16 * u;
@@ -1369,7 +1455,14 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
             *reinterpret_cast<float4*>(sG + row * CWV_S + c4) = g;
             bs[u] += (g.x + g.y) + (g.z + g.w);
             if (u < NI) {
-                float4 v = shifted(rxv[u], il + row < Cs);
+                float4 v;
+                if constexpr (VHX) {
+                    // (pixels past the row end carry the bias instead of zero: they meet the zero fill of gy)
+                    const float4 t = sVH[min(il + row, p.Ci - 1)];
+                    v = make_float4(fmaf(t.z, q[2].x, fmaf(t.y, q[1].x, fmaf(t.x, q[0].x, t.w))), fmaf(t.z, q[2].y, fmaf(t.y, q[1].y, fmaf(t.x, q[0].y, t.w))),
+                                    fmaf(t.z, q[2].z, fmaf(t.y, q[1].z, fmaf(t.x, q[0].z, t.w))), fmaf(t.z, q[2].w, fmaf(t.y, q[1].w, fmaf(t.x, q[0].w, t.w))));
+                    if (il + row >= Cs) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else v = shifted(rxv[u], il + row < Cs);
                 if constexpr (ACTX) { if (actx) v = cm_gelu4(v); }             // gelu(0) = 0: the zero fill survives
                 *reinterpret_cast<float4*>(sXc + row * CWV_S + c4) = v;
             }
@@ -1811,6 +1904,30 @@ int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, fl
     return launch_channel_wgrad2(gy, x, nullptr, Ci, gw, gb, ws, B, Ci, Co, P, act_x, 0, bf16, s);
 }
 
+int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w, const float* vh_b, int vh_ci, float* gw, float* gb, float* ws,
+                            int B, int Ci, int Co, long long P, int act_x, hipStream_t s) {
+    if (Ci > 32 || Ci < 5 || vh_ci < 1 || vh_ci > 3 || P < 64 || !act_x || (long long)Co * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
+        set_error("channel_wgrad: the virtual-input form takes 5 .. 32 virtual channels of <= 3 real ones, read through the GELU, >= 64 pixels");
+        return -2;
+    }
+    ChannelWgradParams p;
+    p.gy = gy; p.x = vh_x; p.x2 = nullptr; p.C1 = Ci; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = 1;
+    p.pm = pix_map(PixelWindow(), P);
+    p.vh_x = vh_x; p.vh_w = vh_w; p.vh_b = vh_b; p.vh_ci = vh_ci;
+    int npc, cps, pk;
+    wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
+    p.span = (long long)cps * pk;
+    const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
+    {
+        ProfScope prof("uno::channel_wgrad_vec_kernel", 4.0 * B * (double)P * (vh_ci + Co), s);
+        hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false, 2, true>), dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
+    }
+    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((Co * (Ci + 1) + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, 0);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
                           long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win) {
     const bool windowed = win.cols != 0;
@@ -1827,6 +1944,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
     ChannelWgradParams p;
     p.gy = gy; p.x = x; p.x2 = x2; p.C1 = x2 ? C1 : Ci; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = act_x ? 1 : 0;
     p.pm = pix_map(win, P);
+    p.vh_x = nullptr; p.vh_w = nullptr; p.vh_b = nullptr; p.vh_ci = 0;
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     if (windowed && (pk != CWV_PK || (Ci <= 4 && !act_x))) { set_error("channel_wgrad: the pixel window goes with the vector / split kernels (>= 64 pixels, > 4 input channels)"); return -2; }

@@ -285,6 +285,7 @@ struct ChannelMixArgs {
     int B, Ci, Co, C1, Co1; long long P; int transpose_w, accumulate, act_in, bf16;
     PixelWindow win;                                                // all operands on one window (proj_out: one plane per batch entry)
     void* ws = nullptr; size_t ws_bytes = 0;                       // optional scratch (uno_scratch_provide): 6 Ci Co bytes let K8-S run on pre-split weights
+    const float* vh_x = nullptr; const float* vh_w = nullptr; const float* vh_b = nullptr; int vh_ci = 0, vh_mode = 0;   // virtual operand (channel_mix.hip): 1 = the input, 2 = dgelu_of
     const void* gmul = nullptr;                                     // y = gelu'(product + bias) * gmul, gmul on the padded planes described below
     int act_cols = 0, act_pitch = 0; long long act_plane = 0;       // y_act on padded planes (generic kernel): the P = H * act_cols dense
                                                                     // pixels land in the top-left corner of act_plane / act_pitch rows
@@ -318,6 +319,9 @@ int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, fl
                          int act_x, int bf16, hipStream_t s);
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
                           long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win = PixelWindow());
+// weight gradient with the X operand virtual (see ChannelMixParams: gelu of it is taken when act_x): Ci <= 32 virtual channels
+int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w, const float* vh_b, int vh_ci, float* gw, float* gb, float* ws,
+                            int B, int Ci, int Co, long long P, int act_x, hipStream_t s);
 int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s);
 
 }  // namespace uno

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..integral_operators import (GradJoin, OperatorBlock_2D, OperatorBlock_3D, channel_mix, channel_mix_cat, channel_mix_cat_project,
-                                  gelu_channel_mix, gelu_channel_mix_pad, gelu_pad2d, gelu_project)
+                                  gelu_channel_mix, gelu_channel_mix_pad, gelu_pad2d, gelu_project, lift_gelu_pad)
 
 
 class UNO_9(nn.Module):
@@ -55,12 +55,11 @@ class UNO_9(nn.Module):
     def forward(self, x):
         S1, S2 = x.shape[1], x.shape[2]
         x = torch.cat((x, self.get_grid(x.shape, x.device).to(x.dtype)), dim=-1).permute(0, 3, 1, 2).contiguous()   # (B, 3, S, S): tiny
-        # lift: fc0(gelu(fc_n1(x))) with the intermediate kept pre-activation (GELU applied as fc0's kernels read it)
-        # ... and fc0's own store epilogue writes gelu(fc0 output), zero-padded at the end of both axes, next to the pre-activation
-        # result it keeps for the backward pass
+        # lift + activation + domain padding: one forward kernel; neither fc_n1's nor fc0's output is stored (both are recomputed from
+        # the 3-channel input where the backward pass needs them)
         scale = math.ceil(S2 / 85)
         margin = scale * self.padding
-        lifted = gelu_channel_mix_pad(channel_mix(x, self.fc_n1.weight, self.fc_n1.bias), self.fc0.weight, self.fc0.bias, margin, margin)
+        lifted = lift_gelu_pad(x, self.fc_n1, self.fc0, margin, margin)
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
 
         product = hasattr(self.conv5, "forward_cat")          # MI355X operator blocks (the CPU baseline builds the model on oracle blocks)

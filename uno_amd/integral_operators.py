@@ -918,6 +918,42 @@ def gelu_channel_mix_pad(pre: torch.Tensor, weight: torch.Tensor, bias: torch.Te
     return gelu_pad2d(gelu_channel_mix(pre, weight, bias), pad_h, pad_w)
 
 
+class _LiftFn(torch.autograd.Function):
+    """The whole lift - zero-pad(gelu(fc0(gelu(fc_n1(x))))), reference darcy_flow_uno2d.py:98-107 - with neither layer's output stored
+    (uno_lift_forward / uno_lift_backward): the first layer has 3 input channels, so every kernel that needs its 32-channel result
+    evaluates it from x.  x is data: no gradient for it."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w0, b0, Hp, Wp):
+        x, w1, w0 = _plain(x), _plain(w1), _plain(w0)
+        b1 = None if b1 is None else _plain(b1)
+        b0 = None if b0 is None else _plain(b0)
+        ctx.save_for_backward(x, w1, w0, *[t for t in (b1, b0) if t is not None])
+        ctx.has = (b1 is not None, b0 is not None)
+        return _native.lift_forward(x, w1, b1, w0, b0, Hp, Wp)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gact):
+        x, w1, w0, *bs = ctx.saved_tensors
+        b1 = bs.pop(0) if ctx.has[0] else None
+        b0 = bs.pop(0) if ctx.has[1] else None
+        gw1, gb1, gw0, gb0 = _native.lift_backward(x, w1, b1, w0, b0, _plain(gact))
+        return None, gw1, gb1, gw0, gb0, None, None
+
+
+def lift_gelu_pad(x: torch.Tensor, fc_n1: nn.Module, fc0: nn.Module, pad_h: int, pad_w: int) -> torch.Tensor:
+    """F.pad(F.gelu(fc0(F.gelu(fc_n1(x)))), [0, pad_w, 0, pad_h]) for a channels-first x (B, Cin, H, W) and two nn.Linear layers, as one
+    forward and four backward kernels that store neither intermediate, where the shapes allow (at most 3 input channels, 16 or 32
+    in the middle, width >= 260, float32, x without gradient); the layer-by-layer forms otherwise."""
+    w1, w0 = fc_n1.weight, fc0.weight
+    if x.dim() == 4 and _dev_act(x) and not x.requires_grad and w1.dtype == torch.float32 and w0.dtype == torch.float32 and pad_h >= 0 and pad_w >= 0:
+        Hp, Wp = x.shape[2] + int(pad_h), x.shape[3] + int(pad_w)
+        if _native.lift_ok(x, w1, w0, Hp, Wp):
+            return _LiftFn.apply(x, w1, fc_n1.bias, w0, fc0.bias, Hp, Wp)
+    return gelu_channel_mix_pad(channel_mix(x, w1, fc_n1.bias), w0, fc0.bias, pad_h, pad_w)
+
+
 class _GeluProjectFn(torch.autograd.Function):
     """out[b, p] = bias + sum_c w[c] gelu(pre[b, c, p]) (K11, csrc/pointwise_fused.hip)."""
 
