@@ -255,21 +255,43 @@ __device__ __forceinline__ void channel_mix_tile(const ChannelMixParams& p, floa
     store_chunk(0);
     __syncthreads();
     const bool wave_ok = MODE != 2 || o0 + 16 * wave < p.Co;         // interior path of a partial channel tile: whole waves idle
+    // ... unless the tile has at most 32 valid output channels (the 32-channel input gradient of the lift): then waves 2, 3 would idle
+    // through the whole K loop while waves 0, 1 - two SIMDs of four - do all the MFMAs.  The K steps of a chunk are split instead: wave
+    // (c, h) takes channel group c = wave & 1 and k-steps 2 h, 2 h + 1 (h = wave >> 1); the two partial sums meet in LDS once per tile.
+    const bool ksplit = MODE == 2 && PT == 128 && o0 + 32 >= p.Co;
+    const int wc = ksplit ? (wave & 1) : wave;
+    const bool mul_ok = ksplit ? (o0 + 16 * wc < p.Co) : wave_ok;
+    const int ks_lo = ksplit ? 2 * (wave >> 1) : 0, ks_hi = ksplit ? ks_lo + 2 : CM_KC / 4;
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) load_chunk((c + 1) * CM_KC);        // global -> registers while this chunk is multiplied
-        if (wave_ok) {
+        if (mul_ok) {
 #pragma unroll
             for (int ks = 0; ks < CM_KC / 4; ++ks) {
+                if (ks < ks_lo || ks >= ks_hi) continue;                                     // (uniform)
                 // D^T = X^T W^T: A[i = px][k] = X[k][16 mt + r16], B[k][j = o] = Wm(16 wave + r16, k): a lane ends up with
                 // 4 consecutive pixels of one output channel -> one 16-byte store
-                const float wv = sW[buf][(4 * ks + kk) * CM_WS + 16 * wave + r16];
+                const float wv = sW[buf][(4 * ks + kk) * CM_WS + 16 * wc + r16];
                 const float* xrow = sX[buf] + (4 * ks + kk) * XS + r16;
 #pragma unroll
                 for (int mt = 0; mt < NM; ++mt) acc[mt] = mfma16(xrow[16 * mt], wv, acc[mt]);
             }
         }
         if (c + 1 < nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    if (ksplit) {
+        // partial sums of waves 2, 3 -> waves 0, 1 (the X staging buffers are free: 2 waves x NM tiles x 64 lanes x 16 bytes = 16 KB)
+        float* sR = &sX[0][0];
+        if (wave >= 2) {
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt) *reinterpret_cast<f32x4*>(sR + (((wave - 2) * NM + mt) * 64 + lane) * 4) = acc[mt];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt) acc[mt] += *reinterpret_cast<const f32x4*>(sR + ((wave * NM + mt) * 64 + lane) * 4);
+        }
         __syncthreads();
     }
 
