@@ -532,7 +532,7 @@ long long uno_lift_bwd_ws_bytes(int B, int Cin, int Cm, int Co, int H, int W) {
     return 4LL * B * P * (Co + Cm) + lift_wgrad_ws(B, Cin, Cm, Co, P);
 }
 
-int uno_lift_backward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g_act, float* gw1,
+int uno_lift_backward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0_, const float* g_act, float* gw1,
                       float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp, void* stream) {
     if (int rc = lift_check("uno_lift_backward", B, Cin, Cm, Co, H, W, Hp, Wp)) return rc;
     if (!gw1 || !gw0) { set_error("uno_lift_backward: null pointer"); return -1; }
@@ -547,28 +547,39 @@ int uno_lift_backward(const float* x, const float* w1, const float* b1, const fl
     }
     if (!x || !w1 || !w0 || !g_act || !ws) { set_error("uno_lift_backward: null pointer"); return -1; }
     const long long P = (long long)H * W;
+    // (measured and dropped, round 5: batch entries in groups whose gz stays in the 256 MB Infinity Cache between the kernel that writes
+    // it and the two that read it - groups of 2 / 4 / 8 of 16 ran the step at 13.1-13.3 / 12.8 / 12.65 ms against 12.37-12.40 whole: the
+    // shorter launches lose more to ramp and tail than the cache gives)
+    const int G = B;
     float* gz = static_cast<float*>(ws);
     float* gh = gz + (size_t)B * Co * P;
     float* wws = gh + (size_t)B * Cm * P;
-    // 1. gz = gelu'(fc0(gelu(h))) * g_act[..., :H, :W], the layer recomputed from the virtual h = fc_n1(x)
-    {
-        ChannelMixArgs a{};
-        a.x = x; a.w = w0; a.bias = b0; a.y = gz; a.gmul = g_act;
-        a.B = B; a.Ci = Cm; a.Co = Co; a.C1 = Cm; a.Co1 = Co; a.P = P; a.act_in = 1;
-        a.act_cols = W; a.act_pitch = Wp; a.act_plane = (long long)Hp * Wp;
-        a.vh_x = x; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 1;
-        if (int rc = launch_channel_mix2(a, s)) return rc;
+    for (int b0 = 0; b0 < B; b0 += G) {
+        const int nb = (B - b0 < G) ? B - b0 : G;
+        const float* xg = x + (size_t)b0 * Cin * P;
+        const float* gg = g_act + (size_t)b0 * Co * Hp * Wp;
+        const int acc = b0 > 0 ? 1 : 0;
+        // 1. gz = gelu'(fc0(gelu(h))) * g_act[..., :H, :W], the layer recomputed from the virtual h = fc_n1(x)
+        {
+            ChannelMixArgs a{};
+            a.x = xg; a.w = w0; a.bias = b0_; a.y = gz; a.gmul = gg;
+            a.B = nb; a.Ci = Cm; a.Co = Co; a.C1 = Cm; a.Co1 = Co; a.P = P; a.act_in = 1;
+            a.act_cols = W; a.act_pitch = Wp; a.act_plane = (long long)Hp * Wp;
+            a.vh_x = xg; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 1;
+            if (int rc = launch_channel_mix2(a, s)) return rc;
+        }
+        // 2. g_h = (w0^T gz) * gelu'(h)
+        {
+            ChannelMixArgs a{};
+            a.x = gz; a.w = w0; a.y = gh; a.B = nb; a.Ci = Co; a.Co = Cm; a.C1 = Co; a.Co1 = Cm; a.P = P; a.transpose_w = 1;
+            a.vh_x = xg; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 2;
+            if (int rc = launch_channel_mix2(a, s)) return rc;
+        }
+        // 3. fc0's weight / bias gradient: gz x gelu(h)^T;  4. fc_n1's: g_h x x^T
+        if (int rc = launch_channel_wgrad_vh(gz, xg, w1, b1, Cin, gw0, gb0, wws, nb, Cm, Co, P, 1, s, acc)) return rc;
+        if (int rc = launch_channel_wgrad2(gh, xg, nullptr, Cin, gw1, gb1, wws, nb, Cin, Cm, P, 0, acc, 0, s)) return rc;
     }
-    // 2. g_h = (w0^T gz) * gelu'(h)
-    {
-        ChannelMixArgs a{};
-        a.x = gz; a.w = w0; a.y = gh; a.B = B; a.Ci = Co; a.Co = Cm; a.C1 = Co; a.Co1 = Cm; a.P = P; a.transpose_w = 1;
-        a.vh_x = x; a.vh_w = w1; a.vh_b = b1; a.vh_ci = Cin; a.vh_mode = 2;
-        if (int rc = launch_channel_mix2(a, s)) return rc;
-    }
-    // 3. fc0's weight / bias gradient: gz x gelu(h)^T;  4. fc_n1's: g_h x x^T
-    if (int rc = launch_channel_wgrad_vh(gz, x, w1, b1, Cin, gw0, gb0, wws, B, Cm, Co, P, 1, s)) return rc;
-    return launch_channel_wgrad(gh, x, gw1, gb1, wws, B, Cin, Cm, P, 0, 0, s);
+    return 0;
 }
 
 long long uno_channel_wgrad_ws_bytes(int B, int Ci, int Co, long long P) {

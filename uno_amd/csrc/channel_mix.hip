@@ -1204,7 +1204,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
         ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
-                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + (a.y ? Co : 0) + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.gmul ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * ((vh == 1 ? a.vh_ci : Ci) + (vh == 2 ? a.vh_ci : 0) + (a.y ? Co : 0) + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.gmul ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
         if (split64 || split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
             const bool trw = p.w_so == 1 && p.w_si != 1;
@@ -1927,7 +1927,7 @@ int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, fl
 }
 
 int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w, const float* vh_b, int vh_ci, float* gw, float* gb, float* ws,
-                            int B, int Ci, int Co, long long P, int act_x, hipStream_t s) {
+                            int B, int Ci, int Co, long long P, int act_x, hipStream_t s, int accumulate) {
     if (Ci > 32 || Ci < 5 || vh_ci < 1 || vh_ci > 3 || P < 64 || !act_x || (long long)Co * P >= (1LL << 29) || (long long)B * ((P + 31) / 32) > 0x7fffffffLL) {
         set_error("channel_wgrad: the virtual-input form takes 5 .. 32 virtual channels of <= 3 real ones, read through the GELU, >= 64 pixels");
         return -2;
@@ -1944,7 +1944,7 @@ int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w
         ProfScope prof("uno::channel_wgrad_vec_kernel", 4.0 * B * (double)P * (vh_ci + Co), s);
         hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, false, 2, true>), dim3(8 * tiles * ((p.nsplit + 7) / 8)), dim3(256), 0, s, p, npc, cps);
     }
-    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((Co * (Ci + 1) + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, 0);
+    hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((Co * (Ci + 1) + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate ? 1 : 0);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

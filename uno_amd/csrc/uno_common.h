@@ -321,7 +321,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
                           long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win = PixelWindow());
 // weight gradient with the X operand virtual (see ChannelMixParams: gelu of it is taken when act_x): Ci <= 32 virtual channels
 int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w, const float* vh_b, int vh_ci, float* gw, float* gb, float* ws,
-                            int B, int Ci, int Co, long long P, int act_x, hipStream_t s);
+                            int B, int Ci, int Co, long long P, int act_x, hipStream_t s, int accumulate = 0);
 int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s);
 
 }  // namespace uno
