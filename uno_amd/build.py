@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuno_spectral.so")
 STAMP = os.path.join(LIBDIR, "libuno_spectral.stamp")
-SOURCES = ["capi.hip", "dft2d_fwd.hip", "dft2d_fwd_r4.hip", "dft2d_inv.hip", "dft2d_inv_b.hip", "dft2d_inv_c.hip", "dft2d_plane.hip", "dft2d_b16.hip", "mode_gemm.hip", "cdft_axis.hip", "dft3d_volume.hip", "dft_generic.hip", "resample2d.hip", "channel_mix.hip", "adam.hip", "pointwise_fused.hip", "instnorm.hip"]
+SOURCES = ["capi.hip", "dft2d_fwd.hip", "dft2d_fwd_r4.hip", "dft2d_inv.hip", "dft2d_inv_b.hip", "dft2d_inv_c.hip", "dft2d_plane.hip", "dft2d_b16.hip", "mode_gemm.hip", "cdft_axis.hip", "dft3d_volume.hip", "dft_generic.hip", "resample2d.hip", "channel_mix.hip", "adam.hip", "pointwise_fused.hip", "instnorm.hip", "lift_bwd.hip"]
 HEADERS = ["uno_common.h", "dft2d_fwd_kernel.h", "dft2d_fwd_ft_kernel.h", "dft2d_fwd_ht_kernel.h", "dft2d_inv_kernel.h", os.path.join("..", "..", "include", "uno_spectral.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,259 @@
+// K15 - the backward pass of the lift (reference darcy_flow_uno2d.py:98-107: fc_n1, GELU, fc0, GELU, pad) in ONE kernel per pixel tile.
+//
+//   h = w1 x + b1 (Cm = 32 channels from Cin <= 3),  a = gelu(h),  z = w0 a + b0 (Co = 64),  act = pad(gelu(z))        forward
+//   gz = gelu'(z) * g[..., :H, :W]                      (g: the gradient of the padded activation)
+//   gh = gelu'(h) * (w0^T gz)                           -> stored: the weight gradient of fc_n1 is taken from it (K9, few-input form)
+//   gw0 = sum_px gz a^T,  gb0 = sum_px gz               -> one (Co, Cm + 1) block of partial sums per workgroup, summed by K9's second stage
+//
+// The four-kernel form (capi.hip, uno_lift_backward) writes gz (64 channels) once and reads it twice: 2.2 GB of the pass's 3.8 GB.
+// Here gz lives in LDS only: a workgroup of 256 threads owns 128 pixels, recomputes a and z, and runs the three small GEMMs
+// (z: 64 x 32 x 128, gh: 32 x 64 x 128, gw0: 64 x 32 over its 128 pixels) on v_mfma_f32_16x16x4_f32 from LDS-resident operands.
+// HBM traffic: x (12 B per pixel), g (256 B), gh (128 B) and 8.4 KB of partial sums per TPW tiles.
+//
+// LDS (pitch TS = 148 floats: rows 16-byte aligned; 148 mod 64 = 20 makes the k-contiguous fragment reads of the weight-gradient
+// GEMM - lane (row r16, k kk) at r16 * 148 + kk - hit 64 distinct banks):
+//   sA [32][TS]  a = gelu(h)   (operand of the z and gw0 GEMMs; afterwards the staging area of gh's row-wise stores)
+//   sZ [64][TS]  g, then gz in place (the lane that reads g[o][px] writes gz[o][px])
+//   sW [32][80]  w0 as [m][o];  sWT [64][48]  w0 as [o][m];  sVH [32] (w1 row, b1);  sX [3][132] the tile's real channels
+// 79.6 KB: two workgroups per CU.  MFMA operand convention as everywhere in this library: D[i][j] = sum_k A[i][k] B[k][j], a lane
+// (r16, kk) supplies A[i = r16][k = kk] and B[k = kk][j = r16] and receives D[i = 4 kk + r][j = r16], r = 0..3.
+#include "uno_common.h"
+
+namespace uno {
+
+constexpr int LB_PT = 128;          // pixels per tile
+constexpr int LB_TS = 148;          // LDS row pitch (floats)
+constexpr int LB_CM = 32, LB_CO = 64;
+constexpr int LB_WS = 80, LB_WTS = 48;       // k rows 16 banks apart for the four k-lanes of a fragment read
+constexpr int LB_XS = 132;                     // pitch of the staged real channels
+constexpr int LB_TPW = 4;           // pixel tiles per workgroup (one block of partial sums per workgroup)
+
+struct LiftBwdParams {
+    const float* x;         // (B, Cin, P)
+    const float* w1;        // (32, Cin)
+    const float* b1;        // (32) or nullptr
+    const float* w0;        // (64, 32)
+    const float* b0;        // (64) or nullptr
+    const float* g;         // (B, 64, Hp, Wp)
+    float* gh;              // (B, 32, P)
+    float* part;            // (B * wg_per_batch, 64, 33)
+    int B, Cin, P, npt;
+    PixMap pm_g;            // pixel -> offset inside a padded plane of g
+};
+
+__device__ __forceinline__ float4 lb_load4_run(const float* plane, const PixRun& run, int px) {      // four consecutive pixels; rows of any length
+    const int f0 = run(px), f3 = run(px + 3);
+    if (f3 - f0 == 3) return io_ld4(plane + f0);
+    return make_float4(plane[f0], plane[run(px + 1)], plane[run(px + 2)], plane[f3]);
+}
+__device__ __forceinline__ float4 lb_vh(const float4& t, const float4* q) {       // t = (w[c][0..2], b[c]); q: the real channels at 4 pixels
+    return make_float4(fmaf(t.z, q[2].x, fmaf(t.y, q[1].x, fmaf(t.x, q[0].x, t.w))), fmaf(t.z, q[2].y, fmaf(t.y, q[1].y, fmaf(t.x, q[0].y, t.w))),
+                       fmaf(t.z, q[2].z, fmaf(t.y, q[1].z, fmaf(t.x, q[0].z, t.w))), fmaf(t.z, q[2].w, fmaf(t.y, q[1].w, fmaf(t.x, q[0].w, t.w))));
+}
+
+__global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lb_smem[];
+    float* sA = lb_smem;                            // [32][TS]
+    float* sZ = sA + LB_CM * LB_TS;                 // [64][TS]
+    float* sW = sZ + LB_CO * LB_TS;                 // [32][68]   w0[o][m] at [m][o]
+    float* sWT = sW + LB_CM * LB_WS;                // [64][36]   w0[o][m] at [o][m]
+    float4* sVH = reinterpret_cast<float4*>(sWT + LB_CO * LB_WTS);      // [32]
+    float* sX = reinterpret_cast<float*>(sVH + LB_CM);                  // [3][LB_XS]: x of the tile (zero past the row end / past Cin)
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int P = p.P;
+
+    // weights: once per workgroup
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + 256 * u, o = e >> 5, m = e & 31;
+        const float v = p.w0[e];
+        sW[m * LB_WS + o] = v;
+        sWT[o * LB_WTS + m] = v;
+    }
+    if (tid < LB_CM) {
+        const float* wr = p.w1 + tid * p.Cin;
+        sVH[tid] = make_float4(wr[0], p.Cin > 1 ? wr[1] : 0.f, p.Cin > 2 ? wr[2] : 0.f, p.b1 ? p.b1[tid] : 0.f);
+    }
+    const float b0v = p.b0 ? p.b0[16 * wave + r16] : 0.f;          // z's channel of this lane in the MFMA layout
+    const float* xb = p.x + (size_t)b * p.Cin * P;
+    const float* gb = p.g + (size_t)b * LB_CO * p.pm_g.PS;
+    float* ghb = p.gh + (size_t)b * LB_CM * P;
+
+    f32x4 acc3[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};       // gw0 partial: D[o = 16 wave + 4 kk + r][m = 16 t + r16], over all tiles of this workgroup
+    float bsum = 0.f;                                               // gb0 partial of channel 16 wave + r16 (this lane's pixels)
+
+    // the real channels at four pixels starting at px (zero past the row end; channels past Cin zero)
+    auto x_quads = [&](int px, float4* q) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* row = xb + (size_t)min(k, p.Cin - 1) * P;
+            float4 v;
+            if (px + 3 < P) v = io_ld4(row + px);
+            else v = make_float4(px < P ? row[px] : 0.f, px + 1 < P ? row[px + 1] : 0.f, px + 2 < P ? row[px + 2] : 0.f, 0.f);
+            q[k] = k < p.Cin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, p.npt);
+    // a tile's global loads: this thread's pixel quad tid & 31 of the real channels and of rows (tid >> 5) + 8 u of g.  The NEXT tile's
+    // are issued as soon as the current tile's values are in LDS and arrive while its three GEMMs run (one tile per workgroup at a time
+    // left the loads un-overlapped: two workgroups per CU cannot hide them)
+    float4 xq[3], gq[8];
+    auto load_tile = [&](int tile) {
+        const int p0 = tile * LB_PT, px = p0 + (tid & 31) * 4;
+        const PixRun grun = pix_run(p.pm_g, p0);
+        x_quads(px, xq);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* grow = gb + (size_t)((tid >> 5) + 8 * u) * p.pm_g.PS;
+            if (px + 3 < P) gq[u] = lb_load4_run(grow, grun, px);
+            else gq[u] = make_float4(px < P ? grow[grun(px)] : 0.f, px + 1 < P ? grow[grun(px + 1)] : 0.f, px + 2 < P ? grow[grun(px + 2)] : 0.f, 0.f);
+        }
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int p0 = tile * LB_PT;
+        // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at pixel quad tid & 31), g -> sZ (row-wise, 16-byte pieces)
+        {
+            const int q4 = (tid & 31) * 4, px = p0 + q4;
+            const float vm0 = px < P ? 1.f : 0.f, vm1 = px + 1 < P ? 1.f : 0.f, vm2 = px + 2 < P ? 1.f : 0.f, vm3 = px + 3 < P ? 1.f : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = (tid >> 5) + 8 * u;
+                const float4 h = lb_vh(sVH[m], xq);
+                // pixels past the row end contribute nothing to the weight gradient: a = 0 there
+                *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(uno_gelu(h.x) * vm0, uno_gelu(h.y) * vm1, uno_gelu(h.z) * vm2, uno_gelu(h.w) * vm3);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = gq[u];
+            if (tid < 32) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(sX + k * LB_XS + q4) = xq[k];
+            }
+        }
+        if (tile + 1 < t_end) load_tile(tile + 1);
+        __syncthreads();
+        // ---- z = w0 a: D[px = 16 mt + 4 kk + r][o = 16 wave + r16]
+        f32x4 acc1[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc1[mt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < LB_CM / 4; ++ks) {
+            const float wv = sW[(4 * ks + kk) * LB_WS + 16 * wave + r16];
+            const float* arow = sA + (4 * ks + kk) * LB_TS + r16;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv, acc1[mt]);
+        }
+        // gz = gelu'(z + b0) * g, in place in sZ (row 16 wave + r16: this wave's rows only)
+        {
+            float* zrow = sZ + (16 * wave + r16) * LB_TS + 4 * kk;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const float4 g4 = *reinterpret_cast<const float4*>(zrow + 16 * mt);
+                const float4 gz = make_float4(uno_dgelu(acc1[mt][0] + b0v) * g4.x, uno_dgelu(acc1[mt][1] + b0v) * g4.y,
+                                              uno_dgelu(acc1[mt][2] + b0v) * g4.z, uno_dgelu(acc1[mt][3] + b0v) * g4.w);
+                *reinterpret_cast<float4*>(zrow + 16 * mt) = gz;
+                bsum += (gz.x + gz.y) + (gz.z + gz.w);
+            }
+        }
+        __syncthreads();
+        // ---- gh = w0^T gz: wave (wp, wm) = (pixel half, channel group): D[px = 64 wp + 16 mt + 4 kk + r][m = 16 wm + r16]
+        const int wp = wave >> 1, wm = wave & 1;
+        f32x4 acc2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc2[mt] = f32x4{0, 0, 0, 0};
+#pragma unroll 4
+        for (int ks = 0; ks < LB_CO / 4; ++ks) {
+            const float wv = sWT[(4 * ks + kk) * LB_WTS + 16 * wm + r16];
+            const float* zrow = sZ + (4 * ks + kk) * LB_TS + 64 * wp + r16;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc2[mt] = mfma16(zrow[16 * mt], wv, acc2[mt]);
+        }
+        // ---- gw0 += gz a^T over this tile's pixels: A[i = o][k = px] = sZ row 16 wave + r16, B[k = px][j = m] = sA row 16 t + r16
+        {
+            const float* zr = sZ + (16 * wave + r16) * LB_TS + kk;
+            const float* a0 = sA + r16 * LB_TS + kk;
+            const float* a1 = sA + (16 + r16) * LB_TS + kk;
+#pragma unroll 8
+            for (int ks = 0; ks < LB_PT / 4; ++ks) {
+                const float zv = zr[4 * ks];
+                acc3[0] = mfma16(zv, a0[4 * ks], acc3[0]);
+                acc3[1] = mfma16(zv, a1[4 * ks], acc3[1]);
+            }
+        }
+        __syncthreads();                // every wave is done with a: sA becomes the staging area of gh
+        // gh *= gelu'(h) at this lane's pixels (h from the staged x again)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int q4 = 64 * wp + 16 * mt + 4 * kk;
+            const float4 xe[3] = {*reinterpret_cast<const float4*>(sX + q4), *reinterpret_cast<const float4*>(sX + LB_XS + q4),
+                                  *reinterpret_cast<const float4*>(sX + 2 * LB_XS + q4)};
+            const float4 h = lb_vh(sVH[16 * wm + r16], xe);
+            *reinterpret_cast<float4*>(sA + (16 * wm + r16) * LB_TS + q4) =
+                make_float4(acc2[mt][0] * uno_dgelu(h.x), acc2[mt][1] * uno_dgelu(h.y), acc2[mt][2] * uno_dgelu(h.z), acc2[mt][3] * uno_dgelu(h.w));
+        }
+        __syncthreads();
+        // row-wise stores of gh: thread -> (row (tid >> 5) + 8 u, pixel quad tid & 31)
+        {
+            const int q4 = (tid & 31) * 4, px = p0 + q4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = (tid >> 5) + 8 * u;
+                const float4 v = *reinterpret_cast<const float4*>(sA + m * LB_TS + q4);
+                float* dst = ghb + (size_t)m * P + px;
+                if (px + 3 < P) io_store4(dst, v.x, v.y, v.z, v.w);
+                else {
+                    if (px < P) dst[0] = v.x;
+                    if (px + 1 < P) dst[1] = v.y;
+                    if (px + 2 < P) dst[2] = v.z;
+                }
+            }
+        }
+        __syncthreads();                // before the next tile overwrites sA / sZ
+    }
+    // partial sums of this workgroup: (64, 33) block, bias in column 32
+    float* part = p.part + ((size_t)b * gridDim.x + blockIdx.x) * (LB_CO * (LB_CM + 1));
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(16 * wave + 4 * kk + r) * (LB_CM + 1) + 16 * t + r16] = acc3[t][r];
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (kk == 0) part[(16 * wave + r16) * (LB_CM + 1) + LB_CM] = bsum;
+}
+
+static size_t lift_bwd_lds() { return sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS + LB_CO * LB_WTS + 3 * LB_XS) + sizeof(float4) * LB_CM; }
+
+bool lift_bwd_fused_applies(int Cin, int Cm, int Co, int W, long long P) {
+    return Cin >= 1 && Cin <= 3 && Cm == LB_CM && Co == LB_CO && W >= 260 && P >= LB_PT && P < (1LL << 24);
+}
+
+long long lift_bwd_fused_parts(int B, long long P) {                // (64, 33) blocks of partial sums the fused kernel leaves
+    const long long npt = (P + LB_PT - 1) / LB_PT;
+    return (long long)B * ((npt + LB_TPW - 1) / LB_TPW);
+}
+
+int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* gh,
+                               float* part, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s) {
+    const long long P = (long long)H * W;
+    LiftBwdParams p;
+    p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.gh = gh; p.part = part;
+    p.B = B; p.Cin = Cin; p.P = (int)P; p.npt = (int)((P + LB_PT - 1) / LB_PT);
+    p.pm_g = PixMap{(int)((long long)Hp * Wp), W, Wp - W, (unsigned)(((1ULL << 40) + W - 1) / (unsigned long long)W)};
+    if ((long long)Hp * Wp * LB_CO >= (1LL << 31) || B > 65535) { set_error("lift_backward: tensor too large"); return -2; }
+    static int lds_slot[64];
+    const size_t lds = lift_bwd_lds();
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(lift_backward_kernel), lds, lds_slot)) { set_error("lift_backward: cannot raise dynamic LDS to %zu", lds); return -4; }
+    {
+        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)P * (Cin + LB_CO + LB_CM), s);
+        hipLaunchKernelGGL(lift_backward_kernel, dim3((unsigned)((p.npt + LB_TPW - 1) / LB_TPW), (unsigned)B), dim3(256), lds, s, p);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("lift_backward launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
+
+}  // namespace uno

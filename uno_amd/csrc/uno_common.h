@@ -322,6 +322,11 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
 // weight gradient with the X operand virtual (see ChannelMixParams: gelu of it is taken when act_x): Ci <= 32 virtual channels
 int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w, const float* vh_b, int vh_ci, float* gw, float* gb, float* ws,
                             int B, int Ci, int Co, long long P, int act_x, hipStream_t s, int accumulate = 0);
+// lift_bwd.hip: the lift's backward pass with gz in LDS only (32 middle / 64 output channels)
+bool lift_bwd_fused_applies(int Cin, int Cm, int Co, int W, long long P);
+long long lift_bwd_fused_parts(int B, long long P);
+int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* gh,
+                               float* part, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s);
 int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s);
 
 }  // namespace uno
