@@ -1,0 +1,27 @@
+"""Per-phase cycle stamps of K15 (lift_backward_kernel) at the Darcy shape from a -DUNO_LB_DEV variant: python tools/dev/lbstamps.py <variant.so>"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+dev = torch.device("cuda:0")
+B, H, W, pad = 16, 421, 421, 25
+npt = (H * W + 127) // 128
+nwg = (npt + 3) // 4
+buf = torch.zeros(B * nwg * 4 * 8, dtype=torch.int64, device=dev)
+os.environ["UNO_LB_STAMPS"] = hex(buf.data_ptr())
+from uno_amd import _native
+_native.LIB_PATH = os.path.abspath(sys.argv[1])
+torch.manual_seed(0)
+x = torch.randn(B, 3, H, W, device=dev)
+w1, b1 = torch.randn(32, 3, device=dev), torch.randn(32, device=dev)
+w0, b0 = torch.randn(64, 32, device=dev) / 6, torch.randn(64, device=dev)
+g = torch.randn(B, 64, H + pad, W + pad, device=dev)
+for _ in range(3):
+    buf.zero_()
+    _native.lift_backward(x, w1, b1, w0, b0, g)
+    torch.cuda.synchronize()
+s = buf.view(-1, 4, 8).double()
+names = ["phase 0: a, g -> LDS, next tile's loads issued", "barriers", "GEMM z", "epilogue gz", "GEMM gh", "GEMM gw0", "epilogue gh -> LDS", "gh stores"]
+tot = s.sum(2).mean().item()
+for i, n in enumerate(names):
+    print(f"  {n:48s} {s[:, :, i].mean().item() / 4:9.0f} cycles per wave and tile ({100 * s[:, :, i].mean().item() / tot:4.1f} %)")
+print(f"  per workgroup (4 tiles) {tot:9.0f} cycles")

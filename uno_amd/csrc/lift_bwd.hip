@@ -18,6 +18,7 @@
 // 79.6 KB: two workgroups per CU.  MFMA operand convention as everywhere in this library: D[i][j] = sum_k A[i][k] B[k][j], a lane
 // (r16, kk) supplies A[i = r16][k = kk] and B[k = kk][j = r16] and receives D[i = 4 kk + r][j = r16], r = 0..3.
 #include "uno_common.h"
+#include <cstdlib>
 
 namespace uno {
 
@@ -39,6 +40,7 @@ struct LiftBwdParams {
     float* part;            // (B * wg_per_batch, 64, 33)
     int B, Cin, P, npt;
     PixMap pm_g;            // pixel -> offset inside a padded plane of g
+    unsigned long long* stamps;     // development (-DUNO_LB_DEV): per-phase cycles of every wave, 8 values each
 };
 
 __device__ __forceinline__ float4 lb_load4_run(const float* plane, const PixRun& run, int px) {      // four consecutive pixels; rows of any length
@@ -96,14 +98,45 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         }
     };
 
+#ifdef UNO_LB_DEV
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#define LB_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define LB_STAMP(i) do { } while (0)
+#endif
     const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, p.npt);
     // a tile's global loads: this thread's pixel quad tid & 31 of the real channels and of rows (tid >> 5) + 8 u of g.  The NEXT tile's
     // are issued as soon as the current tile's values are in LDS and arrive while its three GEMMs run (one tile per workgroup at a time
-    // left the loads un-overlapped: two workgroups per CU cannot hide them)
-    float4 xq[3], gq[8];
+    // left the loads un-overlapped: two workgroups per CU cannot hide them).  Interior tiles take straight-line code - the guarded form
+    // (branches around scalar loads, a wait inside each) serialised the eight row loads: 17 k of a tile's 38 k cycles.  A tile that
+    // contains the end of a row of the padded grid (at most one: rows are longer than a tile) loads every quad twice, from its first and
+    // from its last pixel's address; the lanes of the one straddling quad pick per element in phase 0 (all others: the same address).
+    float4 xq[3], gq[8], gq2[8];
+    bool g_two = false;         // (uniform) the tile in the registers has a row end inside it
+    int g_nb = 4;               // elements of this thread's quad before that row end
     auto load_tile = [&](int tile) {
         const int p0 = tile * LB_PT, px = p0 + (tid & 31) * 4;
         const PixRun grun = pix_run(p.pm_g, p0);
+        if (p0 + LB_PT <= P) {                                  // (uniform) all 128 pixels exist
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xq[k] = io_ld4(xb + (size_t)min(k, p.Cin - 1) * P + px);
+            const int f0 = grun(px), f3 = grun(px + 3);
+            g_two = grun.bound < p0 + LB_PT;
+            g_nb = min(max(grun.bound - px, 0), 4);
+            if (g_two) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* grow = gb + (size_t)((tid >> 5) + 8 * u) * p.pm_g.PS;
+                    gq[u] = io_ld4(grow + f0);
+                    gq2[u] = io_ld4(grow + f3 - 3);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gq[u] = io_ld4(gb + (size_t)((tid >> 5) + 8 * u) * p.pm_g.PS + f0);
+            }
+            return;
+        }
+        g_two = false;
         x_quads(px, xq);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -127,6 +160,11 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
                 // pixels past the row end contribute nothing to the weight gradient: a = 0 there
                 *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(uno_gelu(h.x) * vm0, uno_gelu(h.y) * vm1, uno_gelu(h.z) * vm2, uno_gelu(h.w) * vm3);
             }
+            if (g_two) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    gq[u] = make_float4(g_nb > 0 ? gq[u].x : gq2[u].x, g_nb > 1 ? gq[u].y : gq2[u].y, g_nb > 2 ? gq[u].z : gq2[u].z, g_nb > 3 ? gq[u].w : gq2[u].w);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = gq[u];
             if (tid < 32) {
@@ -135,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
             }
         }
         if (tile + 1 < t_end) load_tile(tile + 1);
+        LB_STAMP(0);
         __syncthreads();
+        LB_STAMP(1);
         // ---- z = w0 a: D[px = 16 mt + 4 kk + r][o = 16 wave + r16]
         f32x4 acc1[8];
 #pragma unroll
@@ -147,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv, acc1[mt]);
         }
+        LB_STAMP(2);
         // gz = gelu'(z + b0) * g, in place in sZ (row 16 wave + r16: this wave's rows only)
         {
             float* zrow = sZ + (16 * wave + r16) * LB_TS + 4 * kk;
@@ -159,7 +200,9 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
                 bsum += (gz.x + gz.y) + (gz.z + gz.w);
             }
         }
+        LB_STAMP(3);
         __syncthreads();
+        LB_STAMP(1);
         // ---- gh = w0^T gz: wave (wp, wm) = (pixel half, channel group): D[px = 64 wp + 16 mt + 4 kk + r][m = 16 wm + r16]
         const int wp = wave >> 1, wm = wave & 1;
         f32x4 acc2[4];
@@ -172,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc2[mt] = mfma16(zrow[16 * mt], wv, acc2[mt]);
         }
+        LB_STAMP(4);
         // ---- gw0 += gz a^T over this tile's pixels: A[i = o][k = px] = sZ row 16 wave + r16, B[k = px][j = m] = sA row 16 t + r16
         {
             const float* zr = sZ + (16 * wave + r16) * LB_TS + kk;
@@ -184,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
                 acc3[1] = mfma16(zv, a1[4 * ks], acc3[1]);
             }
         }
+        LB_STAMP(5);
         __syncthreads();                // every wave is done with a: sA becomes the staging area of gh
+        LB_STAMP(1);
         // gh *= gelu'(h) at this lane's pixels (h from the staged x again)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -195,7 +241,9 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
             *reinterpret_cast<float4*>(sA + (16 * wm + r16) * LB_TS + q4) =
                 make_float4(acc2[mt][0] * uno_dgelu(h.x), acc2[mt][1] * uno_dgelu(h.y), acc2[mt][2] * uno_dgelu(h.z), acc2[mt][3] * uno_dgelu(h.w));
         }
+        LB_STAMP(6);
         __syncthreads();
+        LB_STAMP(1);
         // row-wise stores of gh: thread -> (row (tid >> 5) + 8 u, pixel quad tid & 31)
         {
             const int q4 = (tid & 31) * 4, px = p0 + q4;
@@ -212,8 +260,16 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
                 }
             }
         }
+        LB_STAMP(7);
         __syncthreads();                // before the next tile overwrites sA / sZ
+        LB_STAMP(1);
     }
+#ifdef UNO_LB_DEV
+    if (p.stamps && lane == 0) {
+        unsigned long long* o_ = p.stamps + (((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o_[i] = tph[i];
+    }
+#endif
     // partial sums of this workgroup: (64, 33) block, bias in column 32
     float* part = p.part + ((size_t)b * gridDim.x + blockIdx.x) * (LB_CO * (LB_CM + 1));
 #pragma unroll
@@ -242,6 +298,10 @@ int launch_lift_backward_fused(const float* x, const float* w1, const float* b1,
     LiftBwdParams p;
     p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.gh = gh; p.part = part;
     p.B = B; p.Cin = Cin; p.P = (int)P; p.npt = (int)((P + LB_PT - 1) / LB_PT);
+    p.stamps = nullptr;
+#ifdef UNO_LB_DEV
+    if (getenv("UNO_LB_STAMPS")) p.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("UNO_LB_STAMPS"), nullptr, 0));
+#endif
     p.pm_g = PixMap{(int)((long long)Hp * Wp), W, Wp - W, (unsigned)(((1ULL << 40) + W - 1) / (unsigned long long)W)};
     if ((long long)Hp * Wp * LB_CO >= (1LL << 31) || B > 65535) { set_error("lift_backward: tensor too large"); return -2; }
     static int lds_slot[64];
