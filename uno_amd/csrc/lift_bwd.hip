@@ -14,8 +14,8 @@
 // GEMM - lane (row r16, k kk) at r16 * 148 + kk - hit 64 distinct banks):
 //   sA [32][TS]  a = gelu(h)   (operand of the z and gw0 GEMMs; afterwards the staging area of gh's row-wise stores)
 //   sZ [64][TS]  g, then gz in place (the lane that reads g[o][px] writes gz[o][px])
-//   sW [32][80]  w0 as [m][o];  sWT [64][48]  w0 as [o][m];  sVH [32] (w1 row, b1);  sX [3][132] the tile's real channels
-// 79.6 KB: two workgroups per CU.  MFMA operand convention as everywhere in this library: D[i][j] = sum_k A[i][k] B[k][j], a lane
+//   sW [32][80]  w0 as [m][o];  sWT [64][48]  w0 as [o][m];  sVH [32] (w1 row, b1)
+// 78 KB: two workgroups per CU.  MFMA operand convention as everywhere in this library: D[i][j] = sum_k A[i][k] B[k][j], a lane
 // (r16, kk) supplies A[i = r16][k = kk] and B[k = kk][j = r16] and receives D[i = 4 kk + r][j = r16], r = 0..3.
 #include "uno_common.h"
 #include <cstdlib>
@@ -26,7 +26,6 @@ constexpr int LB_PT = 128;          // pixels per tile
 constexpr int LB_TS = 148;          // LDS row pitch (floats)
 constexpr int LB_CM = 32, LB_CO = 64;
 constexpr int LB_WS = 80, LB_WTS = 48;       // k rows 16 banks apart for the four k-lanes of a fragment read
-constexpr int LB_XS = 132;                     // pitch of the staged real channels
 constexpr int LB_TPW = 4;           // pixel tiles per workgroup (one block of partial sums per workgroup)
 
 struct LiftBwdParams {
@@ -53,6 +52,13 @@ __device__ __forceinline__ float4 lb_vh(const float4& t, const float4* q) {     
                        fmaf(t.z, q[2].z, fmaf(t.y, q[1].z, fmaf(t.x, q[0].z, t.w))), fmaf(t.z, q[2].w, fmaf(t.y, q[1].w, fmaf(t.x, q[0].w, t.w))));
 }
 
+// gelu(x) and gelu'(x) from one erf
+__device__ __forceinline__ void lb_gelu_both(float x, float& g, float& d) {
+    const float cdf = 0.5f * (1.f + uno_erf(x * 0.70710678118654752440f));
+    g = x * cdf;
+    d = fmaf(x, 0.39894228040143267794f * __expf(-0.5f * x * x), cdf);
+}
+
 __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lb_smem[];
     float* sA = lb_smem;                            // [32][TS]
@@ -60,7 +66,6 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     float* sW = sZ + LB_CO * LB_TS;                 // [32][68]   w0[o][m] at [m][o]
     float* sWT = sW + LB_CM * LB_WS;                // [64][36]   w0[o][m] at [o][m]
     float4* sVH = reinterpret_cast<float4*>(sWT + LB_CO * LB_WTS);      // [32]
-    float* sX = reinterpret_cast<float*>(sVH + LB_CM);                  // [3][LB_XS]: x of the tile (zero past the row end / past Cin)
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -149,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int p0 = tile * LB_PT;
-        // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at pixel quad tid & 31), g -> sZ (row-wise, 16-byte pieces)
+        // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at pixel quad tid & 31), g -> sZ (row-wise, 16-byte pieces); gelu'(h) of the
+        // same elements stays in registers for the end of the tile, where this thread stores exactly these elements of gh
+        float4 dh[4];
         {
             const int q4 = (tid & 31) * 4, px = p0 + q4;
             const float vm0 = px < P ? 1.f : 0.f, vm1 = px + 1 < P ? 1.f : 0.f, vm2 = px + 2 < P ? 1.f : 0.f, vm3 = px + 3 < P ? 1.f : 0.f;
@@ -157,8 +164,10 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
             for (int u = 0; u < 4; ++u) {
                 const int m = (tid >> 5) + 8 * u;
                 const float4 h = lb_vh(sVH[m], xq);
+                float4 a4;
+                lb_gelu_both(h.x, a4.x, dh[u].x); lb_gelu_both(h.y, a4.y, dh[u].y); lb_gelu_both(h.z, a4.z, dh[u].z); lb_gelu_both(h.w, a4.w, dh[u].w);
                 // pixels past the row end contribute nothing to the weight gradient: a = 0 there
-                *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(uno_gelu(h.x) * vm0, uno_gelu(h.y) * vm1, uno_gelu(h.z) * vm2, uno_gelu(h.w) * vm3);
+                *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(a4.x * vm0, a4.y * vm1, a4.z * vm2, a4.w * vm3);
             }
             if (g_two) {
 #pragma unroll
@@ -167,10 +176,6 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = gq[u];
-            if (tid < 32) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(sX + k * LB_XS + q4) = xq[k];
-            }
         }
         if (tile + 1 < t_end) load_tile(tile + 1);
         LB_STAMP(0);
@@ -231,26 +236,21 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         LB_STAMP(5);
         __syncthreads();                // every wave is done with a: sA becomes the staging area of gh
         LB_STAMP(1);
-        // gh *= gelu'(h) at this lane's pixels (h from the staged x again)
+        // w0^T gz -> sA in the row layout
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int q4 = 64 * wp + 16 * mt + 4 * kk;
-            const float4 xe[3] = {*reinterpret_cast<const float4*>(sX + q4), *reinterpret_cast<const float4*>(sX + LB_XS + q4),
-                                  *reinterpret_cast<const float4*>(sX + 2 * LB_XS + q4)};
-            const float4 h = lb_vh(sVH[16 * wm + r16], xe);
-            *reinterpret_cast<float4*>(sA + (16 * wm + r16) * LB_TS + q4) =
-                make_float4(acc2[mt][0] * uno_dgelu(h.x), acc2[mt][1] * uno_dgelu(h.y), acc2[mt][2] * uno_dgelu(h.z), acc2[mt][3] * uno_dgelu(h.w));
-        }
+        for (int mt = 0; mt < 4; ++mt)
+            *reinterpret_cast<float4*>(sA + (16 * wm + r16) * LB_TS + 64 * wp + 16 * mt + 4 * kk) = make_float4(acc2[mt][0], acc2[mt][1], acc2[mt][2], acc2[mt][3]);
         LB_STAMP(6);
         __syncthreads();
         LB_STAMP(1);
-        // row-wise stores of gh: thread -> (row (tid >> 5) + 8 u, pixel quad tid & 31)
+        // row-wise stores of gh = gelu'(h) * (w0^T gz): thread -> (row (tid >> 5) + 8 u, pixel quad tid & 31)
         {
             const int q4 = (tid & 31) * 4, px = p0 + q4;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int m = (tid >> 5) + 8 * u;
-                const float4 v = *reinterpret_cast<const float4*>(sA + m * LB_TS + q4);
+                float4 v = *reinterpret_cast<const float4*>(sA + m * LB_TS + q4);
+                v = make_float4(v.x * dh[u].x, v.y * dh[u].y, v.z * dh[u].z, v.w * dh[u].w);           // gh = gelu'(h) (w0^T gz)
                 float* dst = ghb + (size_t)m * P + px;
                 if (px + 3 < P) io_store4(dst, v.x, v.y, v.z, v.w);
                 else {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     if (kk == 0) part[(16 * wave + r16) * (LB_CM + 1) + LB_CM] = bsum;
 }
 
-static size_t lift_bwd_lds() { return sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS + LB_CO * LB_WTS + 3 * LB_XS) + sizeof(float4) * LB_CM; }
+static size_t lift_bwd_lds() { return sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS + LB_CO * LB_WTS) + sizeof(float4) * LB_CM; }
 
 bool lift_bwd_fused_applies(int Cin, int Cm, int Co, int W, long long P) {
     return Cin >= 1 && Cin <= 3 && Cm == LB_CM && Co == LB_CO && W >= 260 && P >= LB_PT && P < (1LL << 24);
