@@ -181,30 +181,48 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         LB_STAMP(0);
         __syncthreads();
         LB_STAMP(1);
-        // ---- z = w0 a: D[px = 16 mt + 4 kk + r][o = 16 wave + r16]
+        // ---- z = w0 a: D[px = 16 mt + 4 kk + r][o = 16 wave + r16], in two halves of four pixel tiles: the gelu' epilogue of the first
+        // half (16 evaluations per lane, ~370 VALU instructions) is placed BETWEEN the 32 MFMAs of the second half - inside one wave's
+        // program order independent VALU work runs while the matrix pipe is busy
         f32x4 acc1[8];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) acc1[mt] = f32x4{0, 0, 0, 0};
+        float wv[LB_CM / 4];
+#pragma unroll
+        for (int ks = 0; ks < LB_CM / 4; ++ks) wv[ks] = sW[(4 * ks + kk) * LB_WS + 16 * wave + r16];
 #pragma unroll
         for (int ks = 0; ks < LB_CM / 4; ++ks) {
-            const float wv = sW[(4 * ks + kk) * LB_WS + 16 * wave + r16];
             const float* arow = sA + (4 * ks + kk) * LB_TS + r16;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv, acc1[mt]);
+            for (int mt = 0; mt < 4; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv[ks], acc1[mt]);
         }
         LB_STAMP(2);
-        // gz = gelu'(z + b0) * g, in place in sZ (row 16 wave + r16: this wave's rows only)
-        {
-            float* zrow = sZ + (16 * wave + r16) * LB_TS + 4 * kk;
+        float* const zrow = sZ + (16 * wave + r16) * LB_TS + 4 * kk;       // gz = gelu'(z + b0) * g, in place in sZ (this wave's rows only)
+        auto gz_tile = [&](int mt) {
+            const float4 g4 = *reinterpret_cast<const float4*>(zrow + 16 * mt);
+            const float4 gz = make_float4(uno_dgelu(acc1[mt][0] + b0v) * g4.x, uno_dgelu(acc1[mt][1] + b0v) * g4.y,
+                                          uno_dgelu(acc1[mt][2] + b0v) * g4.z, uno_dgelu(acc1[mt][3] + b0v) * g4.w);
+            *reinterpret_cast<float4*>(zrow + 16 * mt) = gz;
+            bsum += (gz.x + gz.y) + (gz.z + gz.w);
+        };
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                const float4 g4 = *reinterpret_cast<const float4*>(zrow + 16 * mt);
-                const float4 gz = make_float4(uno_dgelu(acc1[mt][0] + b0v) * g4.x, uno_dgelu(acc1[mt][1] + b0v) * g4.y,
-                                              uno_dgelu(acc1[mt][2] + b0v) * g4.z, uno_dgelu(acc1[mt][3] + b0v) * g4.w);
-                *reinterpret_cast<float4*>(zrow + 16 * mt) = gz;
-                bsum += (gz.x + gz.y) + (gz.z + gz.w);
-            }
+        for (int ks = 0; ks < LB_CM / 4; ++ks) {
+            const float* arow = sA + (4 * ks + kk) * LB_TS + r16;
+#pragma unroll
+            for (int mt = 4; mt < 8; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv[ks], acc1[mt]);
         }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) gz_tile(mt);
+        __builtin_amdgcn_sched_group_barrier(0x100, 36, 0);             // the second half's operand reads, the first half's g
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);          // ~1/32 of the epilogue's VALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 4; mt < 8; ++mt) gz_tile(mt);
         LB_STAMP(3);
         __syncthreads();
         LB_STAMP(1);
