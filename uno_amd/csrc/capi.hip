@@ -551,7 +551,7 @@ int uno_lift_backward(const float* x, const float* w1, const float* b1, const fl
         // one kernel per pixel tile: gz never leaves LDS (lift_bwd.hip); ws = gh (B, Cm, P), then the blocks of partial sums, then K9's scratch
         float* gh = static_cast<float*>(ws);
         float* part = gh + (size_t)B * Cm * P;
-        const long long nparts = lift_bwd_fused_parts(B, P);
+        const long long nparts = lift_bwd_fused_parts(B, H, W);
         float* wws = part + (size_t)nparts * Co * (Cm + 1);
         if (int rc = launch_lift_backward_fused(x, w1, b1, w0, b0_, g_act, gh, part, B, Cin, H, W, Hp, Wp, s)) return rc;
         if (int rc = launch_channel_wgrad_finish(part, gw0, gb0, Cm, Co, nparts, 0, s)) return rc;

@@ -28,6 +28,45 @@ constexpr int LB_CM = 32, LB_CO = 64;
 constexpr int LB_WS = 80, LB_WTS = 48;       // k rows 16 banks apart for the four k-lanes of a fragment read
 constexpr int LB_TPW = 4;           // pixel tiles per workgroup (one block of partial sums per workgroup)
 
+// Pixel SLOTS.  Both kernels walk the H x W domain as H rows of W4 = W rounded up to a multiple of 4 slots: a thread's four slots are
+// four columns of ONE row in every tensor - dense (pitch W: x, gh) and padded (pitch Wp: g, act) alike - so no quad straddles a row
+// end, padded rows are read and written from 8 / 16-byte aligned addresses, and the one to three slots past a row's end are masked.
+// (Flat pixel quads, the first version, straddled row ends in the padded tensors: every quad of a tile with a row end was loaded twice.)
+struct LiftGeom {
+    int H, W, W4, nslot, npt;           // nslot = H * W4, npt = tiles of 128 slots
+    int skip_d, skip_p;                 // offset of slot s in row r: s + r * skip (dense: W - W4 <= 0, padded: Wp - W4)
+    int Pd, Pp;                         // plane sizes: H * W, Hp * Wp
+    unsigned magic;                     // ceil(2^40 / W4)
+};
+static LiftGeom lift_geom(int H, int W, int Hp, int Wp) {
+    LiftGeom g;
+    g.H = H; g.W = W; g.W4 = (W + 3) & ~3; g.nslot = H * g.W4; g.npt = (g.nslot + 127) / 128;
+    g.skip_d = W - g.W4; g.skip_p = Wp - g.W4; g.Pd = H * W; g.Pp = Hp * Wp;
+    g.magic = (unsigned)(((1ULL << 40) + g.W4 - 1) / (unsigned long long)g.W4);
+    return g;
+}
+// this thread's quad of a tile: row, valid slots (0 .. 4), offsets in a dense and in a padded plane
+struct LiftQuad { int nv, od, op; };
+__device__ __forceinline__ LiftQuad lift_quad(const LiftGeom& g, int s0, int s) {
+    const int r0 = (int)(((unsigned long long)(unsigned)s0 * g.magic) >> 40);      // (uniform) row of the tile's first slot
+    const int r = r0 + (s >= (r0 + 1) * g.W4 ? 1 : 0);                             // a tile of 128 slots touches two rows at most (W4 >= 260)
+    const int col = s - r * g.W4;
+    return LiftQuad{r < g.H ? min(max(g.W - col, 0), 4) : 0, s + r * g.skip_d, s + r * g.skip_p};
+}
+// four floats at plane[off ..] from an address clamped into the plane (the last quads of a plane's last row), shifted back into place
+__device__ __forceinline__ float4 lift_ld4(const float* plane, int off, int plane_len) {
+    const int oc = max(min(off, plane_len - 4), 0);
+    const float4 v = io_ld4(plane + oc);
+    const int sh = off - oc;
+    float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
+    if (sh & 1) { t0 = t1; t1 = t2; t2 = t3; }
+    if (sh & 2) { t0 = t2; t1 = t3; }
+    return make_float4(t0, t1, t2, t3);           // (elements past the plane's end hold stale values: the caller masks by nv)
+}
+__device__ __forceinline__ float4 lift_mask(const float4& v, int nv) {
+    return make_float4(nv > 0 ? v.x : 0.f, nv > 1 ? v.y : 0.f, nv > 2 ? v.z : 0.f, nv > 3 ? v.w : 0.f);
+}
+
 struct LiftBwdParams {
     const float* x;         // (B, Cin, P)
     const float* w1;        // (32, Cin)
@@ -37,16 +76,11 @@ struct LiftBwdParams {
     const float* g;         // (B, 64, Hp, Wp)
     float* gh;              // (B, 32, P)
     float* part;            // (B * wg_per_batch, 64, 33)
-    int B, Cin, P, npt;
-    PixMap pm_g;            // pixel -> offset inside a padded plane of g
+    int B, Cin;
+    LiftGeom geo;
     unsigned long long* stamps;     // development (-DUNO_LB_DEV): per-phase cycles of every wave, 8 values each
 };
 
-__device__ __forceinline__ float4 lb_load4_run(const float* plane, const PixRun& run, int px) {      // four consecutive pixels; rows of any length
-    const int f0 = run(px), f3 = run(px + 3);
-    if (f3 - f0 == 3) return io_ld4(plane + f0);
-    return make_float4(plane[f0], plane[run(px + 1)], plane[run(px + 2)], plane[f3]);
-}
 __device__ __forceinline__ float4 lb_vh(const float4& t, const float4* q) {       // t = (w[c][0..2], b[c]); q: the real channels at 4 pixels
     return make_float4(fmaf(t.z, q[2].x, fmaf(t.y, q[1].x, fmaf(t.x, q[0].x, t.w))), fmaf(t.z, q[2].y, fmaf(t.y, q[1].y, fmaf(t.x, q[0].y, t.w))),
                        fmaf(t.z, q[2].z, fmaf(t.y, q[1].z, fmaf(t.x, q[0].z, t.w))), fmaf(t.z, q[2].w, fmaf(t.y, q[1].w, fmaf(t.x, q[0].w, t.w))));
@@ -69,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const int P = p.P;
+    const LiftGeom& G = p.geo;
 
     // weights: once per workgroup
 #pragma unroll
@@ -84,24 +118,12 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         sVH[tid] = make_float4(wr[0], p.Cin > 1 ? wr[1] : 0.f, p.Cin > 2 ? wr[2] : 0.f, p.b1 ? p.b1[tid] : 0.f);
     }
     const float b0v = p.b0 ? p.b0[16 * wave + r16] : 0.f;          // z's channel of this lane in the MFMA layout
-    const float* xb = p.x + (size_t)b * p.Cin * P;
-    const float* gb = p.g + (size_t)b * LB_CO * p.pm_g.PS;
-    float* ghb = p.gh + (size_t)b * LB_CM * P;
+    const float* xb = p.x + (size_t)b * p.Cin * G.Pd;
+    const float* gb = p.g + (size_t)b * LB_CO * G.Pp;
+    float* ghb = p.gh + (size_t)b * LB_CM * G.Pd;
 
     f32x4 acc3[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};       // gw0 partial: D[o = 16 wave + 4 kk + r][m = 16 t + r16], over all tiles of this workgroup
     float bsum = 0.f;                                               // gb0 partial of channel 16 wave + r16 (this lane's pixels)
-
-    // the real channels at four pixels starting at px (zero past the row end; channels past Cin zero)
-    auto x_quads = [&](int px, float4* q) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float* row = xb + (size_t)min(k, p.Cin - 1) * P;
-            float4 v;
-            if (px + 3 < P) v = io_ld4(row + px);
-            else v = make_float4(px < P ? row[px] : 0.f, px + 1 < P ? row[px + 1] : 0.f, px + 2 < P ? row[px + 2] : 0.f, 0.f);
-            q[k] = k < p.Cin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
 
 #ifdef UNO_LB_DEV
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
@@ -109,73 +131,42 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
 #else
 #define LB_STAMP(i) do { } while (0)
 #endif
-    const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, p.npt);
-    // a tile's global loads: this thread's pixel quad tid & 31 of the real channels and of rows (tid >> 5) + 8 u of g.  The NEXT tile's
-    // are issued as soon as the current tile's values are in LDS and arrive while its three GEMMs run (one tile per workgroup at a time
-    // left the loads un-overlapped: two workgroups per CU cannot hide them).  Interior tiles take straight-line code - the guarded form
-    // (branches around scalar loads, a wait inside each) serialised the eight row loads: 17 k of a tile's 38 k cycles.  A tile that
-    // contains the end of a row of the padded grid (at most one: rows are longer than a tile) loads every quad twice, from its first and
-    // from its last pixel's address; the lanes of the one straddling quad pick per element in phase 0 (all others: the same address).
-    float4 xq[3], gq[8], gq2[8];
-    bool g_two = false;         // (uniform) the tile in the registers has a row end inside it
-    int g_nb = 4;               // elements of this thread's quad before that row end
+    const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
+    // a tile's global loads: this thread's quad (slots 4 (tid & 31) ..) of the real channels and of rows (tid >> 5) + 8 u of g - straight-
+    // line code (the guarded form of the first version, branches around scalar tails with a wait inside each, serialised the eight row
+    // loads: 17 k of a tile's 38 k cycles).  The NEXT tile's loads are issued as soon as the current tile's values are in LDS and arrive
+    // while its GEMMs run (two workgroups per CU cannot hide them otherwise).
+    float4 xq[3], gq[8];
+    LiftQuad cur = {0, 0, 0}, nxt = {0, 0, 0};
     auto load_tile = [&](int tile) {
-        const int p0 = tile * LB_PT, px = p0 + (tid & 31) * 4;
-        const PixRun grun = pix_run(p.pm_g, p0);
-        if (p0 + LB_PT <= P) {                                  // (uniform) all 128 pixels exist
+        const int s0 = tile * LB_PT;
+        nxt = lift_quad(G, s0, s0 + (tid & 31) * 4);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) xq[k] = io_ld4(xb + (size_t)min(k, p.Cin - 1) * P + px);
-            const int f0 = grun(px), f3 = grun(px + 3);
-            g_two = grun.bound < p0 + LB_PT;
-            g_nb = min(max(grun.bound - px, 0), 4);
-            if (g_two) {
+        for (int k = 0; k < 3; ++k) xq[k] = lift_ld4(xb + (size_t)min(k, p.Cin - 1) * G.Pd, nxt.od, G.Pd);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float* grow = gb + (size_t)((tid >> 5) + 8 * u) * p.pm_g.PS;
-                    gq[u] = io_ld4(grow + f0);
-                    gq2[u] = io_ld4(grow + f3 - 3);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) gq[u] = io_ld4(gb + (size_t)((tid >> 5) + 8 * u) * p.pm_g.PS + f0);
-            }
-            return;
-        }
-        g_two = false;
-        x_quads(px, xq);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float* grow = gb + (size_t)((tid >> 5) + 8 * u) * p.pm_g.PS;
-            if (px + 3 < P) gq[u] = lb_load4_run(grow, grun, px);
-            else gq[u] = make_float4(px < P ? grow[grun(px)] : 0.f, px + 1 < P ? grow[grun(px + 1)] : 0.f, px + 2 < P ? grow[grun(px + 2)] : 0.f, 0.f);
-        }
+        for (int u = 0; u < 8; ++u) gq[u] = lift_ld4(gb + (size_t)((tid >> 5) + 8 * u) * G.Pp, nxt.op, G.Pp);
     };
     if (t_begin < t_end) load_tile(t_begin);
     __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const int p0 = tile * LB_PT;
-        // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at pixel quad tid & 31), g -> sZ (row-wise, 16-byte pieces); gelu'(h) of the
+        cur = nxt;
+        // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at quad tid & 31), g -> sZ (row-wise, 16-byte pieces); gelu'(h) of the
         // same elements stays in registers for the end of the tile, where this thread stores exactly these elements of gh
         float4 dh[4];
         {
-            const int q4 = (tid & 31) * 4, px = p0 + q4;
-            const float vm0 = px < P ? 1.f : 0.f, vm1 = px + 1 < P ? 1.f : 0.f, vm2 = px + 2 < P ? 1.f : 0.f, vm3 = px + 3 < P ? 1.f : 0.f;
+            const int q4 = (tid & 31) * 4;
+            const float vm0 = cur.nv > 0 ? 1.f : 0.f, vm1 = cur.nv > 1 ? 1.f : 0.f, vm2 = cur.nv > 2 ? 1.f : 0.f, vm3 = cur.nv > 3 ? 1.f : 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int m = (tid >> 5) + 8 * u;
                 const float4 h = lb_vh(sVH[m], xq);
                 float4 a4;
                 lb_gelu_both(h.x, a4.x, dh[u].x); lb_gelu_both(h.y, a4.y, dh[u].y); lb_gelu_both(h.z, a4.z, dh[u].z); lb_gelu_both(h.w, a4.w, dh[u].w);
-                // pixels past the row end contribute nothing to the weight gradient: a = 0 there
+                // slots past a row's end contribute nothing to the weight gradient: a = 0 there
                 *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(a4.x * vm0, a4.y * vm1, a4.z * vm2, a4.w * vm3);
             }
-            if (g_two) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    gq[u] = make_float4(g_nb > 0 ? gq[u].x : gq2[u].x, g_nb > 1 ? gq[u].y : gq2[u].y, g_nb > 2 ? gq[u].z : gq2[u].z, g_nb > 3 ? gq[u].w : gq2[u].w);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = gq[u];
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = lift_mask(gq[u], cur.nv);
         }
         if (tile + 1 < t_end) load_tile(tile + 1);
         LB_STAMP(0);
@@ -261,20 +252,20 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         LB_STAMP(6);
         __syncthreads();
         LB_STAMP(1);
-        // row-wise stores of gh = gelu'(h) * (w0^T gz): thread -> (row (tid >> 5) + 8 u, pixel quad tid & 31)
+        // row-wise stores of gh = gelu'(h) * (w0^T gz): thread -> (row (tid >> 5) + 8 u, quad tid & 31)
         {
-            const int q4 = (tid & 31) * 4, px = p0 + q4;
+            const int q4 = (tid & 31) * 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int m = (tid >> 5) + 8 * u;
                 float4 v = *reinterpret_cast<const float4*>(sA + m * LB_TS + q4);
-                v = make_float4(v.x * dh[u].x, v.y * dh[u].y, v.z * dh[u].z, v.w * dh[u].w);           // gh = gelu'(h) (w0^T gz)
-                float* dst = ghb + (size_t)m * P + px;
-                if (px + 3 < P) io_store4(dst, v.x, v.y, v.z, v.w);
+                v = make_float4(v.x * dh[u].x, v.y * dh[u].y, v.z * dh[u].z, v.w * dh[u].w);
+                float* dst = ghb + (size_t)m * G.Pd + cur.od;
+                if (cur.nv == 4) io_store4(dst, v.x, v.y, v.z, v.w);
                 else {
-                    if (px < P) dst[0] = v.x;
-                    if (px + 1 < P) dst[1] = v.y;
-                    if (px + 2 < P) dst[2] = v.z;
+                    if (cur.nv > 0) dst[0] = v.x;
+                    if (cur.nv > 1) dst[1] = v.y;
+                    if (cur.nv > 2) dst[2] = v.z;
                 }
             }
         }
@@ -299,35 +290,37 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     if (kk == 0) part[(16 * wave + r16) * (LB_CM + 1) + LB_CM] = bsum;
 }
 
+// (A forward kernel of the same scheme - a -> LDS, z on the MFMA with the first half's GELU between the second half's MFMAs, the 64 x 128
+// result through LDS into aligned row-wise stores - was built and measured in round 5: 345-352 us against 325-341 us for the generic K8
+// tile with the virtual input, which keeps that layer.  Not kept.)
+
 static size_t lift_bwd_lds() { return sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS + LB_CO * LB_WTS) + sizeof(float4) * LB_CM; }
 
 bool lift_bwd_fused_applies(int Cin, int Cm, int Co, int W, long long P) {
-    return Cin >= 1 && Cin <= 3 && Cm == LB_CM && Co == LB_CO && W >= 260 && P >= LB_PT && P < (1LL << 24);
+    return Cin >= 1 && Cin <= 3 && Cm == LB_CM && Co == LB_CO && W >= 260 && P >= LB_PT && P < (1LL << 24) - (1 << 16);
 }
 
-long long lift_bwd_fused_parts(int B, long long P) {                // (64, 33) blocks of partial sums the fused kernel leaves
-    const long long npt = (P + LB_PT - 1) / LB_PT;
+long long lift_bwd_fused_parts(int B, int H, int W) {                // (64, 33) blocks of partial sums the fused kernel leaves
+    const long long npt = ((long long)H * ((W + 3) & ~3) + LB_PT - 1) / LB_PT;
     return (long long)B * ((npt + LB_TPW - 1) / LB_TPW);
 }
 
 int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* gh,
                                float* part, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s) {
-    const long long P = (long long)H * W;
     LiftBwdParams p;
     p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.gh = gh; p.part = part;
-    p.B = B; p.Cin = Cin; p.P = (int)P; p.npt = (int)((P + LB_PT - 1) / LB_PT);
+    p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp);
     p.stamps = nullptr;
 #ifdef UNO_LB_DEV
     if (getenv("UNO_LB_STAMPS")) p.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("UNO_LB_STAMPS"), nullptr, 0));
 #endif
-    p.pm_g = PixMap{(int)((long long)Hp * Wp), W, Wp - W, (unsigned)(((1ULL << 40) + W - 1) / (unsigned long long)W)};
     if ((long long)Hp * Wp * LB_CO >= (1LL << 31) || B > 65535) { set_error("lift_backward: tensor too large"); return -2; }
     static int lds_slot[64];
     const size_t lds = lift_bwd_lds();
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(lift_backward_kernel), lds, lds_slot)) { set_error("lift_backward: cannot raise dynamic LDS to %zu", lds); return -4; }
     {
-        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)P * (Cin + LB_CO + LB_CM), s);
-        hipLaunchKernelGGL(lift_backward_kernel, dim3((unsigned)((p.npt + LB_TPW - 1) / LB_TPW), (unsigned)B), dim3(256), lds, s, p);
+        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)H * W * (Cin + LB_CO + LB_CM), s);
+        hipLaunchKernelGGL(lift_backward_kernel, dim3((unsigned)((p.geo.npt + LB_TPW - 1) / LB_TPW), (unsigned)B), dim3(256), lds, s, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("lift_backward launch: %s", hipGetErrorString(e)); return -5; }
