@@ -548,14 +548,13 @@ int uno_lift_backward(const float* x, const float* w1, const float* b1, const fl
     if (!x || !w1 || !w0 || !g_act || !ws) { set_error("uno_lift_backward: null pointer"); return -1; }
     const long long P = (long long)H * W;
     if (lift_bwd_fused_applies(Cin, Cm, Co, W, P)) {
-        // one kernel per pixel tile: gz never leaves LDS (lift_bwd.hip); ws = gh (B, Cm, P), then the blocks of partial sums, then K9's scratch
-        float* gh = static_cast<float*>(ws);
-        float* part = gh + (size_t)B * Cm * P;
+        // one kernel per pixel tile: neither gz nor gh leaves the chip (lift_bwd.hip); ws = the two arrays of partial-sum blocks
+        float* part = static_cast<float*>(ws);
         const long long nparts = lift_bwd_fused_parts(B, H, W);
-        float* wws = part + (size_t)nparts * Co * (Cm + 1);
-        if (int rc = launch_lift_backward_fused(x, w1, b1, w0, b0_, g_act, gh, part, B, Cin, H, W, Hp, Wp, s)) return rc;
+        float* part1 = part + (size_t)nparts * Co * (Cm + 1);
+        if (int rc = launch_lift_backward_fused(x, w1, b1, w0, b0_, g_act, part, part1, B, Cin, H, W, Hp, Wp, s)) return rc;
         if (int rc = launch_channel_wgrad_finish(part, gw0, gb0, Cm, Co, nparts, 0, s)) return rc;
-        return launch_channel_wgrad(gh, x, gw1, gb1, wws, B, Cin, Cm, P, 0, 0, s);
+        return launch_channel_wgrad_finish(part1, gw1, gb1, Cin, Cm, nparts, 0, s);
     }
     // (measured and dropped, round 5: batch entries in groups whose gz stays in the 256 MB Infinity Cache between the kernel that writes
     // it and the two that read it - groups of 2 / 4 / 8 of 16 ran the step at 13.1-13.3 / 12.8 / 12.65 ms against 12.37-12.40 whole: the

@@ -2,13 +2,13 @@
 //
 //   h = w1 x + b1 (Cm = 32 channels from Cin <= 3),  a = gelu(h),  z = w0 a + b0 (Co = 64),  act = pad(gelu(z))        forward
 //   gz = gelu'(z) * g[..., :H, :W]                      (g: the gradient of the padded activation)
-//   gh = gelu'(h) * (w0^T gz)                           -> stored: the weight gradient of fc_n1 is taken from it (K9, few-input form)
+//   gh = gelu'(h) * (w0^T gz),  gw1 = sum_px gh x^T,  gb1 = sum_px gh      (x is data: gh has no other consumer and is not stored)
 //   gw0 = sum_px gz a^T,  gb0 = sum_px gz               -> one (Co, Cm + 1) block of partial sums per workgroup, summed by K9's second stage
 //
 // The four-kernel form (capi.hip, uno_lift_backward) writes gz (64 channels) once and reads it twice: 2.2 GB of the pass's 3.8 GB.
 // Here gz lives in LDS only: a workgroup of 256 threads owns 128 pixels, recomputes a and z, and runs the three small GEMMs
 // (z: 64 x 32 x 128, gh: 32 x 64 x 128, gw0: 64 x 32 over its 128 pixels) on v_mfma_f32_16x16x4_f32 from LDS-resident operands.
-// HBM traffic: x (12 B per pixel), g (256 B), gh (128 B) and 8.4 KB of partial sums per TPW tiles.
+// HBM traffic: x (12 B per pixel), g (256 B) and 9 KB of partial sums per TPW tiles.
 //
 // LDS (pitch TS = 148 floats: rows 16-byte aligned; 148 mod 64 = 20 makes the k-contiguous fragment reads of the weight-gradient
 // GEMM - lane (row r16, k kk) at r16 * 148 + kk - hit 64 distinct banks):
@@ -74,8 +74,8 @@ struct LiftBwdParams {
     const float* w0;        // (64, 32)
     const float* b0;        // (64) or nullptr
     const float* g;         // (B, 64, Hp, Wp)
-    float* gh;              // (B, 32, P)
-    float* part;            // (B * wg_per_batch, 64, 33)
+    float* part;            // (B * wg_per_batch, 64, 33): fc0's weight / bias gradient, one block of partial sums per workgroup
+    float* part1;           // (B * wg_per_batch, 32, Cin + 1): fc_n1's - gh = gelu'(h) (w0^T gz) never leaves the kernel either
     int B, Cin;
     LiftGeom geo;
     unsigned long long* stamps;     // development (-DUNO_LB_DEV): per-phase cycles of every wave, 8 values each
@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     const float b0v = p.b0 ? p.b0[16 * wave + r16] : 0.f;          // z's channel of this lane in the MFMA layout
     const float* xb = p.x + (size_t)b * p.Cin * G.Pd;
     const float* gb = p.g + (size_t)b * LB_CO * G.Pp;
-    float* ghb = p.gh + (size_t)b * LB_CM * G.Pd;
 
     f32x4 acc3[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};       // gw0 partial: D[o = 16 wave + 4 kk + r][m = 16 t + r16], over all tiles of this workgroup
     float bsum = 0.f;                                               // gb0 partial of channel 16 wave + r16 (this lane's pixels)
@@ -137,6 +136,12 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     // loads: 17 k of a tile's 38 k cycles).  The NEXT tile's loads are issued as soon as the current tile's values are in LDS and arrive
     // while its GEMMs run (two workgroups per CU cannot hide them otherwise).
     float4 xq[3], gq[8];
+    float4 xc[3];               // the CURRENT tile's real channels (masked): operand of fc_n1's weight gradient at the end of the tile
+    float g1[4][4];             // fc_n1: partial sums of rows (tid >> 5) + 8 u against the three real channels, and of the rows themselves
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g1[u][k] = 0.f;
     LiftQuad cur = {0, 0, 0}, nxt = {0, 0, 0};
     auto load_tile = [&](int tile) {
         const int s0 = tile * LB_PT;
@@ -150,6 +155,8 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
         cur = nxt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xc[k] = lift_mask(xq[k], cur.nv);
         // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at quad tid & 31), g -> sZ (row-wise, 16-byte pieces); gelu'(h) of the
         // same elements stays in registers for the end of the tile, where this thread stores exactly these elements of gh
         float4 dh[4];
@@ -252,21 +259,18 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         LB_STAMP(6);
         __syncthreads();
         LB_STAMP(1);
-        // row-wise stores of gh = gelu'(h) * (w0^T gz): thread -> (row (tid >> 5) + 8 u, quad tid & 31)
+        // gh = gelu'(h) * (w0^T gz) in the row layout, thread -> (row (tid >> 5) + 8 u, quad tid & 31): not stored - x is data, gh's only
+        // consumer is fc_n1's weight gradient gw1 = sum gh x^T, gb1 = sum gh, accumulated here (3 real channels: 4 FMAs per value)
         {
             const int q4 = (tid & 31) * 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int m = (tid >> 5) + 8 * u;
                 float4 v = *reinterpret_cast<const float4*>(sA + m * LB_TS + q4);
-                v = make_float4(v.x * dh[u].x, v.y * dh[u].y, v.z * dh[u].z, v.w * dh[u].w);
-                float* dst = ghb + (size_t)m * G.Pd + cur.od;
-                if (cur.nv == 4) io_store4(dst, v.x, v.y, v.z, v.w);
-                else {
-                    if (cur.nv > 0) dst[0] = v.x;
-                    if (cur.nv > 1) dst[1] = v.y;
-                    if (cur.nv > 2) dst[2] = v.z;
-                }
+                v = lift_mask(make_float4(v.x * dh[u].x, v.y * dh[u].y, v.z * dh[u].z, v.w * dh[u].w), cur.nv);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g1[u][k] = fmaf(v.x, xc[k].x, fmaf(v.y, xc[k].y, fmaf(v.z, xc[k].z, fmaf(v.w, xc[k].w, g1[u][k]))));
+                g1[u][3] += (v.x + v.y) + (v.z + v.w);
             }
         }
         LB_STAMP(7);
@@ -288,6 +292,20 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
     if (kk == 0) part[(16 * wave + r16) * (LB_CM + 1) + LB_CM] = bsum;
+    // fc_n1: the 32 lanes of a half wave hold the same rows; (32, Cin + 1) block, bias in column Cin
+    float* part1 = p.part1 + ((size_t)b * gridDim.x + blockIdx.x) * (LB_CM * (p.Cin + 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = g1[u][k];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+            if ((tid & 31) == 0) {
+                const int m = (tid >> 5) + 8 * u;
+                if (k < p.Cin) part1[m * (p.Cin + 1) + k] = v;
+                else if (k == 3) part1[m * (p.Cin + 1) + p.Cin] = v;
+            }
+        }
 }
 
 // (A forward kernel of the same scheme - a -> LDS, z on the MFMA with the first half's GELU between the second half's MFMAs, the 64 x 128
@@ -305,10 +323,10 @@ long long lift_bwd_fused_parts(int B, int H, int W) {                // (64, 33)
     return (long long)B * ((npt + LB_TPW - 1) / LB_TPW);
 }
 
-int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* gh,
-                               float* part, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s) {
+int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* part,
+                               float* part1, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s) {
     LiftBwdParams p;
-    p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.gh = gh; p.part = part;
+    p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.part = part; p.part1 = part1;
     p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp);
     p.stamps = nullptr;
 #ifdef UNO_LB_DEV
@@ -319,7 +337,7 @@ int launch_lift_backward_fused(const float* x, const float* w1, const float* b1,
     const size_t lds = lift_bwd_lds();
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(lift_backward_kernel), lds, lds_slot)) { set_error("lift_backward: cannot raise dynamic LDS to %zu", lds); return -4; }
     {
-        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)H * W * (Cin + LB_CO + LB_CM), s);
+        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)H * W * (Cin + LB_CO), s);
         hipLaunchKernelGGL(lift_backward_kernel, dim3((unsigned)((p.geo.npt + LB_TPW - 1) / LB_TPW), (unsigned)B), dim3(256), lds, s, p);
     }
     const hipError_t e = hipGetLastError();
