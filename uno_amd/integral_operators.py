@@ -944,7 +944,7 @@ class _LiftFn(torch.autograd.Function):
 
 def lift_gelu_pad(x: torch.Tensor, fc_n1: nn.Module, fc0: nn.Module, pad_h: int, pad_w: int) -> torch.Tensor:
     """F.pad(F.gelu(fc0(F.gelu(fc_n1(x)))), [0, pad_w, 0, pad_h]) for a channels-first x (B, Cin, H, W) and two nn.Linear layers, as one
-    forward kernel and one backward kernel (+ the first layer's weight gradient) that store neither intermediate, where the shapes allow (at most 3 input channels, 16 or 32
+    forward kernel and one backward kernel that store neither intermediate nor their gradients, where the shapes allow (at most 3 input channels, 16 or 32
     in the middle, width >= 260, float32, x without gradient); the layer-by-layer forms otherwise."""
     w1, w0 = fc_n1.weight, fc0.weight
     if x.dim() == 4 and _dev_act(x) and not x.requires_grad and w1.dtype == torch.float32 and w0.dtype == torch.float32 and pad_h >= 0 and pad_w >= 0:
