@@ -26,7 +26,10 @@ constexpr int LB_PT = 128;          // pixels per tile
 constexpr int LB_TS = 148;          // LDS row pitch (floats)
 constexpr int LB_CM = 32, LB_CO = 64;
 constexpr int LB_WS = 80, LB_WTS = 48;       // k rows 16 banks apart for the four k-lanes of a fragment read
-constexpr int LB_TPW = 4;           // pixel tiles per workgroup (one block of partial sums per workgroup)
+#ifndef UNO_LB_TPW
+#define UNO_LB_TPW 8
+#endif
+constexpr int LB_TPW = UNO_LB_TPW;  // pixel tiles per workgroup (one block of partial sums per workgroup)
 
 // Pixel SLOTS.  Both kernels walk the H x W domain as H rows of W4 = W rounded up to a multiple of 4 slots: a thread's four slots are
 // four columns of ONE row in every tensor - dense (pitch W: x, gh) and padded (pitch Wp: g, act) alike - so no quad straddles a row
