@@ -317,3 +317,33 @@ def test_reads_stay_inside_inputs_training_steps():
             out.append(loss.detach())
         res.append(out + [p.detach().clone() for p in model.parameters()])
     _same(res[1], res[0], "NS-3D steps")
+
+
+# ---- round 5: the lift kernels (virtual first layer, K15) and the windowed fc1 - GELU - fc2 path need widths >= 260, which the ragged
+# S = 75 steps above never reach
+def _lift_and_window_pass(wrap):
+    from uno_amd.integral_operators import channel_mix_cat_project, lift_gelu_pad
+    torch.manual_seed(21)
+    H, W, pad = 9, 261, 3
+    f1, f0 = torch.nn.Linear(3, 32).to(dev()), torch.nn.Linear(32, 64).to(dev())
+    fc1, fc2 = torch.nn.Linear(128, 64).to(dev()), torch.nn.Linear(64, 1).to(dev())
+    x = torch.randn(2, 3, H, W, device=dev())
+    c5 = torch.randn(2, 64, H + pad, W + pad, device=dev(), requires_grad=True)
+    gout = torch.randn(2, 1, H, W, device=dev())
+    if wrap:
+        f1, f0, fc1, fc2 = (_wrap_module(m) for m in (f1, f0, fc1, fc2))
+        x, c5, gout = nan_wrapped(x), nan_wrapped(c5), nan_wrapped(gout)
+    lifted = lift_gelu_pad(x, f1, f0, pad, pad)
+    out = channel_mix_cat_project([c5, lifted], fc1.weight, fc1.bias, fc2.weight, fc2.bias, gelu_first=True, crop=(H, W))[:, :, :H, :W]
+    out.backward(gout)
+    return [out.detach(), c5.grad] + [p.grad for m in (f1, f0, fc1, fc2) for p in m.parameters()]
+
+
+def test_lift_and_window_kernels(redzone):
+    res = _lift_and_window_pass(False)
+    assert all(bool(torch.isfinite(t).all()) for t in res)
+    assert redzone.check("lift + windowed projection") >= 8
+
+
+def test_reads_stay_inside_inputs_lift_and_window():
+    _same(_lift_and_window_pass(True), _lift_and_window_pass(False), "lift + windowed projection")

@@ -217,7 +217,11 @@ def test_clear_border():
 
 
 @pytest.mark.parametrize("B,Cin,Cm,Co,H,W,ph,pw,bias", [(2, 3, 32, 64, 37, 283, 6, 6, True), (1, 3, 32, 64, 421, 421, 25, 25, True), (2, 1, 16, 24, 9, 300, 0, 5, True),
-                                                       (2, 2, 32, 40, 5, 264, 2, 0, False), (3, 3, 16, 128, 4, 260, 1, 1, True)])
+                                                       (2, 2, 32, 40, 5, 264, 2, 0, False), (3, 3, 16, 128, 4, 260, 1, 1, True),
+                                                       # K15 (32 / 64 channels): no padding at all (clamped loads at the planes' ends), a width that is a
+                                                       # multiple of 4, one and two real channels, no biases, many tiles per workgroup and a ragged last one
+                                                       (2, 3, 32, 64, 7, 261, 0, 0, True), (1, 1, 32, 64, 3, 264, 0, 3, False), (2, 2, 32, 64, 41, 300, 5, 0, True),
+                                                       (1, 3, 32, 64, 130, 263, 1, 2, True)])
 def test_whole_lift_without_stored_intermediates(B, Cin, Cm, Co, H, W, ph, pw, bias):
     """uno_lift_forward / uno_lift_backward against float64 torch: F.pad(gelu(fc0(gelu(fc_n1(x))))) and the four parameter gradients, with
     the first layer's output virtual in every kernel (interior and edge pixel tiles, partial channel tiles, 1 - 3 real channels)"""
