@@ -512,6 +512,10 @@ int uno_lift_forward(const float* x, const float* w1, const float* b1, const flo
     if (int rc = lift_check("uno_lift_forward", B, Cin, Cm, Co, H, W, Hp, Wp)) return rc;
     if (B == 0) return 0;
     if (!x || !w1 || !w0 || !act) { set_error("uno_lift_forward: null pointer"); return -1; }
+    if (lift_bwd_fused_applies(Cin, Cm, Co, W, (long long)H * W) && (Wp & ~3) >= 260 && (Wp & ~3) >= W) {      // K16 (lift_bwd.hip): the dedicated kernel at the Darcy widths
+        if (int rc = launch_lift_forward_fused(x, w1, b1, w0, b0, act, B, Cin, H, W, Hp, Wp, (hipStream_t)stream)) return rc;
+        return launch_clear_border(act, (long long)B * Co, Hp, Wp, H, Wp, (hipStream_t)stream);         // the rows below the domain
+    }
     ChannelMixArgs a{};
     a.x = x; a.w = w0; a.bias = b0; a.y = nullptr; a.y_act = act;
     a.B = B; a.Ci = Cm; a.Co = Co; a.C1 = Cm; a.Co1 = Co; a.P = (long long)H * W; a.act_in = 1;

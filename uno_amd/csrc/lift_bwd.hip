@@ -41,20 +41,20 @@ struct LiftGeom {
     int Pd, Pp;                         // plane sizes: H * W, Hp * Wp
     unsigned magic;                     // ceil(2^40 / W4)
 };
-static LiftGeom lift_geom(int H, int W, int Hp, int Wp) {
+static LiftGeom lift_geom(int H, int W, int Hp, int Wp, int slots_per_row = 0) {
     LiftGeom g;
-    g.H = H; g.W = W; g.W4 = (W + 3) & ~3; g.nslot = H * g.W4; g.npt = (g.nslot + 127) / 128;
+    g.H = H; g.W = W; g.W4 = slots_per_row ? slots_per_row : ((W + 3) & ~3); g.nslot = H * g.W4; g.npt = (g.nslot + 127) / 128;
     g.skip_d = W - g.W4; g.skip_p = Wp - g.W4; g.Pd = H * W; g.Pp = Hp * Wp;
     g.magic = (unsigned)(((1ULL << 40) + g.W4 - 1) / (unsigned long long)g.W4);
     return g;
 }
 // this thread's quad of a tile: row, valid slots (0 .. 4), offsets in a dense and in a padded plane
-struct LiftQuad { int nv, od, op; };
+struct LiftQuad { int nv, od, op, row_ok, last; };         // row_ok: the row exists; last: the quad is its row's last one
 __device__ __forceinline__ LiftQuad lift_quad(const LiftGeom& g, int s0, int s) {
     const int r0 = (int)(((unsigned long long)(unsigned)s0 * g.magic) >> 40);      // (uniform) row of the tile's first slot
     const int r = r0 + (s >= (r0 + 1) * g.W4 ? 1 : 0);                             // a tile of 128 slots touches two rows at most (W4 >= 260)
     const int col = s - r * g.W4;
-    return LiftQuad{r < g.H ? min(max(g.W - col, 0), 4) : 0, s + r * g.skip_d, s + r * g.skip_p};
+    return LiftQuad{r < g.H ? min(max(g.W - col, 0), 4) : 0, s + r * g.skip_d, s + r * g.skip_p, r < g.H ? 1 : 0, col == g.W4 - 4 ? 1 : 0};
 }
 // four floats at plane[off ..] from an address clamped into the plane (the last quads of a plane's last row), shifted back into place
 __device__ __forceinline__ float4 lift_ld4(const float* plane, int off, int plane_len) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int k = 0; k < 4; ++k) g1[u][k] = 0.f;
-    LiftQuad cur = {0, 0, 0}, nxt = {0, 0, 0};
+    LiftQuad cur = {0, 0, 0, 0, 0}, nxt = {0, 0, 0, 0, 0};
     auto load_tile = [&](int tile) {
         const int s0 = tile * LB_PT;
         nxt = lift_quad(G, s0, s0 + (tid & 31) * 4);
@@ -311,9 +311,140 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
         }
 }
 
-// (A forward kernel of the same scheme - a -> LDS, z on the MFMA with the first half's GELU between the second half's MFMAs, the 64 x 128
-// result through LDS into aligned row-wise stores - was built and measured in round 5: 345-352 us against 325-341 us for the generic K8
-// tile with the virtual input, which keeps that layer.  Not kept.)
+// ------------------------------------------------------------------------------------------------ K16: the forward pass, same scheme
+// act = zero-pad(gelu(w0 gelu(w1 x + b1) + b0)): per 128-slot tile a = gelu(h) -> LDS, z = w0 a on the MFMA in two halves with the first
+// half's GELU between the second half's MFMAs, the 64 x 128 result through LDS into row-wise 16-byte stores.  The slots of a row cover
+// the WHOLE padded row (Wp rounded down to a multiple of 4; the lane of a row's last quad adds the one to three zeros that remain): the
+// kernel writes the padding columns itself - whole 128-byte lines instead of a row's ragged end followed, in another launch, by the
+// 100-byte strip next to it (first version of this kernel, flat pixels + clear_border: 345 us at 2.2 TB/s, like the generic K8 tile).
+// Only the rows below the domain are left to clear_border (contiguous).
+struct LiftFwdParams {
+    const float* x; const float* w1; const float* b1; const float* w0; const float* b0;
+    float* act;             // (B, 64, Hp, Wp)
+    int B, Cin, tail;       // tail: columns of a padded row behind its last quad (Wp mod 4)
+    LiftGeom geo;
+};
+
+__global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lb_smem[];
+    float* sA = lb_smem;                            // [32][TS]  a = gelu(h)
+    float* sO = sA + LB_CM * LB_TS;                 // [64][TS]  gelu(z), row layout
+    float* sW = sO + LB_CO * LB_TS;                 // [32][80]  w0 as [m][o]
+    float4* sVH = reinterpret_cast<float4*>(sW + LB_CM * LB_WS);
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const LiftGeom& G = p.geo;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + 256 * u;
+        sW[(e & 31) * LB_WS + (e >> 5)] = p.w0[e];
+    }
+    if (tid < LB_CM) {
+        const float* wr = p.w1 + tid * p.Cin;
+        sVH[tid] = make_float4(wr[0], p.Cin > 1 ? wr[1] : 0.f, p.Cin > 2 ? wr[2] : 0.f, p.b1 ? p.b1[tid] : 0.f);
+    }
+    const float b0v = p.b0 ? p.b0[16 * wave + r16] : 0.f;
+    const float* xb = p.x + (size_t)b * p.Cin * G.Pd;
+    float* ab = p.act + (size_t)b * LB_CO * G.Pp;
+    float4 xq[3];
+    LiftQuad cur = {0, 0, 0, 0, 0}, nxt = {0, 0, 0, 0, 0};
+    auto load_x = [&](int tile) {
+        const int s0 = tile * LB_PT;
+        nxt = lift_quad(G, s0, s0 + (tid & 31) * 4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xq[k] = lift_ld4(xb + (size_t)min(k, p.Cin - 1) * G.Pd, nxt.od, G.Pd);
+    };
+    const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
+    if (t_begin < t_end) load_x(t_begin);
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        cur = nxt;
+        {
+            const int q4 = (tid & 31) * 4;
+            const float4 q[3] = {lift_mask(xq[0], cur.nv), lift_mask(xq[1], cur.nv), lift_mask(xq[2], cur.nv)};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = (tid >> 5) + 8 * u;
+                const float4 h = lb_vh(sVH[m], q);
+                *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(uno_gelu(h.x), uno_gelu(h.y), uno_gelu(h.z), uno_gelu(h.w));
+            }
+        }
+        if (tile + 1 < t_end) load_x(tile + 1);
+        __syncthreads();
+        f32x4 acc1[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc1[mt] = f32x4{0, 0, 0, 0};
+        float wv[LB_CM / 4];
+#pragma unroll
+        for (int ks = 0; ks < LB_CM / 4; ++ks) wv[ks] = sW[(4 * ks + kk) * LB_WS + 16 * wave + r16];
+#pragma unroll
+        for (int ks = 0; ks < LB_CM / 4; ++ks) {
+            const float* arow = sA + (4 * ks + kk) * LB_TS + r16;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv[ks], acc1[mt]);
+        }
+        float* const orow = sO + (16 * wave + r16) * LB_TS + 4 * kk;
+        auto out_tile = [&](int mt) {
+            *reinterpret_cast<float4*>(orow + 16 * mt) = make_float4(uno_gelu(acc1[mt][0] + b0v), uno_gelu(acc1[mt][1] + b0v),
+                                                                     uno_gelu(acc1[mt][2] + b0v), uno_gelu(acc1[mt][3] + b0v));
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < LB_CM / 4; ++ks) {
+            const float* arow = sA + (4 * ks + kk) * LB_TS + r16;
+#pragma unroll
+            for (int mt = 4; mt < 8; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv[ks], acc1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) out_tile(mt);
+        __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 4; mt < 8; ++mt) out_tile(mt);
+        __syncthreads();
+        // row-wise stores: thread -> (row (tid >> 5) + 8 u, quad tid & 31); slots past the domain's width are the padding: zeros
+        if (cur.row_ok) {
+            const int q4 = (tid & 31) * 4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int o = (tid >> 5) + 8 * u;
+                const float4 v = lift_mask(*reinterpret_cast<const float4*>(sO + o * LB_TS + q4), cur.nv);
+                float* dst = ab + (size_t)o * G.Pp + cur.op;
+                io_store4(dst, v.x, v.y, v.z, v.w);
+                if (cur.last) {                         // the row's last columns (fewer than four)
+                    if (p.tail > 0) dst[4] = 0.f;
+                    if (p.tail > 1) dst[5] = 0.f;
+                    if (p.tail > 2) dst[6] = 0.f;
+                }
+            }
+        }
+        __syncthreads();                // (the stores' LDS reads are done before the next tile's epilogue overwrites sO ... and sA)
+    }
+}
+
+int launch_lift_forward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin,
+                              int H, int W, int Hp, int Wp, hipStream_t s) {
+    LiftFwdParams p;
+    p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.act = act;
+    p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp, Wp & ~3); p.tail = Wp & 3;
+    if ((long long)Hp * Wp * LB_CO >= (1LL << 31) || B > 65535 || (long long)H * Wp >= (1LL << 24)) { set_error("lift_forward: tensor too large"); return -2; }
+    static int lds_slot[64];
+    const size_t lds = sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS) + sizeof(float4) * LB_CM;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(lift_forward_kernel), lds, lds_slot)) { set_error("lift_forward: cannot raise dynamic LDS to %zu", lds); return -4; }
+    {
+        ProfScope prof("uno::lift_forward_kernel", 4.0 * B * ((double)H * W * Cin + (double)H * Wp * LB_CO), s);
+        hipLaunchKernelGGL(lift_forward_kernel, dim3((unsigned)((p.geo.npt + LB_TPW - 1) / LB_TPW), (unsigned)B), dim3(256), lds, s, p);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("lift_forward launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
+}
 
 static size_t lift_bwd_lds() { return sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS + LB_CO * LB_WTS) + sizeof(float4) * LB_CM; }
 
