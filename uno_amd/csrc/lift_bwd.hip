@@ -48,19 +48,21 @@ static LiftGeom lift_geom(int H, int W, int Hp, int Wp, int slots_per_row = 0) {
     g.magic = (unsigned)(((1ULL << 40) + g.W4 - 1) / (unsigned long long)g.W4);
     return g;
 }
+__device__ __forceinline__ int lift_clamped(int off, int plane_len) { return max(min(off, plane_len - 4), 0); }
 // this thread's quad of a tile: row, valid slots (0 .. 4), offsets in a dense and in a padded plane
-struct LiftQuad { int nv, od, op, row_ok, last; };         // row_ok: the row exists; last: the quad is its row's last one
+struct LiftQuad { int nv, od, op, row_ok, last, shd, shp; };         // row_ok: the row exists; last: the quad is its row's last one;
+                                                                     // od / op: CLAMPED offsets, shd / shp: elements the loaded piece must be shifted by
 __device__ __forceinline__ LiftQuad lift_quad(const LiftGeom& g, int s0, int s) {
     const int r0 = (int)(((unsigned long long)(unsigned)s0 * g.magic) >> 40);      // (uniform) row of the tile's first slot
     const int r = r0 + (s >= (r0 + 1) * g.W4 ? 1 : 0);                             // a tile of 128 slots touches two rows at most (W4 >= 260)
     const int col = s - r * g.W4;
-    return LiftQuad{r < g.H ? min(max(g.W - col, 0), 4) : 0, s + r * g.skip_d, s + r * g.skip_p, r < g.H ? 1 : 0, col == g.W4 - 4 ? 1 : 0};
+    const int od = s + r * g.skip_d, op = s + r * g.skip_p, odc = lift_clamped(od, g.Pd), opc = lift_clamped(op, g.Pp);
+    return LiftQuad{r < g.H ? min(max(g.W - col, 0), 4) : 0, odc, opc, r < g.H ? 1 : 0, col == g.W4 - 4 ? 1 : 0, od - odc, op - opc};
 }
 // four floats at plane[off ..] from an address clamped into the plane (the last quads of a plane's last row), shifted back into place
-__device__ __forceinline__ float4 lift_ld4(const float* plane, int off, int plane_len) {
-    const int oc = max(min(off, plane_len - 4), 0);
-    const float4 v = io_ld4(plane + oc);
-    const int sh = off - oc;
+// The RAW piece is returned: the shift is applied where the value is consumed (lift_fix) - applied here it used the loaded registers at
+// once and the wave waited for every load right after issuing it (the first phase of both kernels: 6 k - 7 k cycles per tile).
+__device__ __forceinline__ float4 lift_fix(const float4& v, int sh) {
     float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
     if (sh & 1) { t0 = t1; t1 = t2; t2 = t3; }
     if (sh & 2) { t0 = t2; t1 = t3; }
@@ -145,21 +147,21 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int k = 0; k < 4; ++k) g1[u][k] = 0.f;
-    LiftQuad cur = {0, 0, 0, 0, 0}, nxt = {0, 0, 0, 0, 0};
+    LiftQuad cur = {0, 0, 0, 0, 0, 0, 0}, nxt = {0, 0, 0, 0, 0, 0, 0};
     auto load_tile = [&](int tile) {
         const int s0 = tile * LB_PT;
         nxt = lift_quad(G, s0, s0 + (tid & 31) * 4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xq[k] = lift_ld4(xb + (size_t)min(k, p.Cin - 1) * G.Pd, nxt.od, G.Pd);
+        for (int k = 0; k < 3; ++k) xq[k] = io_ld4(xb + (size_t)min(k, p.Cin - 1) * G.Pd + nxt.od);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gq[u] = lift_ld4(gb + (size_t)((tid >> 5) + 8 * u) * G.Pp, nxt.op, G.Pp);
+        for (int u = 0; u < 8; ++u) gq[u] = io_ld4(gb + (size_t)((tid >> 5) + 8 * u) * G.Pp + nxt.op);
     };
     if (t_begin < t_end) load_tile(t_begin);
     __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
         cur = nxt;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xc[k] = lift_mask(xq[k], cur.nv);
+        for (int k = 0; k < 3; ++k) { xq[k] = lift_fix(xq[k], cur.shd); xc[k] = lift_mask(xq[k], cur.nv); }
         // ---- phase 0: a = gelu(h) -> sA (rows (tid >> 5) + 8 u at quad tid & 31), g -> sZ (row-wise, 16-byte pieces); gelu'(h) of the
         // same elements stays in registers for the end of the tile, where this thread stores exactly these elements of gh
         float4 dh[4];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
                 *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(a4.x * vm0, a4.y * vm1, a4.z * vm2, a4.w * vm3);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = lift_mask(gq[u], cur.nv);
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = lift_mask(lift_fix(gq[u], cur.shp), cur.nv);
         }
         if (tile + 1 < t_end) load_tile(tile + 1);
         LB_STAMP(0);
@@ -323,6 +325,7 @@ struct LiftFwdParams {
     float* act;             // (B, 64, Hp, Wp)
     int B, Cin, tail;       // tail: columns of a padded row behind its last quad (Wp mod 4)
     LiftGeom geo;
+    unsigned long long* stamps;     // development (-DUNO_LB_DEV)
 };
 
 __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
@@ -347,22 +350,28 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
     const float b0v = p.b0 ? p.b0[16 * wave + r16] : 0.f;
     const float* xb = p.x + (size_t)b * p.Cin * G.Pd;
     float* ab = p.act + (size_t)b * LB_CO * G.Pp;
-    float4 xq[3];
-    LiftQuad cur = {0, 0, 0, 0, 0}, nxt = {0, 0, 0, 0, 0};
-    auto load_x = [&](int tile) {
+    // the real channels of a tile are requested TWO tiles ahead (register sets A / B in turn): a tile of this kernel lasts ~9 k cycles,
+    // less than a load that misses L2 takes under load - with one tile of distance the first phase waited for them (5.8 k of 15.3 k cycles)
+    float4 xqA[3], xqB[3];
+    LiftQuad qdA = {0, 0, 0, 0, 0, 0, 0}, qdB = {0, 0, 0, 0, 0, 0, 0};
+    auto load_x = [&](int tile, float4* xq, LiftQuad& qd) {
         const int s0 = tile * LB_PT;
-        nxt = lift_quad(G, s0, s0 + (tid & 31) * 4);
+        qd = lift_quad(G, s0, s0 + (tid & 31) * 4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xq[k] = lift_ld4(xb + (size_t)min(k, p.Cin - 1) * G.Pd, nxt.od, G.Pd);
+        for (int k = 0; k < 3; ++k) xq[k] = io_ld4(xb + (size_t)min(k, p.Cin - 1) * G.Pd + qd.od);
     };
+#ifdef UNO_LB_DEV
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
     const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
-    if (t_begin < t_end) load_x(t_begin);
+    if (t_begin < t_end) load_x(t_begin, xqA, qdA);
+    if (t_begin + 1 < t_end) load_x(t_begin + 1, xqB, qdB);
     __syncthreads();
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        cur = nxt;
+    auto do_tile = [&](int tile, float4* xq, LiftQuad& qd) {
+        const LiftQuad cur = qd;
         {
             const int q4 = (tid & 31) * 4;
-            const float4 q[3] = {lift_mask(xq[0], cur.nv), lift_mask(xq[1], cur.nv), lift_mask(xq[2], cur.nv)};
+            const float4 q[3] = {lift_mask(lift_fix(xq[0], cur.shd), cur.nv), lift_mask(lift_fix(xq[1], cur.shd), cur.nv), lift_mask(lift_fix(xq[2], cur.shd), cur.nv)};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int m = (tid >> 5) + 8 * u;
@@ -370,8 +379,10 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
                 *reinterpret_cast<float4*>(sA + m * LB_TS + q4) = make_float4(uno_gelu(h.x), uno_gelu(h.y), uno_gelu(h.z), uno_gelu(h.w));
             }
         }
-        if (tile + 1 < t_end) load_x(tile + 1);
+        if (tile + 2 < t_end) load_x(tile + 2, xq, qd);
+        LB_STAMP(0);
         __syncthreads();
+        LB_STAMP(1);
         f32x4 acc1[8];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) acc1[mt] = f32x4{0, 0, 0, 0};
@@ -384,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv[ks], acc1[mt]);
         }
+        LB_STAMP(2);
         float* const orow = sO + (16 * wave + r16) * LB_TS + 4 * kk;
         auto out_tile = [&](int mt) {
             *reinterpret_cast<float4*>(orow + 16 * mt) = make_float4(uno_gelu(acc1[mt][0] + b0v), uno_gelu(acc1[mt][1] + b0v),
@@ -407,7 +419,9 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 4; mt < 8; ++mt) out_tile(mt);
+        LB_STAMP(3);
         __syncthreads();
+        LB_STAMP(1);
         // row-wise stores: thread -> (row (tid >> 5) + 8 u, quad tid & 31); slots past the domain's width are the padding: zeros
         if (cur.row_ok) {
             const int q4 = (tid & 31) * 4;
@@ -424,8 +438,20 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
                 }
             }
         }
+        LB_STAMP(7);
         __syncthreads();                // (the stores' LDS reads are done before the next tile's epilogue overwrites sO ... and sA)
+        LB_STAMP(1);
+    };
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+        do_tile(tile, xqA, qdA);
+        if (tile + 1 < t_end) do_tile(tile + 1, xqB, qdB);
     }
+#ifdef UNO_LB_DEV
+    if (p.stamps && lane == 0) {
+        unsigned long long* o_ = p.stamps + (((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o_[i] = tph[i];
+    }
+#endif
 }
 
 int launch_lift_forward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin,
@@ -433,6 +459,10 @@ int launch_lift_forward_fused(const float* x, const float* w1, const float* b1, 
     LiftFwdParams p;
     p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.act = act;
     p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp, Wp & ~3); p.tail = Wp & 3;
+    p.stamps = nullptr;
+#ifdef UNO_LB_DEV
+    if (getenv("UNO_LF_STAMPS")) p.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("UNO_LF_STAMPS"), nullptr, 0));
+#endif
     if ((long long)Hp * Wp * LB_CO >= (1LL << 31) || B > 65535 || (long long)H * Wp >= (1LL << 24)) { set_error("lift_forward: tensor too large"); return -2; }
     static int lds_slot[64];
     const size_t lds = sizeof(float) * (LB_CM * LB_TS + LB_CO * LB_TS + LB_CM * LB_WS) + sizeof(float4) * LB_CM;
