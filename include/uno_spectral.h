@@ -267,9 +267,10 @@ int uno_channel_mix_dgelu_padded(const float* x, const float* w, const float* bi
  *   h = fc_n1(x) (Cm = 16 or 32 channels; w1 (Cm, Cin), b1 (Cm) or NULL),  z = fc0(gelu(h)) (w0 (Co, Cm), b0 or NULL),
  *   act (B, Co, Hp, Wp) = zero-pad(gelu(z))
  * with NEITHER h nor z stored: h is 12 bytes per pixel of input against 128 of output, so every kernel that needs it evaluates it
- * from x.  With Cm = 32, Co = 64 the forward pass is one dedicated kernel that writes whole padded rows, and the backward pass is one kernel per pixel tile (recomputed a = gelu(h) and z; gz = gelu'(z) g and
- * gh = gelu'(h) w0^T gz stay on the chip, both layers' weight-gradient sums are accumulated there) plus two small reductions; other
- * widths run four kernels with gz and gh in scratch.
+ * from x.  With Cm = 32, Co = 64 the forward pass is one dedicated kernel that writes whole padded rows, and the backward pass is
+ * one kernel per pixel tile (recomputed a = gelu(h) and z; gz = gelu'(z) g and gh = gelu'(h) w0^T gz stay on the chip, both layers'
+ * weight-gradient sums are accumulated there) plus two small reductions; other widths run the generic kernels with gz and gh in
+ * scratch.
  * uno_lift_backward: g_act (B, Co, Hp, Wp) -> gw1 (Cm, Cin), gb1 (Cm) or NULL, gw0 (Co, Cm), gb0 (Co) or NULL (written, not
  * accumulated; no gradient for x - it is data); ws: uno_lift_bwd_ws_bytes() bytes.  260 <= W <= Wp, H * W < 2^24, float32. */
 int uno_lift_forward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin,
