@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-config", choices=("c1", "c2"), default="c2", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -58,31 +59,36 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(batch: int, steps: int, threads: int):
+C1_S, C1_WIDTH, C1_BATCH, C1_STEPS = 85, 32, 8, 20     # BASELINE.json configs[0]: Darcy 85^2, 32 ch, batch 8, the reference's CPU-runnable case
+
+
+def cpu_baseline(batch: int, steps: int, threads: int, config: str = "c2"):
     """The oracle's FFT-sequence restatement of the reference step (rfft2 -> einsum -> irfft2 blocks, same loss, reference-Adam
-    arithmetic - BASELINE.md section 3) timed on the host cores: `steps` timed steps on `batch` samples of the same 421^2
-    workload after one untimed step."""
+    arithmetic - BASELINE.md section 3) timed on the host cores: `steps` timed steps on `batch` samples after one untimed step.
+    config "c2": the 421^2 / 64-channel headline workload; "c1": BASELINE.json configs[0], UNO_9(3,32,pad=5) at 85^2 (the model
+    /root/reference/darcy_flow_main.py:95 builds)."""
     import torch
     from oracle import spectral_oracle as so            # checker/baseline only - never the product path
     from uno_amd.harness import DarcyTrainer, UNO_9, synthetic_darcy_batch
+    grid, width = (C1_S, C1_WIDTH) if config == "c1" else (S, WIDTH)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    model = UNO_9(3, WIDTH, pad=PAD, block_cls=so.OracleOperatorBlock2d)
+    model = UNO_9(3, width, pad=PAD, block_cls=so.OracleOperatorBlock2d)
     tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
-    a1, u1 = synthetic_darcy_batch(1, S, 99, "cpu")
+    a1, u1 = synthetic_darcy_batch(1, grid, 99, "cpu")
     tr.step(a1, u1)                                     # untimed: thread pool, allocator, FFT plans
-    a, u = synthetic_darcy_batch(batch, S, 1234, "cpu")
+    a, u = synthetic_darcy_batch(batch, grid, 1234, "cpu")
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step(a, u)
     dt = (time.perf_counter() - t0) / steps
-    return {"samples_per_s": batch / dt, "s_per_step": dt, "batch": batch, "steps": steps, "threads": threads}
+    return {"samples_per_s": batch / dt, "s_per_step": dt, "batch": batch, "steps": steps, "threads": threads, "config": config}
 
 
-def _cpu_child(batch, steps, threads, limit_s):
+def _cpu_child(batch, steps, threads, limit_s, config="c2"):
     """Run one CPU leg in a child process (killed by PID after `limit_s`: a pathological host can never stall the bench)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-batch", str(batch), "--cpu-steps", str(steps),
-           "--cpu-threads", str(threads)]
+           "--cpu-threads", str(threads), "--cpu-config", config]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -101,20 +107,27 @@ def _cpu_child(batch, steps, threads, limit_s):
 
 def cpu_baseline_bounded(batch: int, steps: int):
     """N-thread leg (B = 16, >= 3 timed steps: BASELINE.md section 3) + a 1-thread figure on a smaller sample.
-    Thread count: measured on the GPU box (2 x EPYC 9575F, 256 hw threads): 16 threads 0.74-1.0 samples/s, 32 -> 0.64,
-    64 -> 0.37, all 256 did not finish in 20 min (oversubscribed FFT / GEMM thread pools) - 16 is the best setting."""
+    Thread count: BASELINE.md section 3 asks for os.cpu_count() threads; on the GPU box (2 x EPYC 9575F, 256 hw threads) that
+    setting is the SLOWEST one - the sweep is profiles/r06_cpu_threads.txt (tools/cpu_thread_sweep.py) - so the leg runs at the
+    sweep's best setting, 16 threads, and says so in `cores`.
+    `c1`: BASELINE.json configs[0] (the reference's own CPU-runnable case: UNO_9(3,32,pad=5), 85^2, batch 8), 20 timed steps."""
     import torch
     hw = os.cpu_count() or 1
     cores = min(hw, 16)
     main = _cpu_child(batch, steps, cores, 420)
     one = _cpu_child(2, 1, 1, 240)
+    c1 = _cpu_child(C1_BATCH, C1_STEPS, cores, 240, "c1")
     out = {"value": main["samples_per_s"] if main else None, "unit": "samples/s", "cores": cores, "kind": "port",
            "sample": (f"{steps} timed training steps (after 1 untimed) on {batch} synthetic 421x421 samples each, UNO_9(3,{WIDTH},pad={PAD}), "
                       f"oracle FFT path (torch.fft.rfft2 -> einsum -> irfft2, reference op sequence), torch {torch.__version__} CPU, "
                       f"{cores} threads of {hw} hw threads, {_cpu_model()}"
                       + (f", {main['s_per_step']:.1f} s/step" if main else ", DID NOT FINISH in 420 s")),
            "one_thread": ({"value": one["samples_per_s"], "unit": "samples/s", "sample": f"1 step on 2 samples, 1 thread ({one['s_per_step']:.1f} s)"}
-                          if one else None)}
+                          if one else None),
+           "c1": ({"value": c1["samples_per_s"], "unit": "samples/s", "cores": cores, "ms_per_step": c1["s_per_step"] * 1e3,
+                   "sample": f"BASELINE.json configs[0]: {C1_STEPS} timed training steps (after 1 untimed) on {C1_BATCH} synthetic {C1_S}x{C1_S} "
+                             f"samples, UNO_9(3,{C1_WIDTH},pad={PAD}), same oracle FFT path, {cores} threads"} if c1 else None),
+           "thread_sweep": "profiles/r06_cpu_threads.txt"}
     return out
 
 
@@ -279,6 +292,68 @@ def spectral_block3d_roofline(dev):
             "fwd_kernels": (kf := _kernel_table(fwd)), "bwd_kernels": (kb := _kernel_table(bwd)),
             "fwd_traffic": _traffic(list(kf), {k: v["launches_per_call"] for k, v in kf.items()}, block="c4"),
             "bwd_traffic": _traffic(list(kb), {k: v["launches_per_call"] for k, v in kb.items()}, block="c4")}
+
+
+def copy_ceiling(dev):
+    """Measured streaming ceilings of THIS device ("report against both spec peak and a measured hipMemcpyDtoD /
+    stream-triad ceiling"): a 1 GiB device-to-device copy (torch's same-device copy_ = hipMemcpyDtoDAsync) and a triad
+    a = b + 2 c on 1 GiB operands, HIP events on the launch stream, bytes = everything read + everything written."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.full((n,), 1.0, dtype=torch.float32, device=dev)
+    c = torch.full((n,), 2.0, dtype=torch.float32, device=dev)
+    tc = _timed(lambda: a.copy_(b), dev, iters=10, reps=5, warm=3)
+    tt = _timed(lambda: torch.add(b, c, alpha=2.0, out=a), dev, iters=10, reps=5, warm=3)
+    del a, b, c
+    torch.cuda.empty_cache()
+    copy_gbs, triad_gbs = 2 * n * 4 / tc / 1e9, 3 * n * 4 / tt / 1e9
+    return {"memcpy_dtod_GBps": copy_gbs, "triad_GBps": triad_gbs, "GBps": max(copy_gbs, triad_gbs),
+            "what": "1 GiB hipMemcpyDtoD (read + write bytes) and 1 GiB triad a = b + 2 c (two reads + one write), median of 5 x 10 calls"}
+
+
+def operator_block_roofline(dev):
+    """The whole OperatorBlock (SURVEY 8(d) "secondary figure": spectral branch + 1x1 convolution + bicubic resampling + sum, reference
+    integral_operators.py:272-284) at the two largest block shapes of the headline model, batch 16, forward, against the IDEAL
+    bytes of a single-pass block - x read once, the output written once, the weights read once:
+        conv0: OperatorBlock_2D(64 -> 128, 446^2 -> 223^2, modes 18)         (contracting)
+        conv5: OperatorBlock_2D(128 + 128 -> 64, 223^2 -> 446^2, modes 18)   (expanding, two-source skip form)
+    `moved_bytes` = what the kernels of one call actually stream (their own algorithmic bytes, summed)."""
+    import math
+    import torch
+    from uno_amd.integral_operators import OperatorBlock_2D
+    D = S + math.ceil(S / 85) * PAD
+    g = torch.Generator().manual_seed(0)
+    out = {}
+
+    def measure(key, fn, ci, co, n_in, n_out, desc):
+        with torch.no_grad():
+            fn()
+            t = _timed(fn, dev, iters=10, reps=5, warm=2)
+            kt = _kernel_table(fn, n=3)
+        ideal = 4.0 * BATCH * (ci * n_in + co * n_out) + 8.0 * 2 * ci * co * 18 * 18 + 4.0 * (ci * co + co)
+        moved = sum(v["bytes_per_launch"] * v["launches_per_call"] for v in kt.values())
+        out[key] = {"config": desc, "fwd_us": t * 1e6, "ideal_bytes": ideal, "achieved": ideal / t / 1e9, "unit": "GB/s",
+                    "frac": ideal / t / 1e9 / HBM_PEAK_GBS, "moved_bytes": moved, "moved_over_ideal": moved / ideal,
+                    "launches": sum(v["launches_per_call"] for v in kt.values()),
+                    "kernels": {k: {"avg_us": v["avg_us"], "launches_per_call": v["launches_per_call"]} for k, v in kt.items()}}
+
+    torch.manual_seed(0)
+    b0 = OperatorBlock_2D(WIDTH, 2 * WIDTH, 40, 40, 18, 18).to(dev)
+    x = torch.randn(BATCH, WIDTH, D, D, generator=g).to(dev)
+    measure("conv0", lambda: b0(x, D // 2, D // 2), WIDTH, 2 * WIDTH, D * D, (D // 2) ** 2,
+            f"OperatorBlock_2D({WIDTH},{2 * WIDTH},modes 18) {D}^2 -> {D // 2}^2, batch {BATCH}, forward incl. GELU")
+    del b0, x
+    torch.cuda.empty_cache()
+    b5 = OperatorBlock_2D(4 * WIDTH, WIDTH, 85, 85, 18, 18).to(dev)
+    x1 = torch.randn(BATCH, 2 * WIDTH, D // 2, D // 2, generator=g).to(dev)
+    x2 = torch.randn(BATCH, 2 * WIDTH, D // 2, D // 2, generator=g).to(dev)
+    measure("conv5", lambda: b5.forward_cat([x1, x2], D, D, defer_gelu=True), 4 * WIDTH, WIDTH, (D // 2) ** 2, D * D,
+            f"OperatorBlock_2D({4 * WIDTH},{WIDTH},modes 18) on two {2 * WIDTH}-channel sources, {D // 2}^2 -> {D}^2, batch {BATCH}, "
+            "forward (pre-activation sum: the GELU is applied by the consumer as it reads)")
+    del b5, x1, x2
+    torch.cuda.empty_cache()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- secondary workloads
@@ -660,7 +735,7 @@ def self_launch(args):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.cpu_batch, args.cpu_steps, args.cpu_threads or min(os.cpu_count() or 1, 16))))
+        print(json.dumps(cpu_baseline(args.cpu_batch, args.cpu_steps, args.cpu_threads or min(os.cpu_count() or 1, 16), args.cpu_config)))
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -801,14 +876,28 @@ def main():
                          "DFT against a constant twiddle matrix is a tall-skinny GEMM at ~20 flop/B, the f32 ridge of the chip",
             "step_kernels": step_kernels,
         }
+        ceiling = copy_ceiling(dev)
+        roofline["copy_ceiling"] = ceiling
+        roofline["frac_of_copy"] = roofline["achieved"] / ceiling["GBps"]
+        roofline["backward"]["frac_of_copy"] = roofline["backward"]["achieved"] / ceiling["GBps"]
+        try:
+            roofline["operator_block"] = operator_block_roofline(dev)
+            for v in roofline["operator_block"].values():
+                v["frac_of_copy"] = v["achieved"] / ceiling["GBps"]
+        except Exception as e:            # a secondary figure never takes the headline down
+            roofline["operator_block"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         block3d = spectral_block3d_roofline(dev) if world == 1 else None
         extras = extra_workloads(dev) if world == 1 and not args.no_extras else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_bounded(args.cpu_batch, args.cpu_steps)
         gb = world * per_rank
+        value = gb * args.steps / elapsed
+        # BASELINE.md holds no published number for this metric (section 1: "None exist"), so vs_baseline stays null; the north-star
+        # target is relative to the CPU path timed on this host (>= 10 x), reported beside it
+        vs_cpu = (value / cpu["value"]) if (cpu and cpu.get("value")) else None
         out = {
-            "metric": "UNO training samples/s (421^2 Darcy)", "value": gb * args.steps / elapsed,
+            "metric": "UNO training samples/s (421^2 Darcy)", "value": value,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -817,7 +906,7 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": loss_val},
             "roofline": roofline, "spectral_block": {k: v for k, v in block.items() if not k.endswith("_kernels")},
             "spectral_block_3d": block3d, "comm": comm, "rccl_ranks": comm["ranks"] if comm and backend == "nccl" else (1 if world == 1 else None),
-            "extras": extras, "cpu_baseline": cpu,
+            "extras": extras, "cpu_baseline": cpu, "vs_cpu_baseline": vs_cpu, "target_vs_cpu_baseline": 10.0,
         }
         print(json.dumps(out))
     if world > 1:
