@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 10
+#define UNO_SPECTRAL_ABI_VERSION 11
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -121,6 +121,26 @@ int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W,
 /* Pruned inverse DFT: images[h][w] = Re sum_{j,l} scale * c_l * keep_j * spec[j][l] e^{+2 pi i (...)}. */
 int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2,
                       float scale, int hermitian_cols, int mask_overlap, void* stream);
+
+/* ABI 11.  Pruned inverse DFT PLUS the up-sampled point-wise branch in one pass over the output:
+ *   images[h][w] = (uno_dft2d_inverse's result) + sum_{u,v} Rh[h][u] Rw[w][v] addend[u][v]
+ * = `x1_out + x2_out` of an up-sampling operator block, reference integral_operators.py:272-273, with x2_out the bicubic /
+ * align_corners / antialias interpolation (:240-242) of the LOW-resolution 1x1-convolution result `addend` (n_img, Hs, Ws) - the
+ * convolution and the interpolation commute - and, with the transposed operators, the input gradient of a down-sampling block.
+ * Rh (H x Hs) and Rw (W x Ws) are banded (<= 12 source rows per 16 output rows, <= 12 source columns per 16 output columns:
+ * up-sampling by two or more) and given as operand tables the caller builds once per size pair (uno_amd/resample.py
+ * upsample_add_tables):
+ *   tile_p0 [ceil(H/16)]           first source row of each 16-row output tile
+ *   row_op  [ceil(H/16)][3][64]    entry (tile, e, lane) = Rh[16 tile + lane % 16][tile_p0 + 3 (lane / 16) + e]
+ *   col_v0  [nwt][2]               first source column of (column tile, side), nwt = ((W/2) + 16) / 16; <= Ws - 12
+ *   col_op  [nwt][2][3][64]        entry (wt, side, ks, lane) = Rw[w][col_v0 + 3 (lane / 16) + ks], w = 16 wt + lane % 16 (side 0)
+ *                                  or W - 16 wt - lane % 16 (side 1); zero for w outside [0, W)
+ * uno_dft2d_inverse_add_applies: 1 where the fused kernel exists (float32, rows of 192..223 or 416..447 elements whose 16-row
+ * tiles fit the LDS, modes1 <= 24, modes2 <= 32), else 0 - the caller then runs uno_dft2d_inverse followed by uno_resample2d. */
+int uno_dft2d_inverse_add_applies(int n_img, int H, int W, int m1, int m2, int Hs, int Ws);
+int uno_dft2d_inverse_add(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale, int hermitian_cols,
+                          int mask_overlap, const float* addend, int Hs, int Ws, const int* tile_p0, const float* row_op,
+                          const int* col_v0, const float* col_op, void* stream);
 
 /* The two transforms with bfloat16 images (the stages of uno_spectral_conv2d_*_bf16); spectra are c64 as above. */
 int uno_dft2d_forward_bf16(const void* images, float* spec, int n_img, int H, int W, int m1, int m2,

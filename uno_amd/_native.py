@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 _lock = threading.Lock()
@@ -39,6 +39,8 @@ _SIGNATURES = {
     "uno_dft2d_forward_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_dft2d_inverse_add_applies": (C.c_int, [_i] * 7),
+    "uno_dft2d_inverse_add": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_dft2d_forward_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
     "uno_dft2d_inverse_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
     "uno_mode_mix": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
@@ -345,13 +347,34 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
     return out
 
 
+def dft2d_inverse_add_applies(n_img, H, W, m1, m2, Hs, Ws) -> bool:
+    """True where dft2d_inverse(..., addend=) runs the fused kernel (K3 + up-sampled addend, csrc/dft2d_inv_add_kernel.h)."""
+    return bool(lib().uno_dft2d_inverse_add_applies(int(n_img), int(H), int(W), int(m1), int(m2), int(Hs), int(Ws)))
+
+
 def dft2d_inverse(spec, H, W, scale=1.0, hermitian_cols=True, mask_overlap=True, channels=None, channel_offset=0,
-                  dtype=torch.float32):
+                  dtype=torch.float32, addend=None):
     """spectra (..., 2*m1, m2) c64 -> images (..., H, W) f32 (or bf16 with dtype=torch.bfloat16, plain form only).  With `channels` = C1 and spec (B, Ctot, 2*m1, m2) only the
-    channels [channel_offset, channel_offset + C1) are transformed -> (B, C1, H, W)."""
+    channels [channel_offset, channel_offset + C1) are transformed -> (B, C1, H, W).
+    addend = (t (..., Hs, Ws) f32, (tile_p0, row_op, col_v0, col_op)): images += the banded up-sampling of t, in the same pass
+    (uno_dft2d_inverse_add; the caller checked dft2d_inverse_add_applies)."""
     _require(spec, torch.complex64, "spec")
     *lead, r2, m2 = spec.shape
     m1 = r2 // 2
+    if addend is not None:
+        t, (p0, rowop, v0, colop) = addend
+        _require(t, torch.float32, "addend")
+        if channels is not None or dtype != torch.float32 or tuple(t.shape[:-2]) != tuple(lead):
+            raise RuntimeError("uno_amd: dft2d_inverse(addend=) takes the plain float32 form with one addend image per spectrum")
+        n = 1
+        for d in lead:
+            n *= d
+        img = torch.empty((*lead, H, W), dtype=torch.float32, device=spec.device)
+        with torch.cuda.device(spec.device):
+            rc = lib().uno_dft2d_inverse_add(_ptr(spec), _ptr(img), n, H, W, m1, m2, float(scale), int(hermitian_cols), int(mask_overlap),
+                                             _ptr(t), t.shape[-2], t.shape[-1], _ptr(p0), _ptr(rowop), _ptr(v0), _ptr(colop), _stream(spec))
+        _check(rc, "uno_dft2d_inverse_add")
+        return img
     if channels is None:
         n = 1
         for d in lead:

@@ -20,13 +20,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libuno_spectral.so")
 STAMP = os.path.join(LIBDIR, "libuno_spectral.stamp")
-SOURCES = ["capi.hip", "dft2d_fwd.hip", "dft2d_fwd_r4.hip", "dft2d_inv.hip", "dft2d_inv_b.hip", "dft2d_inv_c.hip", "dft2d_plane.hip", "dft2d_b16.hip", "mode_gemm.hip", "cdft_axis.hip", "dft3d_volume.hip", "dft_generic.hip", "resample2d.hip", "channel_mix.hip", "adam.hip", "pointwise_fused.hip", "instnorm.hip", "lift_bwd.hip"]
-HEADERS = ["uno_common.h", "dft2d_fwd_kernel.h", "dft2d_fwd_ft_kernel.h", "dft2d_fwd_ht_kernel.h", "dft2d_inv_kernel.h", os.path.join("..", "..", "include", "uno_spectral.h")]
+SOURCES = ["capi.hip", "dft2d_fwd.hip", "dft2d_fwd_r4.hip", "dft2d_inv.hip", "dft2d_inv_b.hip", "dft2d_inv_c.hip", "dft2d_inv_add.hip", "dft2d_plane.hip", "dft2d_b16.hip", "mode_gemm.hip", "cdft_axis.hip", "dft3d_volume.hip", "dft_generic.hip", "resample2d.hip", "channel_mix.hip", "adam.hip", "pointwise_fused.hip", "instnorm.hip", "lift_bwd.hip"]
+HEADERS = ["uno_common.h", "dft2d_fwd_kernel.h", "dft2d_fwd_ft_kernel.h", "dft2d_fwd_ht_kernel.h", "dft2d_inv_kernel.h", "dft2d_inv_add_kernel.h", os.path.join("..", "..", "include", "uno_spectral.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 # per-source flags.  mode_gemm.hip: its 4x4x1 kernel keeps 16 accumulator tiles live across a 4-step unrolled loop; with the
 # default AGPR form the register allocator permutes the tiles at every back edge (268 v_accvgpr moves per iteration)
-EXTRA_FLAGS = {"mode_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# dft2d_inv_add.hip: its kernels park MFMA results (stage 1' of the addend) across a tile to use them as MFMA A operands; in the AGPR form
+# the compiler copies all of them into VGPRs at the head of every tile (112 v_accvgpr_read + twice the registers: scratch reloads on a
+# kernel with one wave per SIMD, 554 us against 187 for K3 alone)
+EXTRA_FLAGS = {"mode_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dft2d_inv_add.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:

@@ -286,6 +286,43 @@ int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W,
     return dft2d(true, spec, images, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap, (hipStream_t)stream);
 }
 
+// K3 + up-sampled addend (dft2d_inv_add_kernel.h): where the form applies
+int uno_dft2d_inverse_add_applies(int n_img, int H, int W, int m1, int m2, int Hs, int Ws) {
+    if (n_img < 1 || H < 1 || W < 1 || m1 < 1 || m2 < 1 || Hs < 1 || Ws < 1 || m1 > H || m2 > W / 2 + 1 || m1 > 40 || m2 > 48) return 0;
+    Dft2dParams p;
+    p.in = nullptr; p.out = nullptr; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2; p.scale = 1.f; p.herm = 1; p.mask = 1;
+    p.bf16 = 0; p.rowfreq = nullptr; p.nw = 1; p.exp = 0; p.accumulate = 0; p.act_out = nullptr;
+    p.sp_group = n_img; p.sp_stride = 0; p.sp_offset = 0; p.twH = nullptr; p.twW = nullptr;
+    p.add_Hs = Hs; p.add_Ws = Ws;
+    if (dft2d_inv_plane_applies(p)) return 0;           // (many small images take the plane-batched kernels)
+    return dft2d_inv_add_applies(p) ? 1 : 0;
+}
+
+int uno_dft2d_inverse_add(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale, int hermitian_cols,
+                          int mask_overlap, const float* addend, int Hs, int Ws, const int* tile_p0, const float* row_op,
+                          const int* col_v0, const float* col_op, void* stream) {
+    const char* who = "uno_dft2d_inverse_add";
+    if (n_img < 0) { set_error("%s: negative image count", who); return -1; }
+    if (n_img > 0 && (!spec || !images || !addend || !tile_p0 || !row_op || !col_v0 || !col_op)) { set_error("%s: null pointer", who); return -1; }
+    if (int rc = check_modes2d(who, H, W, H, W, m1, m2)) return rc;
+    if (Hs < 1 || Ws < 12 || (long long)Hs * Ws * 4 > 0x7fffffffLL) { set_error("%s: bad addend grid %dx%d", who, Hs, Ws); return -1; }
+    if (n_img == 0) return 0;
+    if (!uno_dft2d_inverse_add_applies(n_img, H, W, m1, m2, Hs, Ws)) {
+        set_error("%s: the fused form does not apply to %d images of %dx%d, modes (%d, %d) (query uno_dft2d_inverse_add_applies)", who, n_img, H, W, m1, m2);
+        return -3;
+    }
+    Dft2dParams p;
+    p.in = spec; p.out = images; p.n_img = n_img; p.H = H; p.W = W; p.m1 = m1; p.m2 = m2;
+    p.scale = scale; p.herm = hermitian_cols ? 1 : 0; p.mask = mask_overlap ? 1 : 0; p.bf16 = 0; p.rowfreq = nullptr; p.nw = 1; p.exp = 0;
+    p.accumulate = 0; p.act_out = nullptr;
+    p.sp_group = n_img; p.sp_stride = 0; p.sp_offset = 0;
+    p.twH = twiddle_table(H);
+    p.twW = twiddle_table(W);
+    if (!p.twH || !p.twW) return -6;
+    p.add_src = addend; p.add_Hs = Hs; p.add_Ws = Ws; p.add_p0 = tile_p0; p.add_rowop = row_op; p.add_v0 = col_v0; p.add_colop = col_op;
+    return launch_dft2d_inv_add(p, (hipStream_t)stream);
+}
+
 int uno_dft2d_forward_bf16(const void* images, float* spec, int n_img, int H, int W, int m1, int m2, float scale,
                            int hermitian_cols, int mask_overlap, void* stream) {
     return dft2d(false, static_cast<const float*>(images), spec, n_img, H, W, m1, m2, scale, hermitian_cols, mask_overlap,

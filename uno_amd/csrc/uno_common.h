@@ -184,6 +184,15 @@ struct Dft2dParams {
     int exp;                // development: knock-out switches of the bf16-MFMA kernels (dft2d_b16.hip), 0 in production
     int accumulate;         // plane-batched inverse only: out += result (the point-wise branch of OperatorBlock_3D lands in the spectral branch's buffer)
     float* act_out;         // ... and, if set, act_out = gelu(out) is written in the same pass (blocks without normalisation)
+    // K3-A (dft2d_inv_add_kernel.h): out = transform + separable banded up-sampling of add_src (n_img, add_Hs, add_Ws); host-built operand
+    // tables (uno_amd/resample.py): first source row of each 16-row tile, row operator [tile][3][64], first source column of each
+    // (column tile, side), column operator [column tile][2][3][64]
+    const float* add_src = nullptr;
+    int add_Hs = 0, add_Ws = 0;
+    const int* add_p0 = nullptr;
+    const float* add_rowop = nullptr;
+    const int* add_v0 = nullptr;
+    const float* add_colop = nullptr;
 };
 
 __device__ __forceinline__ size_t spectrum_index(const Dft2dParams& p, int img) {
@@ -259,6 +268,8 @@ struct ProfScope {
 
 int launch_dft2d_fwd(const Dft2dParams& p, hipStream_t s);
 int launch_dft2d_inv(const Dft2dParams& p, hipStream_t s);
+bool dft2d_inv_add_applies(const Dft2dParams& p);       // dft2d_inv_add.hip: K3 + up-sampled addend (p.add_* set)
+int launch_dft2d_inv_add(const Dft2dParams& p, hipStream_t s);
 bool dft2d_fwd_plane_applies(const Dft2dParams& p);      // dft2d_plane.hip: many small images
 bool dft2d_inv_plane_applies(const Dft2dParams& p);
 bool dft2d_b16_applies(const Dft2dParams& p);           // dft2d_b16.hip: bfloat16 images, row stage on the bf16 MFMA

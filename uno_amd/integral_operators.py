@@ -525,15 +525,38 @@ def _stack_wanted(ctx, iw, x, half_weights):
     return bool(ctx.needs_input_grad[iw] and ctx.needs_input_grad[iw + 1] and x.dtype == torch.float32 and not half_weights)
 
 
-def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, stack, join=None):
+# Up-sampling blocks (and the input gradient of down-sampling blocks): the inverse transform adds the resampled low-resolution result of
+# the point-wise branch in the registers it holds its own result in, before the output tile is written (uno_dft2d_inverse_add), instead
+# of K3 writing the block output and the accumulating resampling kernel reading and re-writing it.  False: the two-kernel form (A/B).
+FUSE_UPSAMPLE_ADD = True
+
+
+def _fused_addend(t, H, W, m1, m2, adjoint):
+    """(t, operand tables) for _native.dft2d_inverse(addend=): t (B, C, Hs, Ws) float32 is the low-resolution tensor whose resampling to
+    (H, W) - resample_forward, or resample_adjoint of an (H, W) input grid when `adjoint` - is to be added to the inverse transform of a
+    (B, C, 2 m1, m2) spectrum; None where the fused kernel does not apply (the caller runs the two kernels)."""
+    if not FUSE_UPSAMPLE_ADD or t.dtype != torch.float32 or t.dim() != 4 or not t.is_cuda:
+        return None
+    Hs, Ws = t.shape[-2], t.shape[-1]
+    if Hs * Ws >= H * W or not _native.dft2d_inverse_add_applies(t.shape[0] * t.shape[1], H, W, m1, m2, Hs, Ws):
+        return None
+    from .resample import upsample_add_tables
+    tabs = upsample_add_tables(Hs, Ws, H, W, str(t.device), bool(adjoint))
+    return None if tabs is None else (t, tabs)
+
+
+def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, stack, join=None, addend=None):
     """Backward of the spectral branch: -> (gx or None, gw1, gw2 as autograd should receive them, whether the layer's stack took the call).
     leaves = (weights1, weights2) as the caller passed them (in-place gradient targets); stack = (stack, slot) of the forward pass
-    or None; join: GradJoin whose deferred spectra are merged into this layer's before the inverse transform."""
+    or None; join: GradJoin whose deferred spectra are merged into this layer's before the inverse transform; addend: _fused_addend(...)
+    of the point-wise branch's contribution to gx (float32 only) - the call then runs stage by stage."""
     B, Co = gs.shape[:2]
     Ci, _, m1, m2 = w1.shape[:4]
     gslot = _stack_grad_slot(stack[0], stack[1], Co) if (stack is not None and need_gw) else None
     merging = join is not None and need_gx and bool(join.spectra)
-    if gslot is None and not merging:
+    if addend is not None and not need_gx:
+        raise RuntimeError("uno_amd: an addend for the input gradient needs the input gradient")
+    if gslot is None and not merging and addend is None:
         tg = _grad_targets(leaves) if (need_gw and both_gw) else None
         if need_gw:
             _note_use(leaves[0])
@@ -561,7 +584,8 @@ def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, 
         gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
         if merging:
             gX = join.merge(gX, (H, W))
-        gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype)
+        # addend: the (adjoint-)resampled point-wise contribution joins the transform's result before the tile is written
+        gx = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, dtype=gs.dtype, addend=addend)
     return gx, gw1, gw2, gslot is not None
 
 
@@ -1077,11 +1101,27 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         Co = cw.shape[0]
         cwm = _plain(cw).reshape(Co, Ci)
         cb = None if cb is None else _plain(cb)
-        s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo, xt_out=None if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]])
         same = (H, W) == (Ho, Wo)
         mix_last = same or Ho * Wo < H * W          # the 1x1 convolution runs on whichever side has fewer pixels
+        t = fused = None
+        if not mix_last and not half_weights and x.dtype == torch.float32:
+            # up-sampling block: the 1x1 convolution first, its result joins the inverse transform's (one pass over the output)
+            t = _native.channel_mix(x.view(B, Ci, -1), cwm, cb).view(B, Co, H, W)
+            fused = _fused_addend(t, Ho, Wo, w1.shape[2], w1.shape[3], False)
+        if fused is not None:
+            m1, m2 = w1.shape[2], w1.shape[3]
+            xt = torch.empty((B, Ci, 2 * m1, m2), dtype=torch.complex64, device=x.device) if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]]
+            _native.dft2d_forward(x, m1, m2, 1.0 / (H * W), out=xt, channel_offset=0)
+            O = _native.mode_mix(xt.view(B, Ci, 2, m1 * m2), [w1, w2], 0)
+            s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True, addend=fused)
+        else:
+            s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo, xt_out=None if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]])
         out = s
-        if mix_last:
+        if fused is not None:
+            act = x
+            if fuse_gelu:
+                out = F.gelu(s)
+        elif mix_last:
             act = x if same else resample_forward(x, Ho, Wo)
             if fuse_gelu:
                 _, out = _native.channel_mix2(act.view(B, Ci, -1), None, cwm, cb, out=s.view(B, Co, -1), accumulate=True, y_act=True)
@@ -1090,8 +1130,9 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                 _native.channel_mix(act.view(B, Ci, -1), cwm, cb, out=s.view(B, Co, -1))
         else:
             act = x
-            t = _native.channel_mix(x.view(B, Ci, -1), cwm, cb)
-            resample_forward(t.view(B, Co, H, W), Ho, Wo, out=s)
+            if t is None:
+                t = _native.channel_mix(x.view(B, Ci, -1), cwm, cb).view(B, Co, H, W)
+            resample_forward(t, Ho, Wo, out=s)
             if fuse_gelu:
                 out = F.gelu(s)
         ctx.save_for_backward(xt, w1, w2, cwm, act, s if fuse_gelu else None)
@@ -1124,8 +1165,14 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         need_gc = ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])
         join = ctx.join
         lw1, lw2, lcw, lcb = ctx.leaves
+        # down-sampling block (forward: act = R x; s += Wm act): the point-wise part of gx is the ADJOINT resampling of Wm^T gs, an
+        # up-sampling - it joins the spectral part inside the inverse transform (one pass over gx) where the fused kernel applies
+        g_act = addend = None
+        if mix_last and not same and need_gx and gs.dtype == torch.float32:
+            g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True).view(B, Ci, Ho, Wo)
+            addend = _fused_addend(g_act, H, W, w1.shape[2], w1.shape[3], True)
         gx, gw1, gw2, stacked = _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, ctx.needs_input_grad[1] and ctx.needs_input_grad[2],
-                                                   (lw1, lw2), ctx.stack, join)
+                                                   (lw1, lw2), ctx.stack, join, addend)
         pstack = ctx.stack if stacked else None         # the 1x1 convolution's weight gradient follows the spectral layer's stack
         gcw = gcb = None
         # x is the activation of a fused-GELU block (join.pre): the gradient this block returns must be multiplied by gelu'(pre).
@@ -1142,9 +1189,10 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                     _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True, out=gx.view(B, Ci, -1), dgelu_of=dg_view,
                                         dgelu_total=own_last)
                     dg_done = own_last
-                else:
-                    g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True)
-                    resample_adjoint(g_act.view(B, Ci, Ho, Wo), H, W, out=gx)
+                elif addend is None:
+                    if g_act is None:
+                        g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True).view(B, Ci, Ho, Wo)
+                    resample_adjoint(g_act, H, W, out=gx)
             if need_gc:
                 gcw, gcb = _wgrad_into((lcw, lcb), gs.view(B, Co, -1), act.view(B, Ci, -1), None, ctx.needs_input_grad[3],
                                        has_bias and ctx.needs_input_grad[4], stack=pstack)
@@ -1198,18 +1246,26 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         _native.dft2d_forward(x1, m1, m2, 1.0 / (H * W), out=xt, channel_offset=0)
         _native.dft2d_forward(x2, m1, m2, 1.0 / (H * W), out=xt, channel_offset=C1)
         O = _native.mode_mix(xt.view(B, Ci, 2, m1 * m2), [w1, w2], 0)
-        s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True, dtype=x1.dtype)
-        # point-wise branch accumulates into s
         same = (H, W) == (Ho, Wo)
         mix_last = same or Ho * Wo < H * W
-        if mix_last:
+        t = fused = None
+        if not mix_last and not half_weights and x1.dtype == torch.float32:
+            # up-sampling block: the 1x1 convolution first, its result joins the inverse transform's (one pass over the output)
+            t = _mix2_forward(x1.view(B, C1, -1), x2.view(B, C2, -1), cwm, cb).view(B, Co, H, W)
+            fused = _fused_addend(t, Ho, Wo, m1, m2, False)
+        s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True, dtype=x1.dtype, addend=fused)
+        # point-wise branch accumulates into s
+        if fused is not None:
+            a1, a2 = x1, x2
+        elif mix_last:
             a1 = x1 if same else resample_forward(x1, Ho, Wo)
             a2 = x2 if same else resample_forward(x2, Ho, Wo)
             _mix2_forward(a1.view(B, C1, -1), a2.view(B, C2, -1), cwm, cb, out=s.view(B, Co, -1), accumulate=True)
         else:
             a1, a2 = x1, x2
-            t = _mix2_forward(x1.view(B, C1, -1), x2.view(B, C2, -1), cwm, cb)
-            resample_forward(t.view(B, Co, H, W), Ho, Wo, out=s)
+            if t is None:
+                t = _mix2_forward(x1.view(B, C1, -1), x2.view(B, C2, -1), cwm, cb).view(B, Co, H, W)
+            resample_forward(t, Ho, Wo, out=s)
         ctx.save_for_backward(xt, w1, w2, cwm, a1, a2)
         ctx.geom = (H, W, same, mix_last, cb is not None, tuple(cw.shape))
         return s

@@ -89,6 +89,76 @@ def _tables(n_in: int, n_out: int, device_str: str, mode: str = "bicubic_aa"):
     return tuple(out)
 
 
+ADD_KE = 3          # k-steps of the fused up-sampling operands (csrc/dft2d_inv_add_kernel.h): bands of <= 4 * 3 = 12 sources per 16 outputs
+
+
+def _add_operands(Rh: torch.Tensor, Rw: torch.Tensor):
+    """Operand tables of uno_dft2d_inverse_add for the separable operator out = Rh . t . Rw^T (Rh (H, Hs), Rw (W, Ws) dense float32), or
+    None when a band is too wide.  Layouts: include/uno_spectral.h."""
+    H, Hs = Rh.shape
+    W, Ws = Rw.shape
+    span = 4 * ADD_KE
+    if Hs < 1 or Ws < span:
+        return None
+    lane = torch.arange(64)
+    r16, kk = lane % 16, lane // 16
+
+    def band(M, rows):
+        """(first, last) non-zero column over the given rows of M (rows outside the matrix are skipped); (0, -1) when all are zero"""
+        rows = [r for r in rows if 0 <= r < M.shape[0]]
+        if not rows:
+            return 0, -1
+        nz = (M[rows] != 0).any(0).nonzero().flatten()
+        return (int(nz[0]), int(nz[-1])) if nz.numel() else (0, -1)
+
+    nrt = (H + 15) // 16
+    p0 = torch.zeros(nrt, dtype=torch.int32)
+    rowop = torch.zeros(nrt, ADD_KE, 64, dtype=torch.float32)
+    Rh_pad = torch.zeros(16 * nrt, Hs + span, dtype=torch.float32)
+    Rh_pad[:H, :Hs] = Rh
+    for rt in range(nrt):
+        lo, hi = band(Rh, range(16 * rt, 16 * rt + 16))
+        if hi - lo + 1 > span:
+            return None
+        p0[rt] = lo
+        for e in range(ADD_KE):
+            rowop[rt, e] = Rh_pad[16 * rt + r16, lo + ADD_KE * kk + e]
+    nwt = ((W // 2) + 16) // 16
+    v0 = torch.zeros(nwt, 2, dtype=torch.int32)
+    colop = torch.zeros(nwt, 2, ADD_KE, 64, dtype=torch.float32)
+    Rw_pad = torch.zeros(W + 1, Ws + span, dtype=torch.float32)      # row W: all zero (columns outside [0, W))
+    Rw_pad[:W, :Ws] = Rw
+    for wt in range(nwt):
+        for side in range(2):
+            cols = [16 * wt + i if side == 0 else W - 16 * wt - i for i in range(16)]
+            lo, hi = band(Rw, cols)
+            lo = max(min(lo, Ws - span), 0)          # the 12-byte pieces of a lane stay inside the source row
+            if hi - lo + 1 > span:
+                return None
+            v0[wt, side] = lo
+            w = torch.tensor([c if 0 <= c < W else W for c in cols])[r16]
+            for ks in range(ADD_KE):
+                colop[wt, side, ks] = Rw_pad[w, lo + ADD_KE * kk + ks]
+    return p0, rowop.contiguous(), v0.contiguous(), colop.contiguous()
+
+
+@functools.lru_cache(maxsize=None)
+def upsample_add_tables(Hs: int, Ws: int, H: int, W: int, device_str: str, adjoint: bool = False, mode: str = "bicubic_aa"):
+    """Device operand tables for the fused `inverse transform + resampled addend` kernel, or None.
+    adjoint=False: the addend is resample_forward of an (Hs, Ws) image to (H, W) (an up-sampling block's point-wise branch);
+    adjoint=True: the addend is resample_adjoint, for an (H, W) INPUT grid, of an (Hs, Ws) gradient (a down-sampling block's input
+    gradient: the operators are the transposes of the (H, W) -> (Hs, Ws) matrices)."""
+    if adjoint:
+        Rh, Rw = _matrix(H, Hs, mode).t().contiguous(), _matrix(W, Ws, mode).t().contiguous()
+    else:
+        Rh, Rw = _matrix(Hs, H, mode), _matrix(Ws, W, mode)
+    ops = _add_operands(Rh, Rw)
+    if ops is None:
+        return None
+    dev = torch.device(device_str)
+    return tuple(t.to(dev) for t in ops)
+
+
 def resample_forward(x: torch.Tensor, Ho: int, Wo: int, out: torch.Tensor | None = None) -> torch.Tensor:
     """R_h x R_w^T on the device (no autograd); with `out`, accumulates into it."""
     H, W = x.shape[-2:]
