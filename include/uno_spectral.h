@@ -136,7 +136,7 @@ int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W,
  *   col_op  [nwt][2][3][64]        entry (wt, side, ks, lane) = Rw[w][col_v0 + 3 (lane / 16) + ks], w = 16 wt + lane % 16 (side 0)
  *                                  or W - 16 wt - lane % 16 (side 1); zero for w outside [0, W)
  * uno_dft2d_inverse_add_applies: 1 where the fused kernel exists (float32, rows of 192..223 or 416..447 elements whose 16-row
- * tiles fit the LDS, modes1 <= 24, modes2 <= 32), else 0 - the caller then runs uno_dft2d_inverse followed by uno_resample2d. */
+ * tiles fit the LDS, modes1 <= 27, modes2 <= 24), else 0 - the caller then runs uno_dft2d_inverse followed by uno_resample2d. */
 int uno_dft2d_inverse_add_applies(int n_img, int H, int W, int m1, int m2, int Hs, int Ws);
 int uno_dft2d_inverse_add(const float* spec, float* images, int n_img, int H, int W, int m1, int m2, float scale, int hermitian_cols,
                           int mask_overlap, const float* addend, int Hs, int Ws, const int* tile_p0, const float* row_op,

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -320,6 +321,9 @@ int uno_dft2d_inverse_add(const float* spec, float* images, int n_img, int H, in
     p.twW = twiddle_table(W);
     if (!p.twH || !p.twW) return -6;
     p.add_src = addend; p.add_Hs = Hs; p.add_Ws = Ws; p.add_p0 = tile_p0; p.add_rowop = row_op; p.add_v0 = col_v0; p.add_colop = col_op;
+#ifdef UNO_K3A_DEV       // development builds: knock-out switches of the kernel (tools/dev/k3a_time.py), see dft2d_inv_add_kernel.h
+    { static const int dev_exp = getenv("UNO_K3A_STAGGER") ? atoi(getenv("UNO_K3A_STAGGER")) : 0; p.exp = dev_exp; }
+#endif
     return launch_dft2d_inv_add(p, (hipStream_t)stream);
 }
 

@@ -21,11 +21,13 @@
 // D[w][h] comes out in the layout of the transform's own result (lane (h, g): columns 4 g .. 4 g + 3 of the column tile and, for the
 // mirrored side, W - (4 g ..)), so the addend meets the transform in registers: 6 + 6 MFMAs per column tile next to the transform's
 // 2 KS, no LDS, ~4 VALU.
-// Memory ordering: loads and stores share the in-order vmcnt counter, and this kernel lives on stores that drain asynchronously over
-// a whole tile time - a load issued behind a tile's store burst would not return before the burst has drained.  So the loads of tile
-// rt + 1 (28 pieces of t + 3 operator registers) are issued BEFORE the stores of tile rt, and consumed (stage 1' of every column
-// tile, its results parked in registers) before those stores are issued too: the only stores ahead of them are the previous tile's,
-// a tile time old.  The column loop is fully unrolled (NWTM column tiles at most) so that the parked operands are registers.
+// Memory ordering: loads and stores share the vmcnt counter, and this kernel lives on stores that drain asynchronously over a whole
+// tile time - waiting for a load means waiting for every store issued before it (knock-outs, tools/dev/k3a_time.py: with the loads
+// requested AFTER the column loop the kernel took 397 us, 267 without the loads, 187 without loads and addend MFMAs = K3 alone).  So the
+// loads of tile rt + 1 (28 pieces of t + 3 operator registers) are issued at the TOP of tile rt, straight behind the stores of tile
+// rt - 1, and consumed after tile rt's column loop (stage 1' of every column tile, results parked in registers) but before tile rt's
+// stores are issued: what they wait for has had a whole column loop to drain.  The column loop is fully unrolled (NWTM column tiles) so
+// that the parked operands are registers.
 #pragma once
 #include "dft2d_inv_kernel.h"
 #include <type_traits>
@@ -37,7 +39,7 @@ constexpr int ADD_KE = 3;           // k-steps of both banded operators: bands o
 __device__ __forceinline__ f32x4 f4(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
-template <int KS, int JT, int NWTM>
+template <int KS, int KSK, int NWTM>
 __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_inv_ft_add_kernel(Dft2dParams p) {
     constexpr int NT = (KS + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -73,8 +75,11 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
     const int image = blockIdx.x * (NWT / NW) + slot;
     if (image >= p.n_img) return;               // no barrier below
 
-    constexpr int KSK = 2 * JT + 1;
-    const int ksk = (m1 + 4) >> 2;
+    const int ko = p.exp & 0xff;                 // development knock-outs: 1 no addend loads, 2 no spectrum reload, 4 no stores, 8 no stage 1', 16 no stage 2'
+    // KSK == (m1 + 4) >> 2 k-steps of the column stage exactly (K3 compiles 2 JT + 1 >= that and skips the rest at run time: here every
+    // register counts)
+    constexpr int ksk = KSK;
+    constexpr bool EARLY = NWTM > 7;             // operands requested at the top of the tile (one wave per SIMD); two waves per SIMD: after the column loop
     const float2* O = reinterpret_cast<const float2*>(p.in) + spectrum_index(p, image) * 2 * m1 * m2;
 
     // ---- the addend's loop-invariant operands: column operator, B operand of stage 1' (lane (k-slot kk, column n = r16))
@@ -101,25 +106,24 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
     const int wfast_hi = W - Wh - 1;
     const bool chain = NW == 1;
 
-    // The column stage's A operand (P_k = O[+k] + O[-k], M_k = O[+k] - O[-k], dft2d_inv_kernel.h) is re-read from the image's 5 KB
-    // spectrum for every row tile (L1 / L2 hits, requested with the tile's other operands) instead of living in 8 NT (2 JT + 1)
-    // registers across the tile loop: the parked addend operands need them
+    // column stage's A operand: P_k = O[+k] + O[-k], M_k = O[+k] - O[-k] (dft2d_inv_kernel.h), once per image
+    float Pr[NT][KSK], Pi[NT][KSK], Mr[NT][KSK], Mi[NT][KSK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int l = 16 * t + 4 * (r16 & 3) + (r16 >> 2);
+        const float cs = p.scale * ((p.herm && l < m2) ? herm_weight(l, W) : 1.0f);
+#pragma unroll
+        for (int ks = 0; ks < KSK; ++ks) {
+            const int k = 4 * ks + kk;
+            float2 vp = make_float2(0.f, 0.f), vm = make_float2(0.f, 0.f);
+            if (!(ko & 2) && l < m2 && k < m1 && !(p.mask && !row_survives(k, m1, H))) vp = O[(size_t)k * m2 + l];
+            if (!(ko & 2) && l < m2 && k >= 1 && k <= m1) vm = O[(size_t)(2 * m1 - k) * m2 + l];
+            Pr[t][ks] = (vp.x + vm.x) * cs; Pi[t][ks] = (vp.y + vm.y) * cs;
+            Mr[t][ks] = (vp.x - vm.x) * cs; Mi[t][ks] = (vp.y - vm.y) * cs;
+        }
+    }
     f32x4 Ur[NT], Ui[NT];
     auto stage_b = [&](int rt) {
-        float2 vp[NT][KSK], vm[NT][KSK];
-        float cs[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int l = 16 * t + 4 * (r16 & 3) + (r16 >> 2);
-            cs[t] = p.scale * ((p.herm && l < m2) ? herm_weight(l, W) : 1.0f);
-#pragma unroll
-            for (int ks = 0; ks < KSK; ++ks) {
-                const int k = 4 * ks + kk;
-                vp[t][ks] = make_float2(0.f, 0.f); vm[t][ks] = make_float2(0.f, 0.f);
-                if (l < m2 && k < m1 && !(p.mask && !row_survives(k, m1, H))) vp[t][ks] = O[(size_t)k * m2 + l];
-                if (l < m2 && k >= 1 && k <= m1) vm[t][ks] = O[(size_t)(2 * m1 - k) * m2 + l];
-            }
-        }
         const unsigned hB = (unsigned)min(16 * rt + r16, H - 1);
         const unsigned a4 = 8u * ((4u * hB) % (unsigned)H);
         unsigned aj = 8u * (((unsigned)kk * hB) % (unsigned)H);
@@ -134,24 +138,29 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
                 const float ns = -twb.y;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float pr = (vp[t][ks].x + vm[t][ks].x) * cs[t], pi = (vp[t][ks].y + vm[t][ks].y) * cs[t];
-                    const float mr = (vp[t][ks].x - vm[t][ks].x) * cs[t], mi = (vp[t][ks].y - vm[t][ks].y) * cs[t];
-                    Ur[t] = mfma16(pr, twb.x, Ur[t]);
-                    Ui[t] = mfma16(pi, twb.x, Ui[t]);
-                    Ur[t] = mfma16(mi, ns, Ur[t]);
-                    Ui[t] = mfma16(mr, twb.y, Ui[t]);
+                    Ur[t] = mfma16(Pr[t][ks], twb.x, Ur[t]);
+                    Ui[t] = mfma16(Pi[t][ks], twb.x, Ui[t]);
+                    Ur[t] = mfma16(Mi[t][ks], ns, Ur[t]);
+                    Ui[t] = mfma16(Mr[t][ks], twb.y, Ui[t]);
                 }
             }
             twb = twn;
         }
     };
     // the addend of row tile rt, first half: operands requested (request), stage 1' of every column tile (reduce) -> Ct
-    float rowB[ADD_KE];                         // row operator of the tile, B operand of stage 2'
+    float rowB[ADD_KE], rowN[ADD_KE];           // row operator of the tile (B operand of stage 2') and of the next one
     f32x3 piece[NWTM][2];
     f32x4 Ct[NWTM][2];                          // C^T of (column tile, side): A operand of stage 2'
     auto request = [&](int rt) {
+        if (ko & 1) {
 #pragma unroll
-        for (int e = 0; e < ADD_KE; ++e) rowB[e] = p.add_rowop[((size_t)rt * ADD_KE + e) * 64 + lane];
+            for (int e = 0; e < ADD_KE; ++e) rowN[e] = 0.f;
+#pragma unroll
+            for (int wt = 0; wt < NWTM; ++wt) { piece[wt][0] = f32x3{0, 0, 0}; piece[wt][1] = f32x3{0, 0, 0}; }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < ADD_KE; ++e) rowN[e] = p.add_rowop[((size_t)rt * ADD_KE + e) * 64 + lane];
         const int p0 = p.add_p0[rt];
         const int voff = (min(p0 + urel, Hs - 1) * Ws + ADD_KE * kk) * 4;
 #pragma unroll
@@ -164,6 +173,13 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
     };
     auto reduce = [&]() {
 #pragma unroll
+        for (int e = 0; e < ADD_KE; ++e) rowB[e] = rowN[e];
+        if (ko & 8) {
+#pragma unroll
+            for (int wt = 0; wt < NWTM; ++wt) { Ct[wt][0] = f32x4{0, 0, 0, 0}; Ct[wt][1] = f32x4{0, 0, 0, 0}; }
+            return;
+        }
+#pragma unroll
         for (int wt = 0; wt < NWTM; ++wt) {
             f32x4 c0 = f32x4{0, 0, 0, 0}, c1 = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -175,6 +191,11 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
         }
     };
 
+    // de-phase the waves (development knob p.exp: units of 512 cycles per wave index / workgroup parity)
+    if ((p.exp >> 8) > 0) {
+        const int nsl = ((wave & 3) + 4 * (int)(blockIdx.x & 1)) * (p.exp >> 8);
+        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     if (wsub < nrt) { request(wsub); stage_b(wsub); reduce(); }
 
     for (int rt = wsub; rt < nrt; rt += NW) {
@@ -184,6 +205,10 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
         const int rowbase = phase + r16 * W;
         const bool row_ok = r16 < rows;
         const int nfast = rows == 16 ? max(1, min(nwt, (wfast_hi + 1) >> 4)) : 1;
+        const bool more = rt + NW < nrt;
+        // the NEXT tile's addend operands are requested now, straight behind the previous tile's stores: they land while this tile's
+        // column loop runs (that is also the time those stores have to drain - loads and stores share one in-order counter)
+        if (EARLY && more) request(rt + NW);
 
         // ---- stage A' + stage 2' of the addend, column tile by column tile; tile wt - 1 is staged under tile wt's MFMAs.
         // FULL: all 16 rows exist - column tiles 1 .. NWTM - 2 need no guards, the last one by a uniform test
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
                         E = mfma16(tw[cur][sp].x, Ur[sp >> 2][sp & 3], E);
                         D = mfma16(tw[cur][sp].y, Ui[sp >> 2][sp & 3], D);
                     }
-                    if (sp < ADD_KE) {
+                    if (sp < ADD_KE && !(ko & 16)) {
                         al = mfma16(Ct[wt][0][sp], rowB[sp], al);
                         ar = mfma16(Ct[wt][1][sp], rowB[sp], ar);
                     }
@@ -240,8 +265,11 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
         if (rows == 16) columns(std::true_type{}); else columns(std::false_type{});
 
         // ---- next tile: operands requested, column stage and stage 1' done BEFORE this tile's stores are issued (header)
-        const bool more = rt + NW < nrt;
-        if (more) { request(rt + NW); stage_b(rt + NW); reduce(); }
+        if (more) {
+            if (!EARLY) request(rt + NW);
+            stage_b(rt + NW);
+            reduce();
+        }
 
         // ---- the tile goes out as whole 128-byte lines: LDS index i <-> memory gbase[i]
         float* gbase = tile - phase;
@@ -259,8 +287,8 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
                     if (i + e >= lo && i + e < hi) gbase[i + e] = buf[i + e];
             }
         };
-        const int nfull = hi >> 8;
-        store_guarded(4 * lane);
+        const int nfull = (ko & 4) ? 0 : (hi >> 8);
+        if (!(ko & 4)) store_guarded(4 * lane);
         int it = 1;
         for (; it + 4 <= nfull; it += 4) {
             const float* src = buf + 256 * it + 4 * lane;
@@ -290,19 +318,19 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
 // tables are given
 static bool inv_add_shape_ok(const Dft2dParams& p) {
     const int nwt = ((p.W >> 1) + 16) >> 4;
-    const int KS = (p.m2 + 3) / 4, JT = (2 * p.m1 + 15) / 16;
+    const int KS = (p.m2 + 3) / 4, KSK = (p.m1 + 4) >> 2;
     // (the unrolled column loop is compiled for 7 and 14 column tiles: rows of 192 .. 223 and 416 .. 447 elements)
-    return (nwt == 7 || nwt == 14) && KS <= 8 && JT <= 3 && !p.bf16 && p.add_Ws >= 4 * ADD_KE && p.add_Hs >= 1;
+    return (nwt == 7 || nwt == 14) && KS <= 6 && KSK >= 1 && KSK <= 7 && !p.bf16 && p.add_Ws >= 4 * ADD_KE && p.add_Hs >= 1;
 }
 
-template <int KS, int JT, int NWTM>
+template <int KS, int KSK, int NWTM>
 static int launch_inv_add(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
-    auto k = dft2d_inv_ft_add_kernel<KS, JT, NWTM>;
+    auto k = dft2d_inv_ft_add_kernel<KS, KSK, NWTM>;
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_inv_add: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
     char name[64];
-    snprintf(name, sizeof(name), "uno::dft2d_inv_ft_add_kernel<%d, %d, %d>", KS, JT, NWTM);
+    snprintf(name, sizeof(name), "uno::dft2d_inv_ft_add_kernel<%d, %d, %d>", KS, KSK, NWTM);
     {
         ProfScope prof(name, (double)p.n_img * ((double)p.H * p.W * 4.0 + (double)p.add_Hs * p.add_Ws * 4.0 + 2.0 * p.m1 * p.m2 * 8.0), s);
         hipLaunchKernelGGL(k, dim3((p.n_img + g.g - 1) / g.g), dim3(64 * g.nw * g.g), g.lds, s, p);
@@ -312,13 +340,13 @@ static int launch_inv_add(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     return 0;
 }
 
-template <int KS, int JT>
+template <int KS, int KSK>
 static int launch_inv_add_t(const Dft2dParams& p, hipStream_t s) {
     InvGeometry ft;
     if (!inv_ft_geometry(p, KS, &ft)) { set_error("dft2d_inv_add: the full-tile form does not apply to %dx%d", p.H, p.W); return -3; }
     const int nwt = ((p.W >> 1) + 16) >> 4;
-    if (nwt == 7) return launch_inv_add<KS, JT, 7>(p, ft, s);
-    return launch_inv_add<KS, JT, 14>(p, ft, s);
+    if (nwt == 7) return launch_inv_add<KS, KSK, 7>(p, ft, s);
+    return launch_inv_add<KS, KSK, 14>(p, ft, s);
 }
 
 }  // namespace uno
