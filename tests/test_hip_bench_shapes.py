@@ -157,6 +157,51 @@ def test_c2_darcy_conv5_two_source_block_full_size():
     COVERED.update(n for n in ran if _spectral(n))
 
 
+
+
+K3A_CASES = {   # (images, source grid, output grid, modes, adjoint operators, hermitian columns + overlap mask, scale) of the fused
+                # "inverse transform + resampled point-wise branch" launches of ONE Darcy step (uno_dft2d_inverse_add)
+    "conv4_forward": (16 * 128, 111, 223, 8, False, True, 1.0),
+    "conv5_forward": (16 * 64, 223, 446, 18, False, True, 1.0),
+    "conv0_input_gradient": (16 * 64, 223, 446, 18, True, False, 1.0 / (446 * 446)),
+    # conv1's input gradient carries conv5's deferred c0 spectrum (GradJoin.merge): modes 18 on the 223^2 grid
+    "conv1_input_gradient_merged_spectrum": (16 * 128, 111, 223, 18, True, False, 1.0 / (223 * 223)),
+    "conv1_input_gradient": (16 * 128, 111, 223, 8, True, False, 1.0 / (223 * 223)),
+}
+
+
+@pytest.mark.parametrize("case", list(K3A_CASES))
+def test_c2_darcy_fused_inverse_add_full_size(case):
+    """K3-A at the geometries the headline step launches it with (reference integral_operators.py:272-273 + :240-242: inverse transform
+    of the corner spectrum + bicubic / align_corners / antialias resampling of the low-resolution point-wise result, and the adjoint
+    for the input gradient of a down-sampling block), the whole launch at bench size, 24 images spread over it against float64."""
+    from uno_amd import _native
+    from uno_amd import resample as rs
+    n, Hs, H, m, adjoint, herm, scale = K3A_CASES[case]
+    d = dev()
+    g = torch.Generator().manual_seed(n + H + m)
+    spec = torch.randn(n, 2 * m, m, dtype=torch.complex64, generator=g)
+    t = torch.randn(n, Hs, Hs, generator=g)
+    tabs = rs.upsample_add_tables(Hs, Hs, H, H, str(d), adjoint)
+    assert tabs is not None and _native.dft2d_inverse_add_applies(n, H, H, m, m, Hs, Hs)
+    y, ran = _run_profiled(lambda: _native.dft2d_inverse(spec.to(d), H, H, scale, herm, herm, addend=(t.to(d), tabs)))
+    names = {k for k in ran if _spectral(k)}
+    assert any("dft2d_inv_ft_add_kernel" in k for k in names), ran
+    # float64 reference of the sampled images: dense inverse DFT over the two corners + the dense resampling operators
+    R = (rs._matrix(H, Hs).t() if adjoint else rs._matrix(Hs, H)).double().numpy()          # (H, Hs), square grids: rows == columns
+    K = np.array([j if j < m else H - 2 * m + j for j in range(2 * m)])
+    Eh = np.exp(2j * np.pi * np.outer(np.arange(H), K) / H)                                   # (H, 2m)
+    Ew = np.exp(2j * np.pi * np.outer(np.arange(m), np.arange(H)) / H)                        # (m, W)
+    c = np.array([1.0 if (l == 0 or 2 * l == H) else 2.0 for l in range(m)]) if herm else np.ones(m)
+    keep = np.array([0.0 if (herm and j < m and j >= H - m) else 1.0 for j in range(2 * m)])
+    idx = sorted(set(np.linspace(0, n - 1, 24).astype(int).tolist()))
+    yk = y[idx].cpu().double().numpy()
+    for q, i in enumerate(idx):
+        O = spec[i].numpy().astype(np.complex128) * scale * c[None, :] * keep[:, None]
+        ref = (Eh @ O @ Ew).real + R @ t[i].double().numpy() @ R.T
+        assert rel_err(yk[q], ref) < TOL, (case, i, rel_err(yk[q], ref))
+    COVERED.update(names)
+
 # ------------------------------------------------------------------ C3: NS-2D UNO(14,32), 64^2, batch 32 (navier_stokes_uno2d.py:160-214)
 C3_LAYERS = [   # Ci, Co, H, Ho, modes  (SURVEY Appendix B)
     (32, 48, 64, 48, 22), (48, 96, 48, 32, 14), (96, 192, 32, 16, 6), (192, 192, 16, 16, 6),

@@ -151,6 +151,39 @@ def test_cat_project_with_crop_matches_the_uncropped_layer():
         assert float(gx[:, :, S1:].abs().max()) == 0.0 and float(gx[:, :, :, S2:].abs().max()) == 0.0
 
 
+def test_cropped_projection_deferring_into_a_join_whose_tensor_is_a_fused_gelu_activation():
+    """out_join + defer_grad + crop together (advisor finding, round 5): the tensor `a` is the activation of a block that leaves its
+    pre-activation sum to the join; its first consumer (a block, the owner) completes the joined gradient; its second consumer is the
+    cropped fc1 - GELU - fc2, whose deferred contribution reaches the WINDOW only.  gelu'(pre) must reach the whole plane (the border
+    holds the owner's own gradient): every gradient against the same graph without joins and without the crop."""
+    import uno_amd.integral_operators as io
+    torch.manual_seed(13)
+    B, H, W, S1, S2 = 2, 20, 300, 17, 277
+    P = io.OperatorBlock_2D(8, 64, H, W, 4, 4).cuda()
+    Q = io.OperatorBlock_2D(64, 64, H, W, 4, 4).cuda()
+    w = (torch.randn(64, 128) / 11).cuda().requires_grad_(True)
+    b = torch.randn(64).cuda().requires_grad_(True)
+    w2 = torch.randn(1, 64).cuda().requires_grad_(True)
+    b2 = torch.randn(1).cuda().requires_grad_(True)
+    x0 = torch.randn(B, 8, H, W).cuda()
+    gout = torch.randn(B, 1, S1, S2).cuda()
+    leaves = list(P.parameters()) + list(Q.parameters()) + [w, b, w2, b2]
+
+    def run(joined):
+        for p in leaves:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        J = io.GradJoin() if joined else None
+        a = P(x, H, W, out_join=J) if joined else P(x, H, W)
+        q = Q(a, H, W, join=J) if joined else Q(a, H, W)
+        out = io.channel_mix_cat_project([q, a], w, b, w2, b2, gelu_first=False, defer_grad=J, crop=(S1, S2) if joined else None)
+        (out[:, :, :S1, :S2] * gout).sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in leaves]
+    got, ref = run(True), run(False)
+    for a_, b_ in zip(got, ref):
+        assert rel(a_, b_) < 2e-5, rel(a_, b_)
+
+
 def test_window_argument_errors():
     from uno_amd import _native
     x = torch.randn(1, 64, 20 * 300).cuda()

@@ -1,6 +1,7 @@
 """Bookkeeping of the per-layer spectrum stacks (integral_operators._stack_take and friends: the weight gradient of a layer that a
 roll-out uses several times per graph is batched over its uses, reference ns_train_2d.py:46-68) - host logic only, CPU tensors,
 no kernels: how many slots a layer gets, when a stack is closed, the 2 GiB bound of the per-mode GEMM's operand offsets."""
+import pytest
 import torch
 
 import uno_amd.integral_operators as io
@@ -79,6 +80,44 @@ def test_stale_backward_pass_entries_are_swept(monkeypatch):
     assert io._pass_state() is None            # outside a pass: sweeps
     assert 123456 not in io._PASSES and 123457 in io._PASSES
     io._PASSES.clear()
+
+
+def test_a_swept_pass_that_shows_up_again_raises(monkeypatch):
+    """wall-clock age only guesses that a pass is dead; a live pass whose state was swept must fail loudly at its next
+    contribution instead of overwriting the gradient it had been summing (beta = 0 write into the registered buffer)."""
+    import time
+    from uno_amd import integral_operators as io
+    io._PASSES.clear()
+    io._SWEPT.clear()
+    io._PASSES[777] = {"id": 777, "acc": {}, "stacks": {}, "uses": {}, "born": time.monotonic() - 2 * io._STALE_PASS_SECONDS}
+    assert io._pass_state() is None and 777 in io._SWEPT
+    monkeypatch.setattr(io, "_current_graph_task_id", lambda: 777)
+    with pytest.raises(RuntimeError, match="was idle for more than"):
+        io._pass_state()
+    io._SWEPT.clear()
+
+
+def test_complex_adam_loads_a_capturable_checkpoint_into_a_plain_optimiser():
+    """the step entries of a capturable state are one shared device tensor; a non-capturable ComplexAdam that loads them must
+    count in host integers (one increment per step, not one per parameter)."""
+    from uno_amd.harness import ComplexAdam
+    ps = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(3, dtype=torch.cfloat))]
+    src = ComplexAdam(ps, lr=1e-3)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    src.step()
+    sd = src.state_dict()
+    shared = torch.tensor([4], dtype=torch.int32)
+    for st in sd["state"].values():
+        st["step"] = shared                          # what a capturable optimiser's state_dict carries
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    dst = ComplexAdam(qs, lr=1e-3)
+    dst.load_state_dict(sd)
+    assert all(isinstance(st["step"], int) and st["step"] == 4 for st in dst.state.values())
+    for q in qs:
+        q.grad = torch.randn_like(q)
+    dst.step()
+    assert all(st["step"] == 5 for st in dst.state.values()) and int(shared) == 4
 
 
 def test_private_autograd_entry_points_are_optional(monkeypatch):

@@ -548,12 +548,18 @@ static int lift_check(const char* who, int B, int Cin, int Cm, int Co, int H, in
     return 0;
 }
 
+// size limits of the fused lift kernels (lift_bwd.hip: 32-bit element offsets into the padded planes, 24-bit pixel slots over H x Wp):
+// grids beyond them take the layer-by-layer forms below instead of failing (advisor finding, round 5)
+static bool lift_fused_fits(int B, int H, int Hp, int Wp, int Co) {
+    return (long long)Hp * Wp * Co < (1LL << 31) && B <= 65535 && (long long)H * Wp < (1LL << 24);
+}
+
 int uno_lift_forward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin, int Cm,
                      int Co, int H, int W, int Hp, int Wp, void* stream) {
     if (int rc = lift_check("uno_lift_forward", B, Cin, Cm, Co, H, W, Hp, Wp)) return rc;
     if (B == 0) return 0;
     if (!x || !w1 || !w0 || !act) { set_error("uno_lift_forward: null pointer"); return -1; }
-    if (lift_bwd_fused_applies(Cin, Cm, Co, W, (long long)H * W) && (Wp & ~3) >= 260 && (Wp & ~3) >= W) {      // K16 (lift_bwd.hip): the dedicated kernel at the Darcy widths
+    if (lift_bwd_fused_applies(Cin, Cm, Co, W, (long long)H * W) && lift_fused_fits(B, H, Hp, Wp, Co) && (Wp & ~3) >= 260 && (Wp & ~3) >= W) {      // K16 (lift_bwd.hip): the dedicated kernel at the Darcy widths
         if (int rc = launch_lift_forward_fused(x, w1, b1, w0, b0, act, B, Cin, H, W, Hp, Wp, (hipStream_t)stream)) return rc;
         return launch_clear_border(act, (long long)B * Co, Hp, Wp, H, Wp, (hipStream_t)stream);         // the rows below the domain
     }
@@ -592,7 +598,7 @@ int uno_lift_backward(const float* x, const float* w1, const float* b1, const fl
     }
     if (!x || !w1 || !w0 || !g_act || !ws) { set_error("uno_lift_backward: null pointer"); return -1; }
     const long long P = (long long)H * W;
-    if (lift_bwd_fused_applies(Cin, Cm, Co, W, P)) {
+    if (lift_bwd_fused_applies(Cin, Cm, Co, W, P) && lift_fused_fits(B, H, Hp, Wp, Co)) {
         // one kernel per pixel tile: neither gz nor gh leaves the chip (lift_bwd.hip); ws = the two arrays of partial-sum blocks
         float* part = static_cast<float*>(ws);
         const long long nparts = lift_bwd_fused_parts(B, H, W);

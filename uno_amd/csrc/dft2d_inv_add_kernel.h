@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
     // KSK == (m1 + 4) >> 2 k-steps of the column stage exactly (K3 compiles 2 JT + 1 >= that and skips the rest at run time: here every
     // register counts)
     constexpr int ksk = KSK;
-    constexpr bool EARLY = NWTM > 7;             // operands requested at the top of the tile (one wave per SIMD); two waves per SIMD: after the column loop
+    constexpr bool EARLY = !(NWTM <= 7 && KS <= 4);      // one wave per SIMD: operands requested DURING the tile's column loop; two waves per SIMD: after it
     const float2* O = reinterpret_cast<const float2*>(p.in) + spectrum_index(p, image) * 2 * m1 * m2;
 
     // ---- the addend's loop-invariant operands: column operator, B operand of stage 1' (lane (k-slot kk, column n = r16))
@@ -151,25 +151,36 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
     float rowB[ADD_KE], rowN[ADD_KE];           // row operator of the tile (B operand of stage 2') and of the next one
     f32x3 piece[NWTM][2];
     f32x4 Ct[NWTM][2];                          // C^T of (column tile, side): A operand of stage 2'
-    auto request = [&](int rt) {
+    // first source column of every (column tile, side), byte offset, once (scalar registers): a load of the table inside the tile loop
+    // is no longer provably unclobbered and becomes a vector load + readfirstlane loop in the middle of the MFMA stream
+    int v0s[NWTM][2];
+#pragma unroll
+    for (int wt = 0; wt < NWTM; ++wt)
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) v0s[wt][sd] = __builtin_amdgcn_readfirstlane(p.add_v0[wt * 2 + sd] * 4);
+    int voff_next = 0;
+    auto request_rows = [&](int rt) {            // row operator of tile rt + this lane's byte offset into t for its pieces
         if (ko & 1) {
 #pragma unroll
             for (int e = 0; e < ADD_KE; ++e) rowN[e] = 0.f;
-#pragma unroll
-            for (int wt = 0; wt < NWTM; ++wt) { piece[wt][0] = f32x3{0, 0, 0}; piece[wt][1] = f32x3{0, 0, 0}; }
             return;
         }
 #pragma unroll
         for (int e = 0; e < ADD_KE; ++e) rowN[e] = p.add_rowop[((size_t)rt * ADD_KE + e) * 64 + lane];
-        const int p0 = p.add_p0[rt];
-        const int voff = (min(p0 + urel, Hs - 1) * Ws + ADD_KE * kk) * 4;
+        const int p0 = __builtin_amdgcn_readfirstlane(p.add_p0[rt]);
+        voff_next = (min(p0 + urel, Hs - 1) * Ws + ADD_KE * kk) * 4;
+    };
+    auto request_piece = [&](int wt) {           // the two 12-byte pieces of column tile wt (compile-time wt)
+        if (ko & 1) { piece[wt][0] = f32x3{0, 0, 0}; piece[wt][1] = f32x3{0, 0, 0}; return; }
 #pragma unroll
-        for (int wt = 0; wt < NWTM; ++wt)
+        for (int sd = 0; sd < 2; ++sd) {
+            piece[wt][sd] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(trsrc, voff_next, v0s[wt][sd], 0));
+        }
+    };
+    auto request = [&](int rt) {
+        request_rows(rt);
 #pragma unroll
-            for (int sd = 0; sd < 2; ++sd) {
-                const int v0 = p.add_v0[wt * 2 + sd];          // uniform: scalar load
-                piece[wt][sd] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(trsrc, voff, v0 * 4, 0));
-            }
+        for (int wt = 0; wt < NWTM; ++wt) request_piece(wt);
     };
     auto reduce = [&]() {
 #pragma unroll
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
         const bool more = rt + NW < nrt;
         // the NEXT tile's addend operands are requested now, straight behind the previous tile's stores: they land while this tile's
         // column loop runs (that is also the time those stores have to drain - loads and stores share one in-order counter)
-        if (EARLY && more) request(rt + NW);
+        if (EARLY) request_rows(more ? rt + NW : rt);        // (last tile: valid addresses, results unused - no control flow around the loads)
 
         // ---- stage A' + stage 2' of the addend, column tile by column tile; tile wt - 1 is staged under tile wt's MFMAs.
         // FULL: all 16 rows exist - column tiles 1 .. NWTM - 2 need no guards, the last one by a uniform test
@@ -258,6 +269,9 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
                     }
                 }
                 Ey[cur] = E; Dy[cur] = D; aL[cur] = al; aR[cur] = ar;
+                // the NEXT row tile's pieces of this column tile, spread over the column loop: the previous tile's stores are still
+                // draining through the same path, two loads at a time slip in between them (all 28 at the top of the tile: 343 us)
+                if (EARLY) request_piece(wt);
                 if (wt >= 1) stage(wt - 1, is_fast(wt - 1), Ey[nx], Dy[nx], aL[nx], aR[nx]);
             }
             stage(NWTM - 1, is_fast(NWTM - 1), Ey[(NWTM - 1) & 1], Dy[(NWTM - 1) & 1], aL[(NWTM - 1) & 1], aR[(NWTM - 1) & 1]);

@@ -92,6 +92,13 @@ class ComplexAdam(Optimizer):
         # the loaded state replaced the moment tensors and the step entries: plans and device counters are rebuilt from it on next use
         self._plans.clear()
         self._dev_counters.clear()
+        if not self.capturable:
+            # a capturable checkpoint keeps ONE shared int32 device tensor as the step of every parameter, and torch hands `step` entries
+            # over un-cloned: `st["step"] += 1` per parameter would then advance that shared tensor once per PARAMETER per step (and an
+            # in-memory state_dict would alias the source optimiser's live counter).  Host integers here.
+            for st in self.state.values():
+                if isinstance(st.get("step"), torch.Tensor):
+                    st["step"] = int(st["step"])
 
     @staticmethod
     def _real(t):

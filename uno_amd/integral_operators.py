@@ -193,7 +193,8 @@ INPLACE_PARAM_GRADS = True
 #   uses:   id(weights1 leaf) -> [leaf, [spectral-layer backward calls of this pass that did NOT go through a stack]]
 _PASSES = {}
 _PASSES_LOCK = threading.Lock()
-_STALE_PASS_SECONDS = 120.0
+_STALE_PASS_SECONDS = 3600.0
+_SWEPT = {}                 # ids of swept passes (bounded): a pass that shows up again after its state was released must not go on silently
 
 
 def _sweep_stale_passes():
@@ -201,11 +202,15 @@ def _sweep_stale_passes():
     its entry would stay in _PASSES for ever - graph-task ids are never reused - keep its gradient buffers alive and push every
     parameter it recorded off the in-place path.  Called from a thread that is NOT inside a backward pass; an entry older than
     _STALE_PASS_SECONDS seen from there belongs to no pass that could still be running (a live pass of another thread is younger
-    than that by orders of magnitude: the longest step of this package is a fraction of a second)."""
+    than that by orders of magnitude: the longest step of this package is a fraction of a second).  Should a live pass be swept after
+    all (an hour in a debugger), it raises at its next contribution instead of training on a partial gradient (_SWEPT)."""
     now = time.monotonic()
     with _PASSES_LOCK:
         for tid in [t for t, ps in _PASSES.items() if now - ps["born"] > _STALE_PASS_SECONDS]:
             _PASSES.pop(tid, None)
+            _SWEPT[tid] = now
+        while len(_SWEPT) > 256:
+            _SWEPT.pop(next(iter(_SWEPT)))
 
 
 # The pass state hangs on two private entry points of autograd (the id of the running graph task, the engine's final-callback
@@ -230,6 +235,11 @@ def _pass_state():
         return None
     ps = _PASSES.get(tid)
     if ps is None:
+        if tid in _SWEPT:
+            # wall-clock age is only a heuristic for "this pass raised": a LIVE pass that was paused for longer than the limit (debugger,
+            # contended device) lost its in-place accumulation map when it was swept - later contributions would overwrite earlier ones
+            raise RuntimeError(f"uno_amd: backward pass {tid} was idle for more than {_STALE_PASS_SECONDS:.0f} s and its in-place gradient "
+                               "state was released; raise uno_amd.integral_operators._STALE_PASS_SECONDS or set INPLACE_PARAM_GRADS = False")
         if _PASSES:
             _sweep_stale_passes()              # (a pass that raised never ran its callback; see there)
         with _PASSES_LOCK:
@@ -781,10 +791,11 @@ class _ChannelMixCatFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 g1 = cleared(_native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=dg, window=window))
             w2 = w[:, C1:].contiguous()
-            # accumulates into the window of the other consumer's (whole-plane) gradient: nothing to clear
+            # accumulates into the window of the other consumer's (whole-plane) gradient: nothing to clear.  NOT fusable: a fused
+            # gelu'(pre) epilogue would reach the window only, and the border of the joined gradient holds the owner's own non-zero
+            # contribution - the owner applies gelu' to the whole plane itself (GradJoin.apply reports "not fused")
             ctx.defer.pending.append((lambda out, dgo=None: _native.channel_mix(
-                gy, w2, None, transpose_w=True, out=out.view(B, C2, -1), dgelu_of=None if dgo is None else dgo.view(B, C2, -1),
-                dgelu_total=dgo is not None, window=window), True))
+                gy, w2, None, transpose_w=True, out=out.view(B, C2, -1), window=window), False))
         else:
             if ctx.needs_input_grad[0]:
                 g1 = cleared(_native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=dg, window=window))
