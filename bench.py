@@ -38,6 +38,9 @@ def parse():
                     help="data-parallel workload (BASELINE.json configs): c2 Darcy 421^2 (the headline, default), c4 Navier-Stokes 3-D "
                          "64x64x20 Uno3D_T20 width 32 batch 8 / GPU, c5 Darcy 1024^2 mixed precision batch 4 / GPU")
     ap.add_argument("--strong", action="store_true", help="strong scaling: a global batch of 16 split over the ranks")
+    ap.add_argument("--comm-dtype", choices=("f32", "bf16"), default="f32",
+                    help="gradient buckets on the links: f32 (default; equals one process on the global batch) or bf16 (half the bytes: "
+                         "--workload c4 at width 32 moves 3.8 GB per step; float32 buffer, optimiser state and update)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host CPU leg (developer runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (C3 / C4 / C5, reference-style caller)")
     ap.add_argument("--cpu-batch", type=int, default=16, help="samples per CPU-baseline step")
@@ -383,7 +386,8 @@ def extra_workloads(dev):
     the Darcy model, C3 NS-2D roll-out, C4 NS-3D, C5 1024^2 block / model."""
     import torch
     from uno_amd import _native
-    from uno_amd.harness import (ComplexAdam, DarcyTrainer, GraphedStep, UNO, UNO_9, UNO_9_ReferenceStyle, Uno3D_T20,
+    from tools.reference_style_caller import UNO_9_ReferenceStyle        # measurement comparator, not product code
+    from uno_amd.harness import (ComplexAdam, DarcyTrainer, GraphedStep, UNO, UNO_9, Uno3D_T20,
                                  ns2d_rollout_loss, ns3d_loss, synthetic_darcy_batch)
     out = {}
 
@@ -511,7 +515,8 @@ def workload_kernel_names(dev):
     oracle comparison."""
     import torch
     from uno_amd import _native
-    from uno_amd.harness import (ComplexAdam, DarcyTrainer, UNO, UNO_9_ReferenceStyle, Uno3D_T20, ns2d_rollout_loss, ns3d_loss,
+    from tools.reference_style_caller import UNO_9_ReferenceStyle
+    from uno_amd.harness import (ComplexAdam, DarcyTrainer, UNO, Uno3D_T20, ns2d_rollout_loss, ns3d_loss,
                                  synthetic_darcy_batch, workloads)
     out = {}
 
@@ -673,7 +678,9 @@ def run_secondary(args, dev, world, rank, backend):
         torch.cuda.synchronize(dev)
 
     selfcheck = dp_selfcheck_workload(args.workload, dev, world, rank) if world > 1 else None
-    w = workloads.build(args.workload, dev, seed=1234 + rank)              # this rank's shard, resident in HBM
+    import torch as _t
+    cd = _t.bfloat16 if args.comm_dtype == "bf16" else None
+    w = workloads.build(args.workload, dev, seed=1234 + rank, comm_dtype=cd)      # this rank's shard, resident in HBM
     for _ in range(args.warmup):
         w.step()
     sync_all()
@@ -690,7 +697,7 @@ def run_secondary(args, dev, world, rank, backend):
         elapsed = float(t.item())
         g = w.trainer.grads
         comm = {"backend": backend, "ranks": dist.get_world_size(), "grad_bytes": g.flat.numel() * 4, "buckets": len(g.buckets),
-                "bucket_mb": 32.0, "selfcheck": selfcheck}
+                "bucket_mb": 32.0, "comm_dtype": args.comm_dtype, "reserved_cus": w.trainer.comm_cus, "selfcheck": selfcheck}
     lv = float(loss)
     assert lv == lv, "training produced NaN"
     if rank == 0:
@@ -777,7 +784,7 @@ def main():
         sys.exit(f"--strong needs a world size that divides {BATCH}")
     torch.manual_seed(0)                                    # same init everywhere (then broadcast from rank 0)
     model = UNO_9(3, WIDTH, pad=PAD).to(dev)
-    trainer = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
+    trainer = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3, comm_dtype=(torch.bfloat16 if args.comm_dtype == "bf16" else None))
     a, u = synthetic_darcy_batch(per_rank, S, 1234 + rank, dev)   # per-rank shard of the global batch, in HBM
 
     def sync_all():
@@ -817,7 +824,7 @@ def main():
             trainer.grads.all_reduce_sum()
         sync_all()
         comm = {"backend": backend, "ranks": dist.get_world_size(), "grad_bytes": trainer.grads.flat.numel() * 4,
-                "buckets": len(trainer.grads.buckets), "bucket_mb": 32.0,
+                "buckets": len(trainer.grads.buckets), "bucket_mb": 32.0, "comm_dtype": args.comm_dtype, "reserved_cus": trainer.comm_cus,
                 "blocking_allreduce_ms": (time.perf_counter() - tc) / 5 * 1e3}
         # overlapped vs blocking exchange: the same K steps with the bucket hooks off and ONE blocking all-reduce after the
         # backward pass; and the issue time of every bucket relative to the start of a backward pass (host clock, rank 0)

@@ -122,6 +122,11 @@ int uno_dft2d_forward(const float* images, float* spec, int n_img, int H, int W,
 int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W, int m1, int m2,
                       float scale, int hermitian_cols, int mask_overlap, void* stream);
 
+/* ABI 11.  Data parallelism (reference train loops are single-process; BASELINE.json north_star: RCCL all-reduce beside the backward
+ * pass): set aside `n` compute units for concurrently running communication kernels.  Launch geometries that size themselves to the
+ * device ("one workgroup per CU", persistent grids) then count on the remaining CUs.  Returns the previous value; 0 = none (default). */
+int uno_reserve_cus(int n);
+
 /* ABI 11.  Pruned inverse DFT PLUS the up-sampled point-wise branch in one pass over the output:
  *   images[h][w] = (uno_dft2d_inverse's result) + sum_{u,v} Rh[h][u] Rw[w][v] addend[u][v]
  * = `x1_out + x2_out` of an up-sampling operator block, reference integral_operators.py:272-273, with x2_out the bicubic /

@@ -188,6 +188,88 @@ def test_bucketed_allreduce_with_unused_parameters(tmp_path):
     assert torch.allclose(flat, exp, rtol=1e-6, atol=1e-7)
 
 
+def _bf16_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+        for name, cd in (("f32", None), ("bf16", torch.bfloat16)):
+            torch.manual_seed(100)
+            model = UNO_9(3, 4, pad=5, block_cls=so.OracleOperatorBlock2d)
+            tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3, bucket_mb=0.002, comm_dtype=cd)
+            a, u = synthetic_darcy_batch(4, 72, seed=7, device="cpu")
+            sl = slice(rank * 2, rank * 2 + 2)
+            tr.grads.zero_()
+            B = 2
+            loss = lp_loss_rel_sum(model(a[sl]).reshape(B, -1), u[sl].reshape(B, -1))
+            tr.grads.arm(None)
+            loss.backward()
+            tr.grads.finish()
+            out[name] = tr.grads.flat.clone()
+            tr.opt.step()                               # and the step runs on the widened buffer
+            out[name + "_p"] = torch.cat([(torch.view_as_real(q.detach()) if q.is_complex() else q.detach()).reshape(-1) for q in model.parameters()])
+        if rank == 0:
+            torch.save(out, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_buckets_match_float32_exchange(tmp_path):
+    """SURVEY 8(e) / DESIGN section 6: optional bfloat16 gradient buckets (half the bytes on the links; float32 buffer, optimiser state
+    and update) - world size 2, gloo: the exchanged gradient agrees with the float32 exchange to bfloat16 rounding (relative L2 4e-3:
+    one rounding of each rank's contribution + one of their sum, 2^-9 each), the parameters after the update to 1e-5."""
+    out_path = str(tmp_path / "bf16.pt")
+    mp.spawn(_bf16_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    r = torch.load(out_path)
+    assert r["bf16"].dtype == torch.float32
+    e = float((r["bf16"] - r["f32"]).norm() / r["f32"].norm())
+    assert 0 < e < 4e-3, e                              # (0 < : the low-precision path really ran)
+    assert float((r["bf16_p"] - r["f32_p"]).norm() / r["f32_p"].norm()) < 1e-5
+
+
+def test_aborted_backward_leaves_gradient_buckets_and_pass_state_clean():
+    """A backward pass that raises under arm() (an out-of-memory error the training loop catches): the trainer waits for what was
+    issued, resets the bucket counters and releases the library's pass state - the next step runs as if nothing had happened."""
+    import uno_amd.integral_operators as io
+    from uno_amd.harness.train import FlatGradients
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        lin1, lin2 = torch.nn.Linear(6, 5), torch.nn.Linear(5, 1)
+        tr = DarcyTrainer(torch.nn.Sequential(lin1, lin2), lr=1e-3, weight_decay=0.0, force_collectives=True, bucket_mb=1e-5)
+        assert len(tr.grads.buckets) >= 3
+
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+        x = torch.ones(3, 6)
+        io._PASSES[424242] = {"id": 424242, "acc": {}, "stacks": {}, "uses": {}, "born": 0.0}      # what a failed pass leaves behind
+        with pytest.raises(RuntimeError, match="boom"):
+            tr.step_with(lambda: lin2(Boom.apply(lin1(x))).sum())          # lin2's buckets are issued, then the pass dies
+        g = tr.grads
+        assert not g._armed and g._works == [] and g._next == 0 and g._pending == list(g._bucket_params)
+        assert not io._PASSES
+        ref1, ref2 = torch.nn.Linear(6, 5), torch.nn.Linear(5, 1)
+        ref1.load_state_dict(lin1.state_dict()); ref2.load_state_dict(lin2.state_dict())
+        tr.grads.zero_()
+        loss = lin2(lin1(x)).sum()
+        tr.grads.arm(None, True)
+        loss.backward()
+        tr.grads.finish()
+        ref2(ref1(x)).sum().backward()
+        exp = torch.cat([q.grad.reshape(-1) for q in list(ref1.parameters()) + list(ref2.parameters())])
+        assert torch.allclose(tr.grads.flat[:exp.numel()], exp, rtol=1e-6, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_flat_gradients_rebind_after_zero_grad_set_to_none():
     from uno_amd.harness.train import FlatGradients
     torch.manual_seed(0)
@@ -273,9 +355,9 @@ def test_complex_adam_per_parameter_step_counts():
 
 
 def test_reference_style_caller_reproduces_the_reference_on_cpu():
-    """harness/reference_style.py (the reference's calling convention: channels-last Linear, permute, F.pad, torch.cat) with the
+    """tools/reference_style_caller.py (the reference's calling convention: channels-last Linear, permute, F.pad, torch.cat) with the
     oracle blocks on the host reproduces the reference's prediction - it is the same op sequence."""
-    from uno_amd.harness import UNO_9_ReferenceStyle
+    from tools.reference_style_caller import UNO_9_ReferenceStyle
     c = Case(ZH, "uno9")
     S, B, width, pad = [int(v) for v in c.meta]
     model = UNO_9_ReferenceStyle(3, width, pad=pad, block_cls=so.OracleOperatorBlock2d)

@@ -263,7 +263,7 @@ def test_3d_any_mode_count_vs_dense_oracle():
 @pytest.mark.parametrize("cfg", [((15, 15, 9), (7, 7, 6)), ((8, 64, 40), (8, 48, 30)), ((9, 9, 7), (12, 12, 9))])
 def test_pointwise_op_3d_outside_the_pruned_dft_range_matches_the_reference_sequence(cfg):
     """pointwise_op_3D for grids the pruned-DFT resampling kernels do not take (odd kept-row counts, (W, T) planes over 1792 elements):
-    `_resample3d_plan` is None and the layer runs the stock rocFFT sequence with the corner copies as one mask multiplication -
+    `_resample3d_plan` is None: the layer raises, and with STOCK_FFT_RESAMPLE3D = True runs the stock rocFFT sequence with the corner copies as one mask multiplication -
     compared here with the reference's own op sequence (integral_operators.py:439-467) on the host, forward and every gradient
     (these shapes were skipped by the bench-shape test and compared nowhere)."""
     from uno_amd.integral_operators import _resample3d_plan, pointwise_op_3D
@@ -282,8 +282,15 @@ def test_pointwise_op_3d_outside_the_pruned_dft_range_matches_the_reference_sequ
     yr = ref(xr, *dout)
     yr.backward(gy)
     xd = x.to(dev).requires_grad_(True)
-    y = mod(xd, *dout)
-    y.backward(gy.to(dev))
+    import uno_amd.integral_operators as io
+    with pytest.raises(RuntimeError, match="outside the range of the"):
+        mod(xd, *dout)                              # default: no silent dispatch to rocFFT
+    io.STOCK_FFT_RESAMPLE3D = True
+    try:
+        y = mod(xd, *dout)
+        y.backward(gy.to(dev))
+    finally:
+        io.STOCK_FFT_RESAMPLE3D = False
     assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) < 2e-5
     assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
     assert rel_err(mod.conv.weight.grad.cpu().numpy(), ref.conv.weight.grad.numpy()) < 2e-5

@@ -5,7 +5,10 @@ channels-last `nn.Linear` lift and projection, `F.gelu`, `permute`, `F.pad`, pos
 It exists to answer one question: what does a user get who keeps the reference's model code UNCHANGED and only swaps
 `integral_operators` for this package?  (The fused harness model `UNO_9` additionally uses this package's own helpers -
 channels-first lift, two-source blocks, fused GELU - which a drop-in user would not call.)  Same parameters and
-registration order as `UNO_9`, so the reference's state_dict loads into both."""
+registration order as `UNO_9`, so the reference's state_dict loads into both.
+
+A MEASUREMENT COMPARATOR (bench.py `extras.darcy_reference_style_caller`, two tests): it lives beside the bench, not in the product
+package - a drop-in user runs the reference's own darcy_flow_uno2d.py, not this file."""
 from __future__ import annotations
 
 import math
@@ -14,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .models import UNO_9
+from uno_amd.harness.models import UNO_9
 
 
 class UNO_9_ReferenceStyle(UNO_9):

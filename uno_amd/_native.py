@@ -39,6 +39,7 @@ _SIGNATURES = {
     "uno_dft2d_forward_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
+    "uno_reserve_cus": (C.c_int, [_i]),
     "uno_dft2d_inverse_add_applies": (C.c_int, [_i] * 7),
     "uno_dft2d_inverse_add": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_dft2d_forward_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
@@ -345,6 +346,11 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
                     int(mask_overlap), images.shape[1], out.shape[1], int(channel_offset), _stream(images))
     _check(rc, "uno_dft2d_forward_grouped")
     return out
+
+
+def reserve_cus(n: int) -> int:
+    """Set aside n compute units for communication kernels running beside the library's (uno_reserve_cus); returns the previous value."""
+    return int(lib().uno_reserve_cus(int(n)))
 
 
 def dft2d_inverse_add_applies(n_img, H, W, m1, m2, Hs, Ws) -> bool:

@@ -185,6 +185,9 @@ static int mode_gemm(int op, const float2* act, const float2* const* w, const fl
     return launch_mode_gemm(p, s);
 }
 
+static int g_reserved_cus = 0;
+int reserved_cus() { return __atomic_load_n(&g_reserved_cus, __ATOMIC_RELAXED); }
+
 }  // namespace uno
 
 using namespace uno;
@@ -221,6 +224,11 @@ SideStream* side_stream_of_current_device() {
 extern "C" {
 
 int uno_abi_version(void) { return UNO_SPECTRAL_ABI_VERSION; }
+
+int uno_reserve_cus(int n) {
+    if (n < 0) n = 0;
+    return __atomic_exchange_n(&uno::g_reserved_cus, n, __ATOMIC_RELAXED);
+}
 
 int uno_profile_begin(int max_records) {
     std::lock_guard<std::mutex> lock(g_prof_mu);

@@ -71,7 +71,7 @@ static int b16_cu_count() {
         hipDeviceProp_t prop;
         cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    return cus[dev];
+    return usable_cus(cus[dev]);
 }
 
 static int b16_exp(const char* name, int dflt) {

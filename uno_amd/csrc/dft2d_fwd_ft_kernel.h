@@ -373,7 +373,7 @@ static int ft_device_cu_count() {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    return cus;
+    return usable_cus(cus);
 }
 
 static size_t fwd_ft_lds_bytes(const Dft2dParams& p, int NTF, int R4, int waves) {

@@ -515,7 +515,7 @@ static int device_cu_count() {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    return cus;
+    return usable_cus(cus);
 }
 
 static size_t inv_lds_bytes(const Dft2dParams& p, int KS, int waves, bool tab) {

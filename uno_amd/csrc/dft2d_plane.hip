@@ -395,7 +395,10 @@ static int plane_grid(const void* kernel, size_t lds, int n_img) {
         }
     }
     const long long want = ((long long)n_img + PL_WAVES - 1) / PL_WAVES;
-    return (int)std::min<long long>(want, (long long)resident);
+    // (resident = device CUs x workgroups per CU, cached; CUs set aside for communication kernels leave the grid proportionally smaller)
+    const int r = reserved_cus();
+    const long long mine = r > 0 ? std::max<long long>(1, (long long)resident * std::max(8, 256 - r) / 256) : resident;
+    return (int)std::min<long long>(want, mine);
 }
 
 template <int MT, int NTN>

@@ -257,6 +257,11 @@ inline bool ensure_dynamic_lds(const void* kernel, size_t bytes, int* slot) {
     return true;
 }
 void set_error(const char* fmt, ...);
+// Compute units the launch geometries may count on: the device's, minus those the caller set aside for concurrently running
+// communication kernels (uno_reserve_cus: RCCL's all-reduce of the previous gradient buckets runs beside the backward pass under data
+// parallelism, and a geometry tuned to "one workgroup per CU on all CUs" would run a second round for the CUs RCCL holds)
+int reserved_cus();
+inline int usable_cus(int device_cus) { const int r = reserved_cus(); return device_cus - r >= 8 ? device_cus - r : (device_cus < 8 ? device_cus : 8); }
 
 // RAII timing scope around one kernel launch (no-op unless uno_profile_begin() is active).
 struct ProfScope {

@@ -34,7 +34,7 @@ from torch.autograd.function import once_differentiable
 from . import _native
 
 __all__ = [
-    "enable_mixed_precision", "GradJoin", "channel_mix_cat_project",
+    "enable_mixed_precision", "GradJoin", "channel_mix_cat_project", "release_pass_state",
     "SpectralConv1d_Uno", "pointwise_op_1D", "OperatorBlock_1D",
     "SpectralConv2d_Uno", "pointwise_op_2D", "OperatorBlock_2D",
     "SpectralConv3d_Uno", "pointwise_op_3D", "OperatorBlock_3D",
@@ -195,6 +195,14 @@ _PASSES = {}
 _PASSES_LOCK = threading.Lock()
 _STALE_PASS_SECONDS = 3600.0
 _SWEPT = {}                 # ids of swept passes (bounded): a pass that shows up again after its state was released must not go on silently
+
+
+def release_pass_state():
+    """Drop the state of every backward pass on record.  For a training loop that caught an exception out of loss.backward(): autograd
+    skips the final callbacks of a pass that raised, so its entry would otherwise wait for the time-based sweep.  Only call while no
+    backward pass is running on any thread of this process (harness.DarcyTrainer does, from its except path)."""
+    with _PASSES_LOCK:
+        _PASSES.clear()
 
 
 def _sweep_stale_passes():
@@ -1665,13 +1673,18 @@ class _FftResample3dFn(torch.autograd.Function):
         return _native.fft_resample3d(_plain(gy), ctx.din, (t1, t1), (t2, t2), m3, scale, adjoint=True), None, None
 
 
+# pointwise_op_3D on a grid its pruned-DFT resampling kernels do not take (_resample3d_plan is None): False (default) - raise, naming the
+# limits; True - run the reference's op sequence on torch.fft (rocFFT on the device: a stock-library dispatch the caller asked for)
+STOCK_FFT_RESAMPLE3D = False
+
+
 class pointwise_op_3D(nn.Module):
     """1x1x1 convolution + the reference's FFT crop/resample (quirks kept bug-for-bug: unnormalised
     forward transform, corners copied into an INPUT-sized zero spectrum, irfftn(s=output dims) that
     trims/zero-pads at the END of each axis, identity trilinear resize) - reference
     integral_operators.py:430-468.  The convolution runs on the channel-mix kernels (K8 / K9) for float32 device
     tensors - MIOpen executes a 1x1x1 Conv3d with its naive direct kernels, 0.9 s of a 2.2 s first NS-3D step - the
-    FFT resampling runs on the pruned-DFT kernels (_FftResample3dFn; stock rocFFT outside their shape range); the trilinear resize to the size the tensor already has is an exact
+    FFT resampling runs on the pruned-DFT kernels (_FftResample3dFn; outside their shape range the layer raises unless STOCK_FFT_RESAMPLE3D allows torch.fft); the trilinear resize to the size the tensor already has is an exact
     identity under align_corners=True and is skipped on the device."""
 
     def __init__(self, in_codim, out_codim, dim1, dim2, dim3):
@@ -1700,6 +1713,13 @@ class pointwise_op_3D(nn.Module):
             plan = _resample3d_plan(out.shape[-3:], (dim1, dim2, dim3), out.device)
             if plan is not None:
                 return _FftResample3dFn.apply(out, (dim1, dim2, dim3), plan)
+        if on_device and not STOCK_FFT_RESAMPLE3D:
+            # no silent dispatch to a stock library from a product component: the pruned-DFT resampling kernels do not cover this grid
+            raise RuntimeError(
+                f"pointwise_op_3D: the FFT crop / resample {tuple(out.shape[-3:])} -> {(dim1, dim2, dim3)} is outside the range of the "
+                "pruned-DFT kernels (they take an even number of kept rows per complex axis - at most 80 / 48 - and (W, T) planes of at most "
+                "1792 elements with T <= 64); set uno_amd.integral_operators.STOCK_FFT_RESAMPLE3D = True to run this layer's resampling "
+                "through torch.fft (rocFFT) instead")
         spec = torch.fft.rfftn(out, dim=[-3, -2, -1])
         h1, h2, h3 = dim1 // 2, dim2 // 2, dim3 // 2
         if on_device:
