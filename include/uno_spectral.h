@@ -304,6 +304,14 @@ long long uno_lift_bwd_ws_bytes(int B, int Cin, int Cm, int Co, int H, int W);
 int uno_lift_backward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g_act, float* gw1,
                       float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp,
                       void* stream);
+/* ABI 11.  The same with a SECOND gradient of the padded activation, valid on the H x W domain of the same (Hp, Wp) planes: the lift's
+ * output feeds two layers (conv0 and, through the skip connection, fc1: reference darcy_flow_uno2d.py:108-127), and the kernel that
+ * streams the gradient adds the two as it reads them - no accumulation pass over the 64-channel tensor.  g_act2 may be NULL.
+ * uno_lift_backward_takes_second: 1 where the one-kernel form runs (only it takes the second tensor). */
+int uno_lift_backward_takes_second(int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp);
+int uno_lift_backward2(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g_act,
+                       const float* g_act2, float* gw1, float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co,
+                       int H, int W, int Hp, int Wp, void* stream);
 
 /* GELU followed by zero padding at the end of both axes (the lift's last activation + domain padding, reference
  * darcy_flow_uno2d.py:103-107): backward = 0: out (n_img, Hp, Wp) = pad(gelu(s (n_img, H, W))), gy ignored;

@@ -64,16 +64,16 @@ def test_pointwise_op_3d_golden(name):
         io.STOCK_FFT_RESAMPLE3D = True
     try:
         y = pw(x)
+        assert tuple(y.shape) == tuple(c.y.shape)
+        assert rel_err(y.detach().cpu().numpy(), c.y) < 1e-4
+        # adjoint identity of the (linear) operator: <pw(x) - pw(0), g> == <x, pw^T g>
+        g = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, g)
+        lhs = float(((y - pw(torch.zeros_like(x))).detach() * g).double().sum())
+        rhs = float((x.detach() * gx).double().sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1e-6)
     finally:
         io.STOCK_FFT_RESAMPLE3D = False
-    assert tuple(y.shape) == tuple(c.y.shape)
-    assert rel_err(y.detach().cpu().numpy(), c.y) < 1e-4
-    # adjoint identity of the (linear) operator: <pw(x) - pw(0), g> == <x, pw^T g>
-    g = torch.randn_like(y)
-    (gx,) = torch.autograd.grad(y, x, g)
-    lhs = float(((y - pw(torch.zeros_like(x))).detach() * g).double().sum())
-    rhs = float((x.detach() * gx).double().sum())
-    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1e-6)
 
 
 def test_dim_mutation_quirk():

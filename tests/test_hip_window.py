@@ -280,6 +280,46 @@ def test_whole_lift_without_stored_intermediates(B, Cin, Cm, Co, H, W, ph, pw, b
             assert rel(a, r.grad) < 3e-5
 
 
+@pytest.mark.parametrize("B,Cin,H,W,ph,pw", [(2, 3, 37, 283, 6, 6), (1, 3, 421, 421, 25, 25), (2, 2, 41, 300, 5, 0), (1, 1, 130, 263, 1, 2)])
+def test_lift_backward_adds_a_second_gradient_as_it_reads(B, Cin, H, W, ph, pw):
+    """uno_lift_backward2: the gradient of the lift's output arrives as TWO tensors (its two consumers, reference
+    darcy_flow_uno2d.py:108, :127); the second is valid on the domain only - NaN outside it - and the result equals the call on their sum."""
+    from uno_amd import _native
+    gen = torch.Generator().manual_seed(B + Cin + H + W)
+    x = torch.randn(B, Cin, H, W, generator=gen).cuda()
+    w1, w0 = torch.randn(32, Cin, generator=gen).cuda(), (torch.randn(64, 32, generator=gen) / 32 ** 0.5).cuda()
+    b1, b0 = torch.randn(32, generator=gen).cuda(), torch.randn(64, generator=gen).cuda()
+    assert _native.lift_backward_takes_second(x, w1, w0, H + ph, W + pw)
+    g = torch.randn(B, 64, H + ph, W + pw, generator=gen).cuda()
+    g2 = torch.full((B, 64, H + ph, W + pw), float("nan")).cuda()
+    g2[:, :, :H, :W] = torch.randn(B, 64, H, W, generator=gen).cuda()
+    both = g.clone()
+    both[:, :, :H, :W] += g2[:, :, :H, :W]
+    got = _native.lift_backward(x, w1, b1, w0, b0, g, g2)
+    ref = _native.lift_backward(x, w1, b1, w0, b0, both)
+    for a, r in zip(got, ref):
+        assert torch.isfinite(a).all()
+        assert rel(a, r) < 2e-6, rel(a, r)
+
+
+def test_two_destination_input_gradient_on_a_window():
+    """both input gradients of a two-source layer from one pass over gy on a window (what fc1's backward hands to the lift's join):
+    each equals the one-destination windowed call"""
+    from uno_amd import _native
+    gen = torch.Generator().manual_seed(21)
+    B, C1, C2, Co, H, pitch, rows, cols = 2, 64, 64, 64, 21, 300, 19, 280
+    win = (rows, cols, pitch)
+    gy = torch.randn(B, Co, H * pitch, generator=gen).cuda()
+    w = (torch.randn(Co, C1 + C2, generator=gen) / 8).cuda()
+    dg = torch.randn(B, C1, H * pitch, generator=gen).cuda()
+    g1, g2 = _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=C1, dgelu_of=dg, window=win)
+    r1 = _native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=dg, window=win)
+    r2 = _native.channel_mix(gy, w[:, C1:].contiguous(), None, transpose_w=True, window=win)
+    for a, r in ((g1, r1), (g2, r2)):
+        a4, r4 = a.view(B, -1, H, pitch)[..., :rows, :cols], r.view(B, -1, H, pitch)[..., :rows, :cols]
+        assert rel(a4, r4) < 2e-6
+
+
 def test_lift_gelu_pad_autograd_matches_layer_by_layer():
     from uno_amd.integral_operators import channel_mix, gelu_channel_mix, gelu_pad2d, lift_gelu_pad
     torch.manual_seed(9)

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "uno_lift_forward": (C.c_int, [_fp] * 6 + [_i] * 8 + [_fp]),
     "uno_lift_bwd_ws_bytes": (C.c_longlong, [_i] * 6),
     "uno_lift_backward": (C.c_int, [_fp] * 11 + [_i] * 8 + [_fp]),
+    "uno_lift_backward2": (C.c_int, [_fp] * 12 + [_i] * 8 + [_fp]),
+    "uno_lift_backward_takes_second": (C.c_int, [_i] * 8),
     "uno_channel_mix_dgelu_padded": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "uno_channel_wgrad2_win": (C.c_int, [_fp, _fp, _fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_backward_win": (C.c_int, [_fp] * 7 + [_i, _i, _i, _i, _i, C.c_longlong, _fp]),
@@ -648,14 +650,24 @@ def lift_forward(x, w1, b1, w0, b0, Hp: int, Wp: int):
     return act
 
 
-def lift_backward(x, w1, b1, w0, b0, g_act):
-    """-> gw1 (Cm, Cin), gb1 (Cm) or None, gw0 (Co, Cm), gb0 (Co) or None (uno_lift_backward)."""
+def lift_backward_takes_second(x, w1, w0, Hp: int, Wp: int) -> bool:
+    B, Cin, H, W = x.shape
+    return bool(lib().uno_lift_backward_takes_second(B, Cin, w1.shape[0], w0.shape[0], H, W, int(Hp), int(Wp)))
+
+
+def lift_backward(x, w1, b1, w0, b0, g_act, g_act2=None):
+    """-> gw1 (Cm, Cin), gb1 (Cm) or None, gw0 (Co, Cm), gb0 (Co) or None (uno_lift_backward / uno_lift_backward2).
+    g_act2: a second gradient of the padded activation (same shape, valid on the domain) added as the kernel reads (fused kernel only)."""
     _require(g_act, torch.float32, "grad_output")
     B, Cin, H, W = x.shape
     Cm, Co = w1.shape[0], w0.shape[0]
     Hp, Wp = g_act.shape[-2:]
     if tuple(g_act.shape[:2]) != (B, Co):
         raise RuntimeError("uno_amd: grad_output does not match the lift")
+    if g_act2 is not None:
+        _require(g_act2, torch.float32, "second grad_output")
+        if tuple(g_act2.shape) != tuple(g_act.shape):
+            raise RuntimeError("uno_amd: the two gradients of the lift's output disagree in shape")
     dev = x.device
     gw1 = torch.empty((Cm, Cin), dtype=torch.float32, device=dev)
     gw0 = torch.empty((Co, Cm), dtype=torch.float32, device=dev)
@@ -664,8 +676,8 @@ def lift_backward(x, w1, b1, w0, b0, g_act):
     null = C.c_void_p(0)
     with torch.cuda.device(dev):
         ws = torch.empty(max(1, lib().uno_lift_bwd_ws_bytes(B, Cin, Cm, Co, H, W)), dtype=torch.uint8, device=dev)
-        rc = lib().uno_lift_backward(_ptr(x), _ptr(w1), _ptr(b1) if b1 is not None else null, _ptr(w0), _ptr(b0) if b0 is not None else null,
-                                     _ptr(g_act), _ptr(gw1), _ptr(gb1) if gb1 is not None else null, _ptr(gw0),
+        rc = lib().uno_lift_backward2(_ptr(x), _ptr(w1), _ptr(b1) if b1 is not None else null, _ptr(w0), _ptr(b0) if b0 is not None else null,
+                                     _ptr(g_act), _ptr(g_act2) if g_act2 is not None else null, _ptr(gw1), _ptr(gb1) if gb1 is not None else null, _ptr(gw0),
                                      _ptr(gb0) if gb0 is not None else null, _ptr(ws), B, Cin, Cm, Co, H, W, int(Hp), int(Wp), _stream(x))
     _check(rc, "uno_lift_backward")
     return gw1, gb1, gw0, gb0

@@ -591,9 +591,28 @@ long long uno_lift_bwd_ws_bytes(int B, int Cin, int Cm, int Co, int H, int W) {
     return 4LL * B * P * (Co + Cm) + lift_wgrad_ws(B, Cin, Cm, Co, P);
 }
 
+int uno_lift_backward_takes_second(int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp) {
+    if (B < 1 || Cin < 1 || Cin > 3 || Cm < 5 || Cm > 32 || Cm % 16 || Co < 1 || H < 1 || W < 260 || Hp < H || Wp < W) return 0;
+    return (lift_bwd_fused_applies(Cin, Cm, Co, W, (long long)H * W) && lift_fused_fits(B, H, Hp, Wp, Co)) ? 1 : 0;
+}
+
+int uno_lift_backward2(const float* x, const float* w1, const float* b1, const float* w0, const float* b0_, const float* g_act, const float* g_act2,
+                       float* gw1, float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp,
+                       void* stream);
+
 int uno_lift_backward(const float* x, const float* w1, const float* b1, const float* w0, const float* b0_, const float* g_act, float* gw1,
                       float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp, void* stream) {
+    return uno_lift_backward2(x, w1, b1, w0, b0_, g_act, nullptr, gw1, gb1, gw0, gb0, ws, B, Cin, Cm, Co, H, W, Hp, Wp, stream);
+}
+
+int uno_lift_backward2(const float* x, const float* w1, const float* b1, const float* w0, const float* b0_, const float* g_act, const float* g_act2,
+                       float* gw1, float* gb1, float* gw0, float* gb0, void* ws, int B, int Cin, int Cm, int Co, int H, int W, int Hp, int Wp,
+                       void* stream) {
     if (int rc = lift_check("uno_lift_backward", B, Cin, Cm, Co, H, W, Hp, Wp)) return rc;
+    if (g_act2 && !uno_lift_backward_takes_second(B, Cin, Cm, Co, H, W, Hp, Wp) && B > 0) {
+        set_error("uno_lift_backward2: a second gradient tensor goes with the fused kernel only (query uno_lift_backward_takes_second)");
+        return -3;
+    }
     if (!gw1 || !gw0) { set_error("uno_lift_backward: null pointer"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
@@ -611,7 +630,7 @@ int uno_lift_backward(const float* x, const float* w1, const float* b1, const fl
         float* part = static_cast<float*>(ws);
         const long long nparts = lift_bwd_fused_parts(B, H, W);
         float* part1 = part + (size_t)nparts * Co * (Cm + 1);
-        if (int rc = launch_lift_backward_fused(x, w1, b1, w0, b0_, g_act, part, part1, B, Cin, H, W, Hp, Wp, s)) return rc;
+        if (int rc = launch_lift_backward_fused(x, w1, b1, w0, b0_, g_act, part, part1, B, Cin, H, W, Hp, Wp, s, g_act2)) return rc;
         if (int rc = launch_channel_wgrad_finish(part, gw0, gb0, Cm, Co, nparts, 0, s)) return rc;
         return launch_channel_wgrad_finish(part1, gw1, gb1, Cin, Cm, nparts, 0, s);
     }

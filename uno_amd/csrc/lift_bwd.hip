@@ -79,6 +79,8 @@ struct LiftBwdParams {
     const float* w0;        // (64, 32)
     const float* b0;        // (64) or nullptr
     const float* g;         // (B, 64, Hp, Wp)
+    const float* g2;        // optional second gradient of the padded activation, same planes, valid on the domain (the skip connection's
+                            // other consumer: reference darcy_flow_uno2d.py:122-127 feeds x_fc0 to fc1 as well); nullptr = none
     float* part;            // (B * wg_per_batch, 64, 33): fc0's weight / bias gradient, one block of partial sums per workgroup
     float* part1;           // (B * wg_per_batch, 32, Cin + 1): fc_n1's - gh = gelu'(h) (w0^T gz) never leaves the kernel either
     int B, Cin;
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     const float b0v = p.b0 ? p.b0[16 * wave + r16] : 0.f;          // z's channel of this lane in the MFMA layout
     const float* xb = p.x + (size_t)b * p.Cin * G.Pd;
     const float* gb = p.g + (size_t)b * LB_CO * G.Pp;
+    const float* gb2 = p.g2 ? p.g2 + (size_t)b * LB_CO * G.Pp : nullptr;
 
     f32x4 acc3[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};       // gw0 partial: D[o = 16 wave + 4 kk + r][m = 16 t + r16], over all tiles of this workgroup
     float bsum = 0.f;                                               // gb0 partial of channel 16 wave + r16 (this lane's pixels)
@@ -180,7 +183,13 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
 #pragma unroll
             for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4) = lift_mask(lift_fix(gq[u], cur.shp), cur.nv);
         }
-        if (tile + 1 < t_end) load_tile(tile + 1);
+        if (gb2) {
+            // second gradient tensor: its eight row pieces of THIS tile go through the registers the first one just left, and are added
+            // to sZ in place (same thread, same elements) once the first half of the z GEMM has covered their latency; the next tile's
+            // loads follow.  (A second prefetched register set does not fit: 252 of 256 registers at two workgroups per CU.)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gq[u] = io_ld4(gb2 + (size_t)((tid >> 5) + 8 * u) * G.Pp + cur.op);
+        } else if (tile + 1 < t_end) load_tile(tile + 1);
         LB_STAMP(0);
         __syncthreads();
         LB_STAMP(1);
@@ -200,6 +209,17 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
             for (int mt = 0; mt < 4; ++mt) acc1[mt] = mfma16(arow[16 * mt], wv[ks], acc1[mt]);
         }
         LB_STAMP(2);
+        if (gb2) {
+            const int q4 = (tid & 31) * 4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float4* dst = reinterpret_cast<float4*>(sZ + ((tid >> 5) + 8 * u) * LB_TS + q4);
+                const float4 a = *dst, b2 = lift_mask(lift_fix(gq[u], cur.shp), cur.nv);
+                *dst = make_float4(a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w);
+            }
+            if (tile + 1 < t_end) load_tile(tile + 1);
+            __syncthreads();                // the epilogue below reads other threads' rows of sZ
+        }
         float* const zrow = sZ + (16 * wave + r16) * LB_TS + 4 * kk;       // gz = gelu'(z + b0) * g, in place in sZ (this wave's rows only)
         auto gz_tile = [&](int mt) {
             const float4 g4 = *reinterpret_cast<const float4*>(zrow + 16 * mt);
@@ -488,9 +508,9 @@ long long lift_bwd_fused_parts(int B, int H, int W) {                // (64, 33)
 }
 
 int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* part,
-                               float* part1, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s) {
+                               float* part1, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s, const float* g2) {
     LiftBwdParams p;
-    p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.part = part; p.part1 = part1;
+    p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.g2 = g2; p.part = part; p.part1 = part1;
     p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp);
     p.stamps = nullptr;
 #ifdef UNO_LB_DEV
@@ -501,7 +521,7 @@ int launch_lift_backward_fused(const float* x, const float* w1, const float* b1,
     const size_t lds = lift_bwd_lds();
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(lift_backward_kernel), lds, lds_slot)) { set_error("lift_backward: cannot raise dynamic LDS to %zu", lds); return -4; }
     {
-        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)H * W * (Cin + LB_CO), s);
+        ProfScope prof("uno::lift_backward_kernel", 4.0 * B * (double)H * W * (Cin + LB_CO * (g2 ? 2 : 1)), s);
         hipLaunchKernelGGL(lift_backward_kernel, dim3((unsigned)((p.geo.npt + LB_TPW - 1) / LB_TPW), (unsigned)B), dim3(256), lds, s, p);
     }
     const hipError_t e = hipGetLastError();

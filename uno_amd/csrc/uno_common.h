@@ -344,7 +344,7 @@ long long lift_bwd_fused_parts(int B, int H, int W);
 int launch_lift_forward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, float* act, int B, int Cin,
                               int H, int W, int Hp, int Wp, hipStream_t s);       // writes rows 0 .. H - 1 of the padded planes in full
 int launch_lift_backward_fused(const float* x, const float* w1, const float* b1, const float* w0, const float* b0, const float* g, float* part,
-                               float* part1, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s);
+                               float* part1, int B, int Cin, int H, int W, int Hp, int Wp, hipStream_t s, const float* g2 = nullptr);
 int launch_channel_wgrad_finish(const float* parts, float* gw, float* gb, int Ci, int Co, long long nparts, int accumulate, hipStream_t s);
 
 }  // namespace uno

@@ -59,17 +59,19 @@ class UNO_9(nn.Module):
         # the 3-channel input where the backward pass needs them)
         scale = math.ceil(S2 / 85)
         margin = scale * self.padding
-        lifted = lift_gelu_pad(x, self.fc_n1, self.fc0, margin, margin)
+        product = hasattr(self.conv5, "forward_cat")          # MI355X operator blocks (the CPU baseline builds the model on oracle blocks)
+        fused = product and self.conv5.non_lin and not self.conv5.normalize
+        jl = GradJoin() if fused else None
+        lifted = lift_gelu_pad(x, self.fc_n1, self.fc0, margin, margin, grad_join=jl)
         d1, d2 = lifted.shape[-2], lifted.shape[-1]
 
-        product = hasattr(self.conv5, "forward_cat")          # MI355X operator blocks (the CPU baseline builds the model on oracle blocks)
-        if product and self.conv5.non_lin and not self.conv5.normalize:
+        if fused:
             # `lifted` and `c0` feed two layers each (skip connections).  Their gradients are JOINED: the later consumer leaves its
             # contribution (a truncated spectrum + accumulating closures) to the first consumer, which transforms the summed spectrum
             # once and returns the complete gradient - no second gradient tensor, no element-wise sum (GradJoin)
             # conv0 / conv2 end in a GELU (no normalisation): the block that completes the gradient of their output (conv1 with the
             # join of c0; conv4, c2's only consumer) applies gelu'(pre) in its last accumulating kernel (`out_join`)
-            jl, jc, j2 = GradJoin(), GradJoin(), GradJoin()
+            jc, j2 = GradJoin(), GradJoin()
             c0 = self.conv0(lifted, d1 // 2, d2 // 2, join=jl, out_join=jc)
             c1 = self.conv1(c0, d1 // 4, d2 // 4, join=jc)
             c2 = self.conv2(c1, d1 // 4, d2 // 4, out_join=j2)

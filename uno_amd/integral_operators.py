@@ -628,10 +628,19 @@ class GradJoin:
         # pre-activation sum, and whether the gradient handed back to that block has already been multiplied by gelu'(pre)
         self.pre = None
         self.dgelu_applied = False
+        # the joined tensor is the output of the lift (lift_gelu_pad(grad_join=)): its backward kernel streams the gradient once and can add
+        # a second tensor as it reads.  A deferring consumer whose contribution is a plain windowed tensor then leaves it in `extra` (no
+        # accumulation pass into the owner's buffer); the lift's backward takes it.  (tensor, window) pairs.
+        self.accepts_extra = False
+        self.extra = []
 
     def reset(self):
         self.owner = False
         self.spectra, self.pending = [], []
+
+    def take_extra(self):
+        out, self.extra = self.extra, []
+        return out
 
     def void(self):
         """A consumer or producer that was handed this join cannot honour it (it runs a stock-op path): the fused GELU derivative is
@@ -795,7 +804,14 @@ class _ChannelMixCatFn(torch.autograd.Function):
 
         g1 = g2 = None
         deferred = ctx.defer is not None and ctx.defer.owner and ctx.needs_input_grad[1]
-        if deferred:
+        if deferred and ctx.defer.accepts_extra and ctx.needs_input_grad[0] and C1 % 64 == 0 and not ctx.defer.extra:
+            # x2 is the lift's output: both input gradients from ONE pass over gy (two destinations); x2's stays a tensor of its own,
+            # valid on the window, that the lift's backward kernel adds to the owner's gradient as it reads the two (no border to clear:
+            # that kernel reads the domain only)
+            g1, g2w = _native.channel_mix2(gy, None, w, None, transpose_w=True, split_out=C1, dgelu_of=dg, window=window)
+            cleared(g1)
+            ctx.defer.extra.append((g2w, window))
+        elif deferred:
             if ctx.needs_input_grad[0]:
                 g1 = cleared(_native.channel_mix(gy, w[:, :C1].contiguous(), None, transpose_w=True, dgelu_of=dg, window=window))
             w2 = w[:, C1:].contiguous()
@@ -967,12 +983,17 @@ class _LiftFn(torch.autograd.Function):
     evaluates it from x.  x is data: no gradient for it."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w0, b0, Hp, Wp):
+    def forward(ctx, x, w1, b1, w0, b0, Hp, Wp, grad_join=None):
         x, w1, w0 = _plain(x), _plain(w1), _plain(w0)
         b1 = None if b1 is None else _plain(b1)
         b0 = None if b0 is None else _plain(b0)
         ctx.save_for_backward(x, w1, w0, *[t for t in (b1, b0) if t is not None])
         ctx.has = (b1 is not None, b0 is not None)
+        ctx.join = None
+        if grad_join is not None:
+            grad_join.accepts_extra = bool(_native.lift_backward_takes_second(x, w1, w0, Hp, Wp))
+            grad_join.extra = []
+            ctx.join = grad_join
         return _native.lift_forward(x, w1, b1, w0, b0, Hp, Wp)
 
     @staticmethod
@@ -981,19 +1002,35 @@ class _LiftFn(torch.autograd.Function):
         x, w1, w0, *bs = ctx.saved_tensors
         b1 = bs.pop(0) if ctx.has[0] else None
         b0 = bs.pop(0) if ctx.has[1] else None
-        gw1, gb1, gw0, gb0 = _native.lift_backward(x, w1, b1, w0, b0, _plain(gact))
-        return None, gw1, gb1, gw0, gb0, None, None
+        gact = _plain(gact)
+        g2 = None
+        if ctx.join is not None:
+            ctx.join.accepts_extra = False
+            H, W = x.shape[-2:]
+            for t, (rows, cols, pitch) in ctx.join.take_extra():
+                t = t.view(gact.shape)
+                if g2 is None and rows >= H and cols >= W and pitch == gact.shape[-1]:
+                    g2 = t                  # covers the domain on the same planes: the kernel adds it as it reads
+                else:                       # (not reached by the harness models) any other extra: a windowed element-wise sum
+                    gact = gact.clone()
+                    gact[..., :rows, :cols] += t[..., :rows, :cols]
+        gw1, gb1, gw0, gb0 = _native.lift_backward(x, w1, b1, w0, b0, gact, g2)
+        return None, gw1, gb1, gw0, gb0, None, None, None
 
 
-def lift_gelu_pad(x: torch.Tensor, fc_n1: nn.Module, fc0: nn.Module, pad_h: int, pad_w: int) -> torch.Tensor:
+def lift_gelu_pad(x: torch.Tensor, fc_n1: nn.Module, fc0: nn.Module, pad_h: int, pad_w: int, grad_join=None) -> torch.Tensor:
     """F.pad(F.gelu(fc0(F.gelu(fc_n1(x)))), [0, pad_w, 0, pad_h]) for a channels-first x (B, Cin, H, W) and two nn.Linear layers, as one
     forward kernel and one backward kernel that store neither intermediate nor their gradients, where the shapes allow (at most 3 input channels, 16 or 32
-    in the middle, width >= 260, float32, x without gradient); the layer-by-layer forms otherwise."""
+    in the middle, width >= 260, float32, x without gradient); the layer-by-layer forms otherwise.
+    grad_join: the GradJoin of the RESULT (it feeds two layers: reference darcy_flow_uno2d.py:108, :127) - where the one-kernel backward
+    runs, a deferring consumer may leave its contribution as a tensor of its own (GradJoin.extra) and that kernel adds it while reading."""
     w1, w0 = fc_n1.weight, fc0.weight
     if x.dim() == 4 and _dev_act(x) and not x.requires_grad and w1.dtype == torch.float32 and w0.dtype == torch.float32 and pad_h >= 0 and pad_w >= 0:
         Hp, Wp = x.shape[2] + int(pad_h), x.shape[3] + int(pad_w)
         if _native.lift_ok(x, w1, w0, Hp, Wp):
-            return _LiftFn.apply(x, w1, fc_n1.bias, w0, fc0.bias, Hp, Wp)
+            return _LiftFn.apply(x, w1, fc_n1.bias, w0, fc0.bias, Hp, Wp, grad_join)
+    if grad_join is not None:
+        grad_join.accepts_extra = False
     return gelu_channel_mix_pad(channel_mix(x, w1, fc_n1.bias), w0, fc0.bias, pad_h, pad_w)
 
 
