@@ -172,6 +172,11 @@ int uno_mode_mix(const float* in, const float* const* w, float* out, int op, int
 /* gw[c][i,o] = sum_b conj(xtrunc[b,i]) * go[b,o] per mode. */
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co,
                    int ncorner, int modes_per_corner, void* stream);
+/* ABI 11.  Both per-mode GEMMs of a backward pass - the autograd adjoints of the einsum at reference integral_operators.py:178-179 /
+ * :382-383 - from one launch where the kernels allow (else two): gx_spec[b,i] = sum_o go[b,o] conj(w[i,o]) and
+ * gw[i,o] (+)= sum_b conj(xtrunc[b,i]) go[b,o]; `accumulate` adds into gw. */
+int uno_mode_backward(const float* xtrunc, const float* go, const float* const* w, float* gx_spec, float* const* gw, int B, int Ci,
+                      int Co, int ncorner, int modes_per_corner, int accumulate, void* stream);
 /* uno_mode_wgrad with accumulate != 0: gw[c] += (in-place accumulation into a parameter's gradient buffer). */
 int uno_mode_wgrad_acc(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
                        int modes_per_corner, int accumulate, void* stream);

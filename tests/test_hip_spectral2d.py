@@ -349,3 +349,32 @@ def test_default_modes_module_runs_like_the_reference():
     y_ref = so.spectral_conv2d_fft(x, conv.weights1.detach(), conv.weights2.detach(), 120, 120)
     y = conv.to(dev())(x.to(dev()))
     assert rel_err(y.detach().cpu().numpy(), y_ref.numpy()) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Ci,Co,m1,m2,acc", [(16, 256, 64, 18, 18, False), (16, 64, 128, 18, 18, True), (8, 32, 48, 6, 7, False), (3, 20, 12, 5, 4, True),
+                                               (16, 128, 256, 8, 8, False)])
+def test_paired_backward_gemms_equal_the_two_single_launches(B, Ci, Co, m1, m2, acc):
+    """uno_mode_backward (both per-mode GEMMs of a backward pass from one launch where the kernels allow, the autograd adjoints of the
+    einsum at reference integral_operators.py:178-179) against uno_mode_mix(op 1) + uno_mode_wgrad and against the float64 einsums."""
+    from uno_amd import _native
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + Ci + Co + m1)
+    xt = torch.randn(B, Ci, 2, m1 * m2, dtype=torch.complex64, generator=g).to(dev)
+    go = torch.randn(B, Co, 2, m1 * m2, dtype=torch.complex64, generator=g).to(dev)
+    ws = [torch.randn(Ci, Co, m1, m2, dtype=torch.complex64, generator=g).to(dev) for _ in range(2)]
+    base = [torch.randn(Ci, Co, m1, m2, dtype=torch.complex64, generator=g).to(dev) for _ in range(2)]
+    out = [b.clone() for b in base] if acc else None
+    gX, gws = _native.mode_backward(xt, go, ws, out=out, accumulate=acc)
+    gX1 = _native.mode_mix(go, ws, 1)
+    gw1 = _native.mode_wgrad(xt, go, tuple(ws[0].shape), 2)
+    assert torch.equal(gX.view_as(gX1), gX1)                       # the same kernel bodies: bit for bit
+    W = torch.stack([w.reshape(Ci, Co, -1) for w in ws], 2).to(torch.complex128)          # (Ci, Co, 2, M)
+    ref_gx = torch.einsum("bocm,iocm->bicm", go.to(torch.complex128), W.conj())
+    ref_gw = torch.einsum("bicm,bocm->iocm", xt.to(torch.complex128).conj(), go.to(torch.complex128))
+    assert float((gX.view(B, Ci, 2, -1).to(torch.complex128) - ref_gx).abs().max()) < 2e-5 * float(ref_gx.abs().max())
+    for c in range(2):
+        want = ref_gw[:, :, c].reshape(Ci, Co, m1, m2) + (base[c].to(torch.complex128) if acc else 0)
+        assert float((gws[c].to(torch.complex128) - want).abs().max()) < 2e-5 * float(want.abs().max())
+        if not acc:
+            assert torch.equal(gws[c], gw1[c])

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "uno_dft2d_inverse_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
     "uno_mode_mix": (C.c_int, [_fp, C.POINTER(_fp), _fp] + [_i] * 6 + [_fp]),
     "uno_mode_wgrad": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 5 + [_fp]),
+    "uno_mode_backward": (C.c_int, [_fp, _fp, C.POINTER(_fp), _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
     "uno_spectral_conv3d_fwd_ws_bytes": (C.c_longlong, [_i] * 8),
     "uno_spectral_conv3d_bwd_ws_bytes": (C.c_longlong, [_i] * 8),
     "uno_spectral_conv3d_forward": (C.c_int, [_fp, C.POINTER(_fp), _fp, _fp, _fp] + [_i] * 12 + [_fp]),
@@ -454,6 +455,35 @@ def mode_wgrad(xt, go, weight_shape, ncorner: int, out=None, accumulate: bool = 
         rc = lib().uno_mode_wgrad_acc(_ptr(xt), _ptr(go), _ptr_array(gws), B, Ci, Co, ncorner, Mc, 1 if accumulate else 0, _stream(xt))
     _check(rc, "uno_mode_wgrad")
     return gws
+
+
+def mode_backward(xt, go, weights, out=None, accumulate: bool = False):
+    """Both per-mode GEMMs of a backward pass in one launch (uno_mode_backward): xt (B, Ci, ncorner, modes) and go (B, Co, ncorner, modes)
+    c64 (any trailing shape with ncorner * modes entries per channel), weights: list of ncorner (Ci, Co, modes...) c64
+    -> (gX (B, Ci, ncorner * modes) c64, [gw per corner]); out / accumulate as in mode_wgrad."""
+    _require(xt, torch.complex64, "xtrunc")
+    _require(go, torch.complex64, "grad spectrum")
+    for w in weights:
+        _require(w, torch.complex64, "weights")
+    B, Ci = xt.shape[:2]
+    Co = go.shape[1]
+    nc = len(weights)
+    Mc = weights[0][0, 0].numel()
+    if out is None:
+        accumulate = False
+        gws = [torch.empty(weights[0].shape, dtype=torch.complex64, device=xt.device) for _ in range(nc)]
+    else:
+        gws = list(out)
+        for t in gws:
+            _require(t, torch.complex64, "weight-gradient buffer")
+            if tuple(t.shape) != tuple(weights[0].shape):
+                raise RuntimeError("uno_amd: weight-gradient buffer has the wrong shape")
+    gX = torch.empty((B, Ci, nc * Mc), dtype=torch.complex64, device=xt.device)
+    with torch.cuda.device(xt.device):
+        rc = lib().uno_mode_backward(_ptr(xt), _ptr(go), _ptr_array(list(weights)), _ptr(gX), _ptr_array(gws), B, Ci, Co, nc, Mc,
+                                     1 if accumulate else 0, _stream(xt))
+    _check(rc, "uno_mode_backward")
+    return gX, gws
 
 
 def spectral_conv3d_forward(x, ws_, Ho: int, Wo: int, To: int):

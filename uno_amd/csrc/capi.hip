@@ -145,15 +145,15 @@ static int dft2d(bool inverse, const float* in, float* out, int n_img, int H, in
 }
 
 // op 0: forward mix, op 1: grad wrt input spectrum, op 2: weight grad
-static int mode_gemm(int op, const float2* act, const float2* const* w, const float2* go, float2* out_act,
-                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s, int w_half = 0, int accumulate = 0) {
+// rc: 0 = launch p; 1 = nothing to launch (done); negative = error
+static int mode_gemm_params(ModeGemmParams& p, int op, const float2* act, const float2* const* w, const float2* go, float2* out_act,
+                            float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s, int w_half, int accumulate) {
     if (B < 0 || Ci < 1 || Co < 1 || nc < 1 || nc > 4 || Mc < 1) {
         set_error("mode gemm: bad sizes B=%d Ci=%d Co=%d corners=%d modes=%d", B, Ci, Co, nc, Mc);
         return -1;
     }
-    if (B == 0 && op != 2) return 0;
+    if (B == 0 && op != 2) return 1;
     const long long P = (long long)nc * Mc;
-    ModeGemmParams p;
     p.ncorner = nc; p.Mc = Mc; p.accumulate = (op == 2 && accumulate) ? 1 : 0;
     p.A.half = 0; p.B.half = (op != 2 && w_half) ? 1 : 0;
     for (int c = 0; c < 4; ++c) { p.A.base[c] = nullptr; p.B.base[c] = nullptr; p.out[c] = nullptr; }
@@ -176,13 +176,35 @@ static int mode_gemm(int op, const float2* act, const float2* const* w, const fl
         p.o_sm = (long long)Co * Mc; p.o_sn = Mc;
         for (int c = 0; c < nc; ++c) { p.A.base[c] = act + (long long)c * Mc; p.B.base[c] = go + (long long)c * Mc; p.out[c] = out_w[c]; }
         if (B == 0) {
-            if (accumulate) return 0;
+            if (accumulate) return 1;
             for (int c = 0; c < nc; ++c)
                 if (hipMemsetAsync(out_w[c], 0, sizeof(float2) * (size_t)Ci * Co * Mc, s) != hipSuccess) { set_error("memset failed"); return -5; }
-            return 0;
+            return 1;
         }
     }
+    return 0;
+}
+
+static int mode_gemm(int op, const float2* act, const float2* const* w, const float2* go, float2* out_act,
+                     float2* const* out_w, int B, int Ci, int Co, int nc, int Mc, hipStream_t s, int w_half = 0, int accumulate = 0) {
+    ModeGemmParams p;
+    const int rc = mode_gemm_params(p, op, act, w, go, out_act, out_w, B, Ci, Co, nc, Mc, s, w_half, accumulate);
+    if (rc != 0) return rc < 0 ? rc : 0;
     return launch_mode_gemm(p, s);
+}
+
+// both GEMMs of a backward pass: gX = gO conj(W) (op 1) and gW (+)= conj(X) gO (op 2), one launch where the kernels allow
+static int mode_backward(const float2* xtrunc, const float2* go, const float2* const* w, float2* gx_spec, float2* const* gw, int B, int Ci,
+                         int Co, int nc, int Mc, hipStream_t s, int accumulate) {
+    ModeGemmParams pa, pb;
+    const int ra = mode_gemm_params(pa, 1, go, w, nullptr, gx_spec, nullptr, B, Ci, Co, nc, Mc, s, 0, 0);
+    if (ra < 0) return ra;
+    const int rb = mode_gemm_params(pb, 2, xtrunc, nullptr, go, nullptr, gw, B, Ci, Co, nc, Mc, s, 0, accumulate);
+    if (rb < 0) return rb;
+    if (ra == 0 && rb == 0) return launch_mode_gemm_pair(pa, pb, s);
+    if (rb == 0) if (int rc = launch_mode_gemm(pb, s)) return rc;
+    if (ra == 0) return launch_mode_gemm(pa, s);
+    return 0;
 }
 
 static int g_reserved_cus = 0;
@@ -407,6 +429,17 @@ static int mode_wgrad_impl(const float* xtrunc, const float* go, float* const* g
 int uno_mode_wgrad(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
                    int modes_per_corner, void* stream) {
     return mode_wgrad_impl(xtrunc, go, gw, B, Ci, Co, ncorner, modes_per_corner, 0, stream);
+}
+
+int uno_mode_backward(const float* xtrunc, const float* go, const float* const* w, float* gx_spec, float* const* gw, int B, int Ci, int Co,
+                      int ncorner, int modes_per_corner, int accumulate, void* stream) {
+    if (!w || !gw || (B > 0 && (!xtrunc || !go || !gx_spec))) { set_error("uno_mode_backward: null pointer"); return -1; }
+    if (ncorner < 1 || ncorner > 4) { set_error("uno_mode_backward: ncorner=%d out of range", ncorner); return -1; }
+    for (int c = 0; c < ncorner; ++c)
+        if (!w[c] || !gw[c]) { set_error("uno_mode_backward: null weight / gradient pointer %d", c); return -1; }
+    return mode_backward(reinterpret_cast<const float2*>(xtrunc), reinterpret_cast<const float2*>(go), reinterpret_cast<const float2* const*>(w),
+                         reinterpret_cast<float2*>(gx_spec), reinterpret_cast<float2* const*>(gw), B, Ci, Co, ncorner, modes_per_corner,
+                         (hipStream_t)stream, accumulate);
 }
 
 int uno_mode_wgrad_acc(const float* xtrunc, const float* go, float* const* gw, int B, int Ci, int Co, int ncorner,
@@ -1078,6 +1111,8 @@ int uno_spectral_conv3d_backward(const float* gy, const float* xtrunc, const flo
     // The weight gradient stays on the caller's stream (measured round 3, one box, A/B: on the side stream next to the
     // input-gradient GEMM and the inverse transform - the 2-D arrangement - the C4 block backward took 127 us against 119.5 us
     // in sequence: at 4 corners of weights the two per-mode GEMMs are each bound by the same weight / spectrum streams)
+    // (round 6, measured and not adopted here: both GEMMs in one launch - uno_mode_backward, what the 2-D layers use - took 48.0 us at the
+    // C4 block against 24.5 + 21.0 in sequence: with four corners of weights each role fills the chip on its own)
     if (gw)
         if (int rc = uno_mode_wgrad(xtrunc, gO, gw, B, Ci, Co, 4, (int)Mc, stream)) return rc;
     if (gx) {
@@ -1139,6 +1174,14 @@ static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const 
     if (int rc = dft2d(false, gy, gO, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s, 0, 0, 0, bf16)) return rc;
     // The weight gradient only shares gO with the input-gradient chain: it runs on the side stream next to the
     // (under-filled) input-gradient GEMM and the store-bound inverse DFT.
+    if (gw1 && gx && !w_half) {
+        // round 6: both per-mode GEMMs in ONE launch (they share gO; each alone under-fills the chip), then the inverse transform.
+        // (Rounds 2-5 ran the weight gradient on a side stream beside the input-gradient GEMM and the inverse transform.)
+        const float* wv[2] = {w1, w2};
+        float* gwv[2] = {gw1, gw2};
+        if (int rc = uno_mode_backward(xtrunc, gO, wv, gX, gwv, B, Ci, Co, 2, m1 * m2, accumulate_gw, stream)) return rc;
+        return dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s, 0, 0, 0, bf16);
+    }
     SideStream* side = (gw1 && gx) ? side_stream_of_current_device() : nullptr;
     int rc_w = 0;
     if (gw1) {

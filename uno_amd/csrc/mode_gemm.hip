@@ -244,8 +244,7 @@ __device__ __forceinline__ float lane_pull(int src_lane_x4, float v) {
 // 27.2 -> 20.8 us, input gradient 28.2 -> 22.8, weight gradient 23.3 -> 19.9; Uno3D_T20 (width 32) layer 1 65 -> 57 / 65 -> 59 / 71 -> 62,
 // layer 2 81 -> 75 / 83 -> 69 - and loses everywhere else (C2 block 17 -> 26, 256 x 256 channels at 64 modes weight gradient 25 -> 76).
 template <int MTW, int NTW, int K2B_PF, bool BH, bool ACC = false>
-__global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p, int KS, int ngw, int per_group, int adjacent_modes) {
-    extern __shared__ __attribute__((aligned(16))) float smb[];
+__device__ __forceinline__ void mode_gemm_blocks_body(const ModeGemmParams& p, int KS, int ngw, int per_group, int adjacent_modes, int bid, float* smb) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 2, x = lane & 3;                          // MFMA layout: block (mode) q, row / column x
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
     // column groups) or the same B rows (all row groups): keep a mode group on ONE XCD, so that its operands come out of that
     // XCD's L2 instead of being fetched over the fabric once per workgroup.
     const int nq = (p.Mc + 15) >> 4;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     int grp = (slot / per_group) * 8 + xcd;                                        // mode group (adjacent_modes: group of 4 / KS)
     const int within = slot % per_group;                                           // (column-group workgroup, row group) inside it
     if (adjacent_modes) grp = (4 / KS) * grp + wave / KS;
@@ -419,6 +418,25 @@ __global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p,
     }
 }
 
+template <int MTW, int NTW, int K2B_PF, bool BH, bool ACC = false>
+__global__ __launch_bounds__(256) void mode_gemm_blocks_kernel(ModeGemmParams p, int KS, int ngw, int per_group, int adjacent_modes) {
+    extern __shared__ __attribute__((aligned(16))) float smb[];
+    mode_gemm_blocks_body<MTW, NTW, K2B_PF, BH, ACC>(p, KS, ngw, per_group, adjacent_modes, (int)blockIdx.x, smb);
+}
+
+// The two GEMMs of a backward pass in ONE launch (reference: the autograd adjoints of integral_operators.py:178-179): workgroups
+// [0, Ga) run the input-gradient role gX[b,i] = sum_o gO[b,o] conj(W[i,o]), the rest the weight-gradient role gW[i,o] = sum_b conj(X[b,i])
+// gO[b,o].  Each role alone fills a fraction of the chip (1.3 - 2.4 TB/s in the training step, profiles/r05_step_launches.txt) and its
+// launch ends in a tail of a few workgroups; together they share the read-only gO out of the same XCD's L2 (a mode group lands on the
+// same XCD in both roles) and one launch's ramp and tail.  The bodies are the single-role kernel's, unchanged.
+struct BlocksCfg { int KS, ngw, per_group, adjacent; };
+template <int MA, int NA, int PFA, bool ACCB>
+__global__ __launch_bounds__(256) void mode_gemm_blocks_pair_kernel(ModeGemmParams pa, BlocksCfg ca, int Ga, ModeGemmParams pb, BlocksCfg cb) {
+    extern __shared__ __attribute__((aligned(16))) float smb[];
+    if ((int)blockIdx.x < Ga) mode_gemm_blocks_body<MA, NA, PFA, false, false>(pa, ca.KS, ca.ngw, ca.per_group, ca.adjacent, (int)blockIdx.x, smb);
+    else mode_gemm_blocks_body<4, 4, 2, false, ACCB>(pb, cb.KS, cb.ngw, cb.per_group, cb.adjacent, (int)blockIdx.x - Ga, smb);
+}
+
 template <int MTW, int NTW, int PF>
 static void launch_blocks_t(const ModeGemmParams& p, int KS, int adjacent_modes, hipStream_t s) {
 #ifdef UNO_K2_DEV
@@ -447,6 +465,82 @@ static void launch_blocks_t(const ModeGemmParams& p, int KS, int adjacent_modes,
 static size_t mode_gemm_lds(int qc, bool pipe) {
     const size_t sb = (size_t)2 * 2 * qc * (KC * 16 + 64 / qc), out = (size_t)16 * 16 * (qc + 1) * 2;
     return std::max((pipe ? 2 : 1) * sb, out) * sizeof(float);
+}
+
+// what launch_mode_gemm decides for the 4x4x1 form (its comments there): not used when the last mode group is mostly padding or the
+// output of a short-K call is huge; variant 0: <4,4,2> (short K: the weight gradient), 1: <4,2,4> (more than 8 rows), 2: <2,4,4>
+struct BlocksPlan { bool use; int variant, KS, adjacent; };
+static BlocksPlan blocks_plan(const ModeGemmParams& p) {
+    const int groups = (p.Mc + 15) / 16;
+    const bool padded = 16 * groups * 5 > p.Mc * 6;
+    const bool short_k = p.K <= 32 && p.M >= 16 && p.N >= 16;
+    const bool huge_out = short_k && 8.0 * p.M * p.N * p.Mc * p.ncorner > 200e6;
+    if (padded || huge_out) return BlocksPlan{false, 0, 1, 0};
+    const bool wide_m = p.M > 8;
+    const int tm = wide_m ? 16 : 8, tn = wide_m ? 8 : 16;
+    const long long tiles_per_group = (long long)((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn);
+    const long long tasks = (long long)p.ncorner * groups * tiles_per_group;
+    const bool adjacent = groups >= 48 && (long long)((p.ncorner * groups + 3) / 4) * tiles_per_group >= 200;
+    const int KS = (short_k || adjacent) ? 1 : (tasks < 1024 && p.K >= 32) ? 4 : (tasks < 2048 && p.K >= 16) ? 2 : 1;
+    return BlocksPlan{true, short_k ? 0 : wide_m ? 1 : 2, KS, adjacent ? 1 : 0};
+}
+struct BlocksGrid { BlocksCfg cfg; int grid; size_t lds; };
+static BlocksGrid blocks_grid(const ModeGemmParams& p, int MTW, int NTW, int KS, int adjacent_modes) {
+    const int nq = (p.Mc + 15) / 16;
+    const int ngroups = (p.N + 4 * NTW - 1) / (4 * NTW), mgroups = (p.M + 4 * MTW - 1) / (4 * MTW);
+    const int per_wg = adjacent_modes ? 1 : 4 / KS;
+    const int ngw = (ngroups + per_wg - 1) / per_wg, per_group = ngw * mgroups;
+    const int sub = 4 / KS;
+    const int wg_groups = adjacent_modes ? (p.ncorner * nq + sub - 1) / sub : p.ncorner * nq;
+    return BlocksGrid{BlocksCfg{KS, ngw, per_group, adjacent_modes}, ((wg_groups + 7) / 8) * 8 * per_group,
+                      KS > 1 ? (size_t)4 * MTW * NTW * 8 * 64 * sizeof(float) : 0};
+}
+
+static int mode_gemm_operands_ok(const ModeGemmParams& p) {
+    if (p.ncorner < 1 || p.ncorner > 4 || p.Mc < 1 || p.M < 1 || p.N < 1 || p.K < 1) {
+        set_error("mode_gemm: bad sizes M=%d N=%d K=%d corners=%d modes=%d", p.M, p.N, p.K, p.ncorner, p.Mc);
+        return -2;
+    }
+    const long long spanA = ((long long)(p.M - 1) * p.A.s0 + (long long)(p.K - 1) * p.A.s1 + p.Mc) * 8;
+    const long long spanB = ((long long)(p.N - 1) * p.B.s1 + (long long)(p.K - 1) * p.B.s0 + p.Mc) * 8;
+    if (spanA >= (1LL << 31) || spanB >= (1LL << 31)) { set_error("mode_gemm: an operand spans %lld bytes per corner (limit 2 GiB)", spanA > spanB ? spanA : spanB); return -2; }
+    return 0;
+}
+
+int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
+
+// pa: the input-gradient GEMM, pb: the weight-gradient GEMM of one backward pass (complex64 operands).  One launch where both take the
+// 4x4x1 form in the expected variants, else the two launches.
+int launch_mode_gemm_pair(const ModeGemmParams& pa, const ModeGemmParams& pb, hipStream_t s) {
+    if (int rc = mode_gemm_operands_ok(pa)) return rc;
+    if (int rc = mode_gemm_operands_ok(pb)) return rc;
+    const BlocksPlan A = blocks_plan(pa), Bp = blocks_plan(pb);
+    if (!A.use || !Bp.use || A.variant == 0 || Bp.variant != 0 || pa.B.half || pb.B.half || pa.accumulate) {
+        if (int rc = launch_mode_gemm(pb, s)) return rc;
+        return launch_mode_gemm(pa, s);
+    }
+    const BlocksGrid ga = A.variant == 1 ? blocks_grid(pa, 4, 2, A.KS, A.adjacent) : blocks_grid(pa, 2, 4, A.KS, A.adjacent);
+    const BlocksGrid gb = blocks_grid(pb, 4, 4, Bp.KS, Bp.adjacent);
+    const size_t lds = std::max(ga.lds, gb.lds);
+    const double bytes_a = (8.0 * ((double)pa.M * pa.K + (double)pa.M * pa.N) + 8.0 * (double)pa.K * pa.N) * pa.ncorner * pa.Mc;
+    const double bytes_b = (8.0 * ((double)pb.M * pb.K + (double)pb.M * pb.N) + 8.0 * (double)pb.K * pb.N) * pb.ncorner * pb.Mc;
+    char name[80];
+    snprintf(name, sizeof(name), "uno::mode_gemm_blocks_pair_kernel<%s, %s>", A.variant == 1 ? "4, 2, 4" : "2, 4, 4", pb.accumulate ? "true" : "false");
+    ProfScope prof(name, bytes_a + bytes_b - 8.0 * (double)pb.K * pb.N * pb.ncorner * pb.Mc, s);       // (gO counted once)
+    const dim3 grid(ga.grid + gb.grid);
+    static int lds_slot[4][64];
+#define UNO_PAIR(MA, NA, ACCB, SLOT)                                                                                              \
+    do {                                                                                                                            \
+        auto k = mode_gemm_blocks_pair_kernel<MA, NA, 4, ACCB>;                                                                     \
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_slot[SLOT]);                                                  \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, pa, ga.cfg, ga.grid, pb, gb.cfg);                                            \
+    } while (0)
+    if (A.variant == 1) { if (pb.accumulate) UNO_PAIR(4, 2, true, 0); else UNO_PAIR(4, 2, false, 1); }
+    else { if (pb.accumulate) UNO_PAIR(2, 4, true, 2); else UNO_PAIR(2, 4, false, 3); }
+#undef UNO_PAIR
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mode_gemm pair launch: %s", hipGetErrorString(e)); return -5; }
+    return 0;
 }
 
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s) {

@@ -287,6 +287,7 @@ bool vol3d_inv_applies(int n_vol, int D1, int D2, int D3, int m1, int m2, int m3
 int launch_dft3d_fwd_volume(const Vol3dParams& p, hipStream_t s);
 int launch_dft3d_inv_volume(const Vol3dParams& p, hipStream_t s);
 int launch_mode_gemm(const ModeGemmParams& p, hipStream_t s);
+int launch_mode_gemm_pair(const ModeGemmParams& input_grad, const ModeGemmParams& weight_grad, hipStream_t s);      // both GEMMs of a backward pass, one launch where possible
 int launch_cdft(const CdftParams& p, bool inverse, hipStream_t s);
 int launch_dft2d_generic(const Dft2dParams& p, bool inverse, void* ws, size_t ws_bytes, hipStream_t s);      // dft_generic.hip: any mode count; ws: 8 n_img H m2 bytes
 int launch_cdft_generic(const CdftParams& p, bool inverse, hipStream_t s);

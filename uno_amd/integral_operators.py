@@ -588,18 +588,25 @@ def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, 
     # other consumer are added to this layer's before ONE inverse transform
     gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True, out=gslot)
     gw1 = gw2 = None
+    gX = None
     if gslot is not None:
         gw1, gw2 = _stack_arrived(stack[0], stack[1], leaves, w1.shape, both_gw)
     elif need_gw:
         tg = _grad_targets(leaves) if both_gw else None
         _note_use(leaves[0])
-        gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
-                                      accumulate=bool(tg and tg[0][1]))
+        if need_gx and w1.dtype == torch.complex64:
+            # both per-mode GEMMs of the pass from one launch (uno_mode_backward)
+            gX, (gw1, gw2) = _native.mode_backward(xt, gO, [w1, w2], out=[tg[0][0], tg[1][0]] if tg else None, accumulate=bool(tg and tg[0][1]))
+            gX = gX.view(B, Ci, 2 * m1, m2)
+        else:
+            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
+                                          accumulate=bool(tg and tg[0][1]))
         if tg:
             gw1, gw2 = tg[0][2], tg[1][2]
     gx = None
     if need_gx:
-        gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
+        if gX is None:
+            gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
         if merging:
             gX = join.merge(gX, (H, W))
         # addend: the (adjoint-)resampled point-wise contribution joins the transform's result before the tile is written
@@ -1343,20 +1350,25 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         both_gw = ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
         gslot = _stack_grad_slot(ctx.stack[0], ctx.stack[1], Co) if (ctx.stack is not None and need_gw) else None
         gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True, out=gslot)             # c (.) keep (.) DFT_trunc(gs)
-        gw1 = gw2 = None
+        gw1 = gw2 = gXp = None
         if gslot is not None:
             gw1, gw2 = _stack_arrived(ctx.stack[0], ctx.stack[1], (lw1, lw2), w1.shape, both_gw)
         elif need_gw:
             _note_use(lw1)
             tg = _grad_targets((lw1, lw2)) if both_gw else None
-            gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
-                                          accumulate=bool(tg and tg[0][1]))
+            if (need1 or need2) and w1.dtype == torch.complex64:
+                gXp, (gw1, gw2) = _native.mode_backward(xt, gO, [w1, w2], out=[tg[0][0], tg[1][0]] if tg else None,
+                                                        accumulate=bool(tg and tg[0][1]))
+                gXp = gXp.view(B, Ci, 2 * m1, m2)
+            else:
+                gw1, gw2 = _native.mode_wgrad(xt, gO, tuple(w1.shape[:4]), 2, out=[tg[0][0], tg[1][0]] if tg else None,
+                                              accumulate=bool(tg and tg[0][1]))
             if tg:
                 gw1, gw2 = tg[0][2], tg[1][2]
         gx1 = gx2 = None
         defer = ctx.defer if (need2 and ctx.defer is not None and ctx.defer.owner) else None    # owner's backward still to come
         if need1 or need2:
-            gX = _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
+            gX = gXp if gXp is not None else _native.mode_mix(gO.view(B, Co, 2, m1 * m2), [w1, w2], 1).view(B, Ci, 2 * m1, m2)
             if need1:
                 gx1 = _native.dft2d_inverse(gX, H, W, 1.0 / (H * W), False, False, channels=C1, channel_offset=0, dtype=gs.dtype)
             if defer is not None:
