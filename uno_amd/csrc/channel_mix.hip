@@ -502,8 +502,11 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
 // pixel tiles only; the last (partial) pixel tile of a row runs the guarded 64-channel path twice.
 constexpr int CMW_WS = 128 + 16;
 
-template <bool BF>
-__global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixParams p) {
+// GEN (round 6): the same tile on a pixel WINDOW (ChannelMixParams::pm), with the two 64-channel halves of the tile going to two
+// destinations (Co1 = 64 mod 128) and the gelu' epilogue on the first destination - the two input gradients of fc1 from ONE staging of
+// the output gradient (the generic kernel ran the 128 outputs as two 64-channel tiles, each staging grad_y again: 808 us for 2.9 GB).
+template <bool BF, bool GEN = false>
+__global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(ChannelMixParams p) {
     using T = typename IoElem<BF>::type;
     constexpr int PT = CM_PT, XS = PT + 16, NM = PT / 16;
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * XS];
@@ -513,6 +516,12 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = blockIdx.y;
     if (p0 + PT > p.P || (p.Ci & (CM_KC - 1)) != 0) {
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(&sW[0][0]);
+        if constexpr (GEN) {
+            if (p.dgelu_of) channel_mix_tile<1, PT, false, true, BF>(p, sX, sWn, p0, o0, b); else channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0, b);
+            __syncthreads();
+            if (p.dgelu_of) channel_mix_tile<1, PT, false, true, BF>(p, sX, sWn, p0, o0 + 64, b); else channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0 + 64, b);
+            return;
+        }
         channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0, b);
         __syncthreads();
         channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0 + 64, b);
@@ -521,8 +530,10 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C1 = p.C1;
-    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * p.P;
-    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * p.P : xb;
+    const int PS = GEN ? p.pm.PS : p.P;                 // elements between two channel planes
+    const PixRun run = GEN ? pix_run(p.pm, p0) : PixRun{0, 0x7fffffff, 0};
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)b * C1 * PS;
+    const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (size_t)b * (p.Ci - C1) * PS : xb;
     const bool tr = p.w_so == 1 && p.w_si != 1;
 
     float4 rx[2], rw[2];
@@ -532,7 +543,8 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
-            rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
+            if constexpr (GEN) rx[u] = io_ld4(cb + (size_t)(kb + (e >> 5)) * PS + run(p0 + (e & 31) * 4));
+            else rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
             const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + 64 * u + (tid & 15) * 4)
                                      : (unsigned)((o0 + 64 * u + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
             const f4u wv = *reinterpret_cast<const f4u*>(p.w + woff);
@@ -583,12 +595,15 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
     constexpr int OS = PT + 16;
     float* sO = &sX[0][0] + wave * (8 * OS);
     const int c4 = (lane & 31) * 4;
-    const CmDest<T> dd = cm_dest<T>(p, o0, b);          // a 128-channel tile lies in one destination (Co1 % 128 == 0)
-    T* const aall = p.y_act ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
+    const CmDest<T> dd0 = cm_dest<T>(p, o0, b);         // a 128-channel tile lies in one destination (Co1 % 128 == 0) - GEN: one per half
+    T* const aall = (!GEN && p.y_act) ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
+    const int poff = GEN ? run(p0 + c4) : p0 + c4;      // this lane's four pixels inside a plane
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int ob = o0 + 64 * g + 16 * wave;
         const float bias_l = p.bias ? p.bias[ob + r16] : 0.f;
+        const CmDest<T> dd = GEN ? cm_dest<T>(p, o0 + 64 * g, b) : dd0;
+        const T* const dall = (GEN && p.dgelu_of && o0 + 64 * g < p.Co1) ? reinterpret_cast<const T*>(p.dgelu_of) + (size_t)b * p.Co1 * PS : nullptr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if ((r16 >> 3) == h) {
@@ -598,23 +613,29 @@ __global__ __launch_bounds__(256, 4) void channel_mix_wide_kernel(ChannelMixPara
                         make_float4(acc[g][mt][0], acc[g][mt][1], acc[g][mt][2], acc[g][mt][3]);
             }
             __syncthreads();
-            float4 old[4];
+            float4 old[4], dgv[4];
             T* dst[4];
             size_t aoff[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int o = ob + 8 * h + 2 * it + (lane >> 5);
-                dst[it] = dd.base + (size_t)(o - dd.ob) * p.P + p0 + c4;
+                dst[it] = dd.base + (size_t)(o - dd.ob) * PS + poff;
                 aoff[it] = (size_t)o * p.P + p0 + c4;
                 if (p.accumulate) old[it] = io_ld4(dst[it]);
                 else old[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (GEN) { if (dall) dgv[it] = io_ld4(dall + (size_t)o * PS + poff); }
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = 2 * it + (lane >> 5);
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
                 const float bv = __shfl(bias_l, 8 * h + row);
-                const float w0 = old[it].x + (v.x + bv), w1 = old[it].y + (v.y + bv), w2 = old[it].z + (v.z + bv), w3 = old[it].w + (v.w + bv);
+                float t0 = v.x + bv, t1 = v.y + bv, t2 = v.z + bv, t3 = v.w + bv;
+                if constexpr (GEN) {
+                    // as the generic kernel's epilogue: the PRODUCT is multiplied by gelu'(dgelu_of), then added to the old value
+                    if (dall) { t0 *= cm_dgelu(dgv[it].x); t1 *= cm_dgelu(dgv[it].y); t2 *= cm_dgelu(dgv[it].z); t3 *= cm_dgelu(dgv[it].w); }
+                }
+                const float w0 = old[it].x + t0, w1 = old[it].y + t1, w2 = old[it].z + t2, w3 = old[it].w + t3;
                 io_store4(dst[it], w0, w1, w2, w3);
                 if (aall) io_store4(aall + aoff[it], cm_gelu(w0), cm_gelu(w1), cm_gelu(w2), cm_gelu(w3));
             }
@@ -1150,6 +1171,9 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     if (act_in && dgelu_of) { set_error("channel_mix: act_in and dgelu_of are exclusive"); return -2; }
     if (vh == 2) p.dgelu_of = a.vh_x;             // (non-null marks the gelu' epilogue; never read)
     const bool wide = !vh && Co % 128 == 0 && P >= PT && !act_in && !dgelu_of && (!two_dst || p.Co1 % 128 == 0) && !windowed && !act_pad;      // (the wide and few-input kernels are dense only)
+    // the general wide form (round 6): windows, the gelu' epilogue on the first destination, destinations split at 64 mod 128 channels
+    const bool wide_gen = !wide && !vh && !bf16 && Co % 128 == 0 && P >= PT && !act_in && !act_pad && !a.gmul && !a.proj_w && !a.y_act && a.y &&
+                          a.accumulate != 2 && (!two_dst || p.Co1 % 64 == 0) && Ci % CM_KC == 0 && Ci < 128;
     // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
 #ifdef UNO_CMS_DEV        // development build only (tools/dev/mkvariant.py): A/B switch, knock-outs, stamp buffer from the environment
     static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;
@@ -1183,7 +1207,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         return -2;
     }
     if (a.y_act && (two_dst || dgelu_of)) { set_error("channel_mix: the activated second output goes with a single destination and no dgelu_of"); return -2; }
-    const long long npt = (P + PT - 1) / PT, ncot = (split || (wide && !split64)) ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
+    const long long npt = (P + PT - 1) / PT, ncot = (split || ((wide || wide_gen) && !split64)) ? Co / 128 : (Co + CM_MT - 1) / CM_MT;
     if ((long long)Ci * PSl >= (1LL << 30) || (long long)Ci * Co >= (1LL << 30) || npt * ncot > 0x7fffffffLL || B > 65535) {
         set_error("channel_mix: tensor too large (Ci * pixels and Ci * Co must stay below 2^30)");
         return -2;
@@ -1203,7 +1227,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     }
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
-        ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : wide ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
+        ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : (wide || wide_gen) ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
                        (bf16 ? 2.0 : 4.0) * B * (double)P * ((vh == 1 ? a.vh_ci : Ci) + (vh == 2 ? a.vh_ci : 0) + (a.y ? Co : 0) + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.gmul ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
         if (split64 || split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
@@ -1235,6 +1259,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         }
         else if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else if (wide_gen) hipLaunchKernelGGL((channel_mix_wide_kernel<false, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
 #define UNO_CM_LAUNCH(T, BF) \
