@@ -493,6 +493,20 @@ def extra_workloads(dev):
         return {"config": f"C5 model: UNO_9(3,64,pad=5) at 1024^2 (padded 1089^2), batch {B}, f32", "ms_per_step": ms,
                 "samples_per_s": B / ms * 1e3, "peak_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
+    def darcy_graphed():
+        """The headline step (same model, data, loss, optimiser arithmetic) replayed from ONE HIP graph (harness.GraphedStep, single rank):
+        what the launch gaps of the eager step cost.  Informational: the headline stays the eager data-parallel step."""
+        from uno_amd.harness import lp_loss_rel_sum
+        torch.manual_seed(0)
+        model = UNO_9(3, WIDTH, pad=PAD).to(dev)
+        a, u = synthetic_darcy_batch(BATCH, S, 1234, dev)
+        opt = ComplexAdam(model.parameters(), lr=1e-3, weight_decay=1e-3, capturable=True)
+        gs = GraphedStep(model, opt, lambda a_, u_: lp_loss_rel_sum(model(a_).reshape(BATCH, -1), u_.reshape(BATCH, -1)), (a, u))
+        ms = _train_ms(lambda: gs.step(a, u), dev, steps=10, warmup=3)
+        return {"config": f"UNO_9(3,{WIDTH},pad={PAD}) {S}^2 batch {BATCH}: forward + loss + backward + Adam replayed from one HIP graph (single rank)",
+                "ms_per_step": ms, "samples_per_s": BATCH / ms * 1e3}
+
+    guarded("darcy_graphed_step", darcy_graphed)
     guarded("gpu_stock", lambda: gpu_stock_baseline(dev))
     guarded("darcy_reference_style_caller", ref_style)
     guarded("c3_ns2d", ns2d)

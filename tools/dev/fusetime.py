@@ -64,3 +64,19 @@ for rnd in range(3):
         res[fuse].append((time.perf_counter() - t0) / steps * 1e3)
         print(f"round {rnd} fuse={fuse}: {res[fuse][-1]:.3f} ms/step loss {float(loss):.6f}", flush=True)
 print("fused", min(res[True]), "two-kernel", min(res[False]))
+io.FUSE_UPSAMPLE_ADD = True
+res = {True: [], False: []}
+for rnd in range(3):
+    for pair in (True, False):
+        io.PAIR_BACKWARD_GEMMS = pair
+        for _ in range(3):
+            tr.step(a, u)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(a, u)
+        torch.cuda.synchronize()
+        res[pair].append((time.perf_counter() - t0) / steps * 1e3)
+        print(f"round {rnd} pair_backward_gemms={pair}: {res[pair][-1]:.3f} ms/step", flush=True)
+io.PAIR_BACKWARD_GEMMS = True
+print("paired", min(res[True]), "composite with side stream", min(res[False]))

@@ -1174,14 +1174,8 @@ static int spectral_conv2d_backward(const float* gy, const float* xtrunc, const 
     if (int rc = dft2d(false, gy, gO, B * Co, Ho, Wo, m1, m2, 1.0f, 1, 1, s, 0, 0, 0, bf16)) return rc;
     // The weight gradient only shares gO with the input-gradient chain: it runs on the side stream next to the
     // (under-filled) input-gradient GEMM and the store-bound inverse DFT.
-    if (gw1 && gx && !w_half) {
-        // round 6: both per-mode GEMMs in ONE launch (they share gO; each alone under-fills the chip), then the inverse transform.
-        // (Rounds 2-5 ran the weight gradient on a side stream beside the input-gradient GEMM and the inverse transform.)
-        const float* wv[2] = {w1, w2};
-        float* gwv[2] = {gw1, gw2};
-        if (int rc = uno_mode_backward(xtrunc, gO, wv, gX, gwv, B, Ci, Co, 2, m1 * m2, accumulate_gw, stream)) return rc;
-        return dft2d(true, gX, gx, B * Ci, H, W, m1, m2, 1.0f / ((float)H * (float)W), 0, 0, s, 0, 0, 0, bf16);
-    }
+    // (round 6, measured and not adopted HERE: both per-mode GEMMs in one launch - uno_mode_backward, what the stage-by-stage callers use -
+    // took the C2 block backward from 352-355 to 361 us: this composite already hides the weight gradient behind the inverse transform)
     SideStream* side = (gw1 && gx) ? side_stream_of_current_device() : nullptr;
     int rc_w = 0;
     if (gw1) {

@@ -547,6 +547,10 @@ def _stack_wanted(ctx, iw, x, half_weights):
 # the point-wise branch in the registers it holds its own result in, before the output tile is written (uno_dft2d_inverse_add), instead
 # of K3 writing the block output and the accumulating resampling kernel reading and re-writing it.  False: the two-kernel form (A/B).
 FUSE_UPSAMPLE_ADD = True
+# Layers whose backward could take the composite entry point (no join, no stack, no addend): True - stage by stage with both per-mode
+# GEMMs in ONE launch (uno_mode_backward); False - uno_spectral_conv2d_backward, which runs the weight-gradient GEMM on a side stream
+# beside the input-gradient GEMM and the inverse transform (A/B switch; tools/dev/fusetime.py)
+PAIR_BACKWARD_GEMMS = True
 
 
 def _fused_addend(t, H, W, m1, m2, adjoint):
@@ -574,7 +578,7 @@ def _spectral_backward(gs, xt, w1, w2, H, W, need_gx, need_gw, both_gw, leaves, 
     merging = join is not None and need_gx and bool(join.spectra)
     if addend is not None and not need_gx:
         raise RuntimeError("uno_amd: an addend for the input gradient needs the input gradient")
-    if gslot is None and not merging and addend is None:
+    if gslot is None and not merging and addend is None and not (PAIR_BACKWARD_GEMMS and need_gx and need_gw and w1.dtype == torch.complex64):
         tg = _grad_targets(leaves) if (need_gw and both_gw) else None
         if need_gw:
             _note_use(leaves[0])
