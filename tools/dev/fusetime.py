@@ -80,3 +80,18 @@ for rnd in range(3):
         print(f"round {rnd} pair_backward_gemms={pair}: {res[pair][-1]:.3f} ms/step", flush=True)
 io.PAIR_BACKWARD_GEMMS = True
 print("paired", min(res[True]), "composite with side stream", min(res[False]))
+res = {True: [], False: []}
+for rnd in range(3):
+    for rv in (True, False):
+        io.REVERSE_SWEEP_RESAMPLE = rv
+        for _ in range(3):
+            tr.step(a, u)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(a, u)
+        torch.cuda.synchronize()
+        res[rv].append((time.perf_counter() - t0) / steps * 1e3)
+        print(f"round {rnd} reverse_sweep_resample={rv}: {res[rv][-1]:.3f} ms/step", flush=True)
+io.REVERSE_SWEEP_RESAMPLE = True
+print("reverse sweep before K1", min(res[True]), "after the spectral branch", min(res[False]))

@@ -536,10 +536,11 @@ def spectral_conv3d_backward(gy, xt, ws_, H: int, W: int, T: int, need_gx=True, 
     return gx, gws
 
 
-def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
+def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None, reverse: bool = False):
     """x (..., H, W) f32 -> (..., Ho, Wo); tabX = (start int32 [out], weights f32 [out, K]) band tables on x.device;
     tilesH = (p0 int32 [ntiles], dense weights f32 [ntiles, NP, 16]) enables the fused single-pass kernel.
-    out: accumulate into this (..., Ho, Wo) tensor instead of allocating the result."""
+    out: accumulate into this (..., Ho, Wo) tensor instead of allocating the result.
+    reverse: walk the images in descending order (same result; see csrc/resample2d.hip)."""
     bf16 = _act_dtype(x, "x")
     *lead, H, W = x.shape
     n = 1
@@ -563,7 +564,7 @@ def resample2d(x, Ho: int, Wo: int, tabH, tabW, tilesH=None, out=None):
             targs = (C.c_void_p(0), C.c_void_p(0), 0)
         fn = lib().uno_resample2d_bf16 if bf16 else lib().uno_resample2d
         rc = fn(_ptr(x), _ptr(out), _ptr(tmp), n, H, W, Ho, Wo, _ptr(sH), _ptr(wH), wH.shape[1],
-                _ptr(sW), _ptr(wW), wW.shape[1], *targs, 1 if accumulate else 0, _stream(x))
+                _ptr(sW), _ptr(wW), wW.shape[1], *targs, (1 if accumulate else 0) | (2 if reverse else 0), _stream(x))
     _check(rc, "uno_resample2d")
     return out
 

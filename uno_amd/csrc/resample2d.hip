@@ -117,15 +117,18 @@ template <bool ACCUM, int KT, typename T, bool MF>      // KT: compiled tap coun
 __global__ __launch_bounds__(512, (ACCUM ? (KT <= 5 ? 7 : 1) : (KT <= 12 ? 8 : 1))) void resample_fused_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                              const int* __restrict__ tile_p0, const float* __restrict__ tile_w, int NP,
                                                              const int* __restrict__ startW, const float* __restrict__ wtW, int KW,
-                                                             int H, int W, int Ho, int Wo, int n_img, int ntiles) {
+                                                             int H, int W, int Ho, int Wo, int n_img, int ntiles, int rev) {
     extern __shared__ __attribute__((aligned(16))) float V[];       // [RS_TR][WP] then (VALU form) the tile's dense weights [NP][16]
     // Workgroups go to the 8 XCDs round-robin by linear index: all row tiles of an image on ONE XCD, next to each other in time, so
     // that the band of input rows two neighbouring tiles share (NP - 16 H / Ho rows: 27 against 21.3 at 446 -> 334) comes out of
     // that XCD's L2 instead of over the fabric twice (FETCH_SIZE was 1.66x the image)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int n = (slot / ntiles) * 8 + xcd;
+    int n = (slot / ntiles) * 8 + xcd;
     const int tile = slot % ntiles;
     if (n >= n_img) return;
+    // rev: the images in DESCENDING order - the call runs right before a kernel that reads the same tensor in ascending order (K1 of the
+    // same block): what this sweep read last, the 256 MB of the Infinity Cache that tensor's head still occupies, the next one reads first
+    if (rev) n = n_img - 1 - n;
     const int i0 = tile * RS_TR;
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -361,17 +364,19 @@ __global__ __launch_bounds__(512, (ACCUM ? (KT <= 5 ? 7 : 1) : (KT <= 12 ? 8 : 1
 // device holds at once - are 5-45 % slower on every shape of tools/rsbench.py than one workgroup per tile)
 template <bool A, int K, typename T, bool MF>
 static bool launch_fused_one(dim3 grid, int nthreads, size_t lds, hipStream_t s, const T* in, T* out, const int* tile_p0, const float* tile_w,
-                             int NP, const int* startW, const float* wtW, int KW, int H, int W, int Ho, int Wo, int n_img, int ntiles) {
+                             int NP, const int* startW, const float* wtW, int KW, int H, int W, int Ho, int Wo, int n_img, int ntiles, int rev) {
     auto k = resample_fused_kernel<A, K, T, MF>;
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, lds_slot)) return false;
-    hipLaunchKernelGGL(k, grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles);
+    hipLaunchKernelGGL(k, grid, dim3(nthreads), lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles, rev);
     return true;
 }
 
 int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
                       const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s) {
+    const int rev = (accumulate >> 1) & 1;          // bit 1 of `accumulate`: descending image order (fused kernel only; the result is the same)
+    accumulate &= 1;
     typedef unsigned short bf_t;
     const float* in = static_cast<const float*>(in_);
     float* out = static_cast<float*>(out_);
@@ -398,10 +403,10 @@ int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H,
         bool lds_ok = true;
 #define UNO_RS_LAUNCH(A, K)                                                                                                    \
         do {                                                                                                                   \
-            if (bf16 && mf) lds_ok = launch_fused_one<A, K, bf_t, true>(grid, nthreads, lds, s, inb, outb, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
-            else if (bf16) lds_ok = launch_fused_one<A, K, bf_t, false>(grid, nthreads, lds, s, inb, outb, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
-            else if (mf) lds_ok = launch_fused_one<A, K, float, true>(grid, nthreads, lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
-            else lds_ok = launch_fused_one<A, K, float, false>(grid, nthreads, lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles); \
+            if (bf16 && mf) lds_ok = launch_fused_one<A, K, bf_t, true>(grid, nthreads, lds, s, inb, outb, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles, rev); \
+            else if (bf16) lds_ok = launch_fused_one<A, K, bf_t, false>(grid, nthreads, lds, s, inb, outb, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles, rev); \
+            else if (mf) lds_ok = launch_fused_one<A, K, float, true>(grid, nthreads, lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles, rev); \
+            else lds_ok = launch_fused_one<A, K, float, false>(grid, nthreads, lds, s, in, out, tile_p0, tile_w, NP, startW, wtW, KW, H, W, Ho, Wo, n_img, ntiles, rev); \
         } while (0)
         // tap counts seen in the U-NO models: 4-5 (up-sampling by ~2 and its adjoint's rows), 9-10 (down-sampling by ~2)
 #define UNO_RS_PICK(A)                                                                                                         \

@@ -551,6 +551,10 @@ FUSE_UPSAMPLE_ADD = True
 # GEMMs in ONE launch (uno_mode_backward); False - uno_spectral_conv2d_backward, which runs the weight-gradient GEMM on a side stream
 # beside the input-gradient GEMM and the inverse transform (A/B switch; tools/dev/fusetime.py)
 PAIR_BACKWARD_GEMMS = True
+# A down-sampling resampling kernel reads the tensor that the block's forward transform (K1) reads as well.  True: it runs right BEFORE
+# that K1 and walks the images in descending order, so that what it read last - the part of the tensor still in the 256 MB Infinity
+# Cache - is what K1, walking up, reads first.  False: after the spectral branch, ascending (A/B switch).
+REVERSE_SWEEP_RESAMPLE = True
 
 
 def _fused_addend(t, H, W, m1, m2, adjoint):
@@ -1182,6 +1186,9 @@ class _OperatorBlock2dFn(torch.autograd.Function):
             O = _native.mode_mix(xt.view(B, Ci, 2, m1 * m2), [w1, w2], 0)
             s = _native.dft2d_inverse(O.view(B, Co, 2 * m1, m2), Ho, Wo, 1.0, True, True, addend=fused)
         else:
+            pre_act = None
+            if mix_last and not same and REVERSE_SWEEP_RESAMPLE:
+                pre_act = resample_forward(x, Ho, Wo, reverse=True)         # right before K1 reads x, in the opposite image order
             s, xt = _native.spectral_conv2d_forward(x, w1, w2, Ho, Wo, xt_out=None if ctx.stack is None else ctx.stack[0].X[ctx.stack[1]])
         out = s
         if fused is not None:
@@ -1189,7 +1196,7 @@ class _OperatorBlock2dFn(torch.autograd.Function):
             if fuse_gelu:
                 out = F.gelu(s)
         elif mix_last:
-            act = x if same else resample_forward(x, Ho, Wo)
+            act = x if same else (pre_act if pre_act is not None else resample_forward(x, Ho, Wo))
             if fuse_gelu:
                 _, out = _native.channel_mix2(act.view(B, Ci, -1), None, cwm, cb, out=s.view(B, Co, -1), accumulate=True, y_act=True)
                 out = out.view(B, Co, Ho, Wo)
@@ -1234,7 +1241,9 @@ class _OperatorBlock2dFn(torch.autograd.Function):
         lw1, lw2, lcw, lcb = ctx.leaves
         # down-sampling block (forward: act = R x; s += Wm act): the point-wise part of gx is the ADJOINT resampling of Wm^T gs, an
         # up-sampling - it joins the spectral part inside the inverse transform (one pass over gx) where the fused kernel applies
-        g_act = addend = None
+        g_act = addend = g_t = None
+        if not mix_last and REVERSE_SWEEP_RESAMPLE:
+            g_t = resample_adjoint(gs, H, W, reverse=True).view(B, Co, -1)          # right before K1 reads gs, in the opposite image order
         if mix_last and not same and need_gx and gs.dtype == torch.float32:
             g_act = _native.channel_mix(gs.view(B, Co, -1), cwm, None, transpose_w=True).view(B, Ci, Ho, Wo)
             addend = _fused_addend(g_act, H, W, w1.shape[2], w1.shape[3], True)
@@ -1265,7 +1274,8 @@ class _OperatorBlock2dFn(torch.autograd.Function):
                                        has_bias and ctx.needs_input_grad[4], stack=pstack)
         else:
             # forward: t = Wm x + b;  s += R t
-            g_t = resample_adjoint(gs, H, W).view(B, Co, -1)
+            if g_t is None:
+                g_t = resample_adjoint(gs, H, W).view(B, Co, -1)
             if need_gx:
                 _native.channel_mix(g_t, cwm, None, transpose_w=True, out=gx.view(B, Ci, -1), dgelu_of=dg_view, dgelu_total=own_last)
                 dg_done = own_last
@@ -1353,6 +1363,9 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
         lw1, lw2, lcw, lcb = ctx.leaves
         both_gw = ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
         gslot = _stack_grad_slot(ctx.stack[0], ctx.stack[1], Co) if (ctx.stack is not None and need_gw) else None
+        g_pre = None
+        if not mix_last and REVERSE_SWEEP_RESAMPLE:
+            g_pre = resample_adjoint(gs, H, W, reverse=True).view(B, Co, -1)       # right before K1 reads gs, in the opposite image order
         gO = _native.dft2d_forward(gs, m1, m2, 1.0, True, True, out=gslot)             # c (.) keep (.) DFT_trunc(gs)
         gw1 = gw2 = gXp = None
         if gslot is not None:
@@ -1396,7 +1409,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
                     defer.pending.append((lambda out: resample_adjoint(
                         _native.channel_mix(g_src, cw2, None, transpose_w=True).view(B, C2, Ho, Wo), H, W, out=out), False))
             else:
-                g_src = resample_adjoint(gs, H, W).view(B, Co, -1)
+                g_src = g_pre if g_pre is not None else resample_adjoint(gs, H, W).view(B, Co, -1)
                 defer.pending.append((mix_into, True))
             if gx1 is not None:
                 cw1 = cwm[:, :C1].contiguous()
@@ -1427,7 +1440,7 @@ class _OperatorBlock2dCatFn(torch.autograd.Function):
                         g_act = _native.channel_mix(g_src, cwx.contiguous(), None, transpose_w=True)
                         resample_adjoint(g_act.view(B, Cx, Ho, Wo), H, W, out=gx)
         else:
-            g_src = resample_adjoint(gs, H, W).view(B, Co, -1)
+            g_src = g_pre if g_pre is not None else resample_adjoint(gs, H, W).view(B, Co, -1)
             if both:
                 _mix2_input_grads(g_src, cwm, C1, out1=gx1.view(B, C1, -1), out2=gx2.view(B, C2, -1))
             else:

@@ -159,20 +159,20 @@ def upsample_add_tables(Hs: int, Ws: int, H: int, W: int, device_str: str, adjoi
     return tuple(t.to(dev) for t in ops)
 
 
-def resample_forward(x: torch.Tensor, Ho: int, Wo: int, out: torch.Tensor | None = None) -> torch.Tensor:
-    """R_h x R_w^T on the device (no autograd); with `out`, accumulates into it."""
+def resample_forward(x: torch.Tensor, Ho: int, Wo: int, out: torch.Tensor | None = None, reverse: bool = False) -> torch.Tensor:
+    """R_h x R_w^T on the device (no autograd); with `out`, accumulates into it.  reverse: images in descending order (same result)."""
     H, W = x.shape[-2:]
     (fh, th), _ = _tables(H, Ho, str(x.device))
     (fw, _), _ = _tables(W, Wo, str(x.device))
-    return _native.resample2d(x, Ho, Wo, fh, fw, th, out=out)
+    return _native.resample2d(x, Ho, Wo, fh, fw, th, out=out, reverse=reverse)
 
 
-def resample_adjoint(gy: torch.Tensor, H: int, W: int, out: torch.Tensor | None = None) -> torch.Tensor:
+def resample_adjoint(gy: torch.Tensor, H: int, W: int, out: torch.Tensor | None = None, reverse: bool = False) -> torch.Tensor:
     """Adjoint of resample_forward for an (H, W) input grid: R_h^T gy R_w; with `out`, accumulates into it."""
     Ho, Wo = gy.shape[-2:]
     _, (bh, th) = _tables(H, Ho, str(gy.device))
     _, (bw, _) = _tables(W, Wo, str(gy.device))
-    return _native.resample2d(gy, H, W, bh, bw, th, out=out)
+    return _native.resample2d(gy, H, W, bh, bw, th, out=out, reverse=reverse)
 
 
 class _Resample2dFn(torch.autograd.Function):
