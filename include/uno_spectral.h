@@ -127,6 +127,12 @@ int uno_dft2d_inverse(const float* spec, float* images, int n_img, int H, int W,
  * device ("one workgroup per CU", persistent grids) then count on the remaining CUs.  Returns the previous value; 0 = none (default). */
 int uno_reserve_cus(int n);
 
+/* ABI 11.  (no reference counterpart) Alternating sweep direction: consecutive launches of the streaming kernels walk their work items
+ * (images, batch entries, pixel tiles) in opposite directions, so that a kernel starts with the part of a > 256 MB tensor its predecessor
+ * touched last - the part the Infinity Cache still holds.  Results do not depend on it.  enable = 0 turns it off (every launch front to
+ * back); returns the previous setting (default 1). */
+int uno_sweep_alternation(int enable);
+
 /* ABI 11.  Pruned inverse DFT PLUS the up-sampled point-wise branch in one pass over the output:
  *   images[h][w] = (uno_dft2d_inverse's result) + sum_{u,v} Rh[h][u] Rw[w][v] addend[u][v]
  * = `x1_out + x2_out` of an up-sampling operator block, reference integral_operators.py:272-273, with x2_out the bicubic /

@@ -95,3 +95,18 @@ for rnd in range(3):
         print(f"round {rnd} reverse_sweep_resample={rv}: {res[rv][-1]:.3f} ms/step", flush=True)
 io.REVERSE_SWEEP_RESAMPLE = True
 print("reverse sweep before K1", min(res[True]), "after the spectral branch", min(res[False]))
+res = {True: [], False: []}
+for rnd in range(3):
+    for alt in (True, False):
+        _native.sweep_alternation(alt)
+        for _ in range(3):
+            tr.step(a, u)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(a, u)
+        torch.cuda.synchronize()
+        res[alt].append((time.perf_counter() - t0) / steps * 1e3)
+        print(f"round {rnd} sweep_alternation={alt}: {res[alt][-1]:.3f} ms/step loss {float(loss):.6f}", flush=True)
+_native.sweep_alternation(True)
+print("alternating sweeps", min(res[True]), "all front to back", min(res[False]))

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "uno_dft2d_inverse_bf16": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_dft2d_inverse": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp]),
     "uno_reserve_cus": (C.c_int, [_i]),
+    "uno_sweep_alternation": (C.c_int, [_i]),
     "uno_dft2d_inverse_add_applies": (C.c_int, [_i] * 7),
     "uno_dft2d_inverse_add": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float, _i, _i, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     "uno_dft2d_forward_grouped": (C.c_int, [_fp, _fp] + [_i] * 5 + [C.c_float] + [_i] * 5 + [_fp]),
@@ -354,6 +355,11 @@ def dft2d_forward(images, m1, m2, scale=1.0, hermitian_cols=False, mask_overlap=
 def reserve_cus(n: int) -> int:
     """Set aside n compute units for communication kernels running beside the library's (uno_reserve_cus); returns the previous value."""
     return int(lib().uno_reserve_cus(int(n)))
+
+
+def sweep_alternation(enable: bool) -> bool:
+    """Alternating sweep direction of consecutive launches (uno_sweep_alternation); returns the previous setting."""
+    return bool(lib().uno_sweep_alternation(1 if enable else 0))
 
 
 def dft2d_inverse_add_applies(n_img, H, W, m1, m2, Hs, Ws) -> bool:

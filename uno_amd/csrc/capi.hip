@@ -209,6 +209,11 @@ static int mode_backward(const float2* xtrunc, const float2* go, const float2* c
 
 static int g_reserved_cus = 0;
 int reserved_cus() { return __atomic_load_n(&g_reserved_cus, __ATOMIC_RELAXED); }
+static int g_sweep_alternation = 255;
+static thread_local unsigned t_sweep_count = 0;
+// family bits of the setting: 1 K1, 2 K3, 4 K7, 8 K8, 16 K9, 32 InstanceNorm, 64 GELU-projection backward, 128 lift kernels; a launch of a
+// family that is switched off runs front to back and does not advance the counter
+int next_sweep_reversed(int family) { return (__atomic_load_n(&g_sweep_alternation, __ATOMIC_RELAXED) & family) ? (int)(t_sweep_count++ & 1u) : 0; }
 
 }  // namespace uno
 
@@ -246,6 +251,10 @@ SideStream* side_stream_of_current_device() {
 extern "C" {
 
 int uno_abi_version(void) { return UNO_SPECTRAL_ABI_VERSION; }
+
+int uno_sweep_alternation(int enable) {
+    return __atomic_exchange_n(&uno::g_sweep_alternation, enable == 1 ? 255 : (enable & 255), __ATOMIC_RELAXED);      // (1: all families; other values: a mask, development)
+}
 
 int uno_reserve_cus(int n) {
     if (n < 0) n = 0;

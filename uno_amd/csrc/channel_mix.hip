@@ -83,6 +83,7 @@ struct ChannelMixParams {
                             // corner of (Hp, Wp) planes - rl = W (any width: a lane's four pixels may straddle a row end), skip = Wp - W
     int C1, Co1;
     int w_so, w_si;
+    int rev;                // alternating sweep direction: pixel tiles and batch entries in descending order
     int ncot;               // channel tiles per pixel tile
     int ntile, per_xcd;     // tiles (pixel x channel) per batch entry; ceil(ntile / 8)
     const void* wsplit;     // K8-S with WM = 2: the weights as bf16 pieces in the kernel's own LDS layout (channel_mix_wsplit_kernel)
@@ -481,9 +482,10 @@ __global__ __launch_bounds__(256, (TINY ? 2 : 4)) void channel_mix_kernel(Channe
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (gridDim.x is a multiple of 8), so XCD k gets
     // the k-th contiguous eighth of the tile list.  Neighbouring pixel tiles share the 128-byte lines at their
     // boundary in every row (rows are only 4-byte aligned); on the same XCD they meet in one L2.
-    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    const int bx_ = sweep_x(p.rev);
+    const int tile = (bx_ & 7) * p.per_xcd + (bx_ >> 3);
     if (tile >= p.ntile) return;
-    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CM_MT, b = blockIdx.y;
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CM_MT, b = sweep_y(p.rev);
     if constexpr (TINY) {
         channel_mix_tile<0, PT, ACT, DG, BF>(p, sX, sW, p0, o0, b);
     } else {
@@ -511,9 +513,10 @@ __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(Ch
     constexpr int PT = CM_PT, XS = PT + 16, NM = PT / 16;
     __shared__ __attribute__((aligned(16))) float sX[2][CM_KC * XS];
     __shared__ __attribute__((aligned(16))) float sW[2][CM_KC * CMW_WS];
-    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    const int bx_ = sweep_x(p.rev);
+    const int tile = (bx_ & 7) * p.per_xcd + (bx_ >> 3);
     if (tile >= p.ntile) return;
-    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = blockIdx.y;
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = sweep_y(p.rev);
     if (p0 + PT > p.P || (p.Ci & (CM_KC - 1)) != 0) {
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(&sW[0][0]);
         if constexpr (GEN) {
@@ -736,9 +739,10 @@ __global__ __launch_bounds__(256, 2) void channel_mix_split_kernel(ChannelMixPar
     __shared__ __attribute__((aligned(16))) char smem[LDS_MAIN > CMS_FALLBACK ? LDS_MAIN : CMS_FALLBACK];
     char* sXb = smem;
     char* sWb = smem + NPX * CMS_XPLANE;
-    const int tile = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    const int bx_ = sweep_x(p.rev);
+    const int tile = (bx_ & 7) * p.per_xcd + (bx_ >> 3);
     if (tile >= p.ntile) return;
-    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CT, b = blockIdx.y;
+    const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * CT, b = sweep_y(p.rev);
     if (p0 + PT > p.P) {            // the last, partial pixel tile of a row: the guarded 64-channel path (twice for a 128-channel tile, as the wide kernel)
         auto sXn = reinterpret_cast<float (*)[CM_KC * (PT + 16)]>(smem);
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(smem + 2 * CM_KC * (PT + 16) * 4);
@@ -1213,6 +1217,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         return -2;
     }
     p.ncot = (int)ncot; p.ntile = (int)(npt * ncot); p.per_xcd = (p.ntile + 7) / 8;
+    p.rev = next_sweep_reversed(SWEEP_K8);
     const int accumulate = p.accumulate;
     if (Ci <= 4 && !accumulate && !act_in && !dgelu_of && P >= 1024 && !two_src && !two_dst && !a.y_act && !a.proj_w && !windowed) {
         ProfScope prof("uno::channel_mix_few_in_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co) + 4.0 * Ci * Co, s);
@@ -1311,6 +1316,7 @@ struct ChannelWgradParams {
     const float* vh_x; const float* vh_w; const float* vh_b; int vh_ci;     // vector kernel, VHX: x is VIRTUAL (see ChannelMixParams)
     int act_x;              // scalar kernel: x := gelu(x)
     long long span;         // pixels per split (informational)
+    int rev;                // alternating sweep direction (vector and split kernels): pixel splits in descending order
 };
 
 template <bool BF>
@@ -1421,7 +1427,8 @@ __global__ __launch_bounds__(256, 4) void channel_wgrad_vec_kernel(ChannelWgradP
     // XCD-aware order: workgroups go round-robin to the 8 XCDs; all weight tiles of one pixel split (they read the same
     // gy / x rows) are given to one XCD so that the re-reads hit its L2 (measured before: 1.78x the algorithmic bytes
     // fetched over the fabric for a 2-tile layer)
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int bxr = sweep_x(p.rev);
+    const int xcd = bxr & 7, j = bxr >> 3;
     const int split = (j / ntile) * 8 + xcd, tile = j % ntile;
     if (split >= p.nsplit) return;
     const int o0 = (tile / ntile_i) * CW_T, i0 = (tile % ntile_i) * CW_T;
@@ -1607,7 +1614,8 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     constexpr int ES = BF ? 2 : 4;
     constexpr int NPG = BF ? 1 : 3, NPX = (BF && !ACTX) ? 1 : 3;    // bf16 pieces of the two operands
     const int ntile = ((p.Co + TO - 1) / TO) * ntile_i;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;            // all weight tiles of one pixel split on one XCD (as the vector kernel)
+    const int bxr = sweep_x(p.rev);
+    const int xcd = bxr & 7, j = bxr >> 3;                          // all weight tiles of one pixel split on one XCD (as the vector kernel)
     const int split = (j / ntile) * 8 + xcd, tile = j % ntile;
     if (split >= p.nsplit) return;
     const int o0 = (tile / ntile_i) * TO, i0 = (tile % ntile_i) * CWS_T;
@@ -1964,6 +1972,7 @@ int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     p.span = (long long)cps * pk;
+    p.rev = next_sweep_reversed(SWEEP_K9);
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
     {
         ProfScope prof("uno::channel_wgrad_vec_kernel", 4.0 * B * (double)P * (vh_ci + Co), s);
@@ -1996,6 +2005,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     if (windowed && (pk != CWV_PK || (Ci <= 4 && !act_x))) { set_error("channel_wgrad: the pixel window goes with the vector / split kernels (>= 64 pixels, > 4 input channels)"); return -2; }
     p.span = (long long)cps * pk;
+    p.rev = next_sweep_reversed(SWEEP_K9);
     const int tiles = ((Co + CW_T - 1) / CW_T) * ((Ci + CW_T - 1) / CW_T);
     if (Ci <= 4 && !act_x && P >= 1024) {
         const long long quads = (long long)B * ((P + 3) / 4), qps = (quads + p.nsplit - 1) / p.nsplit;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dft2d_fwd_ft_kernel(Dft2dParams p) {
     int* sTailW = reinterpret_cast<int*>(sTwH + H);                            // [FT_TAILMAX][2][64]: left / right column of a tail element (-1 = none)
 
     const int slot = wave / NW, wsub = wave - slot * NW;
-    const int image = blockIdx.x * (NWT / NW) + slot;
+    const int image = sweep_x(p.rev) * (NWT / NW) + slot;
     const bool active = image < p.n_img;
     const int nrt = (H + 15) >> 4;
     float* buf = sTile + (size_t)wave * tile_stride;
@@ -421,6 +421,7 @@ static int launch_fwd_ft(Dft2dParams p, const FwdFtGeometry& g, hipStream_t s) {
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
+    p.rev = next_sweep_reversed(SWEEP_K1);
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_fwd_ft_kernel<%d, %d, %d>", NT, MT, R4);
     {

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * HT_WAVES) void dft2d_fwd_ht_kernel(Dft2dParams
     float2* sTwH = sTab4 + (size_t)nka * R4 * 16;
 
     const int slot = wave / NW, wsub = wave - slot * NW;
-    const int image = blockIdx.x * (NWT / NW) + slot;
+    const int image = sweep_x(p.rev) * (NWT / NW) + slot;
     const bool active = image < p.n_img;
     const int nrt = (H + 15) >> 4;
     float* buf = sBuf + (size_t)wave * buf_stride;
@@ -494,6 +494,7 @@ static int launch_fwd_ht(Dft2dParams p, const FwdFtGeometry& g, hipStream_t s) {
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_fwd: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
+    p.rev = next_sweep_reversed(SWEEP_K1);
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_fwd_ht_kernel<%d, %d, %d>", NT, MT, R4);
     {

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, ((NWTM <= 7 && KS <= 4) ? 2 : 1)) void dft2d_i
     __syncthreads();
 
     const int slot = wave / NW, wsub = wave - slot * NW;
-    const int image = blockIdx.x * (NWT / NW) + slot;
+    const int image = sweep_x(p.rev) * (NWT / NW) + slot;
     if (image >= p.n_img) return;               // no barrier below
 
     const int ko = p.exp & 0xff;                 // development knock-outs: 1 no addend loads, 2 no spectrum reload, 4 no stores, 8 no stage 1', 16 no stage 2'
@@ -343,6 +343,7 @@ static int launch_inv_add(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_inv_add: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
+    p.rev = next_sweep_reversed(SWEEP_K3);
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_inv_ft_add_kernel<%d, %d, %d>", KS, KSK, NWTM);
     {

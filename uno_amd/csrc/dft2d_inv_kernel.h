@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * INV_MAX_WAVES) void dft2d_inv_kernel(Dft2dPara
     __syncthreads();
 
     const int slot = wave / NW, wsub = wave - slot * NW;
-    const int image = blockIdx.x * (NWT / NW) + slot;
+    const int image = sweep_x(p.rev) * (NWT / NW) + slot;
     if (image >= p.n_img) return;               // no barrier below
 
     // stage-B' A operand.  The corner rows come in +-k pairs (lo corner row k <-> frequency +k, hi corner row
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void dft2d_inv_ft_kernel(Dft2dParams p) {
     __syncthreads();
 
     const int slot = wave / NW, wsub = wave - slot * NW;
-    const int image = blockIdx.x * (NWT / NW) + slot;
+    const int image = sweep_x(p.rev) * (NWT / NW) + slot;
     if (image >= p.n_img) return;               // no barrier below
 
     constexpr int KSK = 2 * JT + 1;
@@ -551,6 +551,7 @@ static int launch_inv_k(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
+    p.rev = next_sweep_reversed(SWEEP_K3);
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_inv_kernel<%d, %d, %s, %s>", KS, JT, BF16 ? "true" : "false", TAB ? "true" : "false");
     {
@@ -596,6 +597,7 @@ static int launch_inv_ft(Dft2dParams p, const InvGeometry& g, hipStream_t s) {
     static int lds_slot[64];
     if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), g.lds, lds_slot)) { set_error("dft2d_inv: cannot raise dynamic LDS to %zu", g.lds); return -4; }
     p.nw = g.nw;
+    p.rev = next_sweep_reversed(SWEEP_K3);
     char name[64];
     snprintf(name, sizeof(name), "uno::dft2d_inv_ft_kernel<%d, %d>", KS, JT);
     {

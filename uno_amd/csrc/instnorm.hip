@@ -82,9 +82,9 @@ __device__ __forceinline__ void in_sweep(const T* row0, const T* row1, int N, F 
 template <bool GELU, typename T>
 __global__ __launch_bounds__(IN_T) void instnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps) {
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps, int rev) {
     __shared__ float red[IN_T / 64];
-    const int r = blockIdx.x, c = r % C;
+    const int r = sweep_x(rev), c = r % C;       // (rev: rows in descending order on every other launch, uno_common.h)
     const T* row = x + (size_t)r * N;
     T* dst = y + (size_t)r * N;
     float s = 0.f;
@@ -113,9 +113,9 @@ template <bool GELU, typename T>
 __global__ __launch_bounds__(IN_T) void instnorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                            T* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N) {
+                                                            T* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N, int rev) {
     __shared__ float red[IN_T / 64];
-    const int r = blockIdx.x, c = r % C;
+    const int r = sweep_x(rev), c = r % C;       // (rev: rows in descending order on every other launch, uno_common.h)
     const T* row = x + (size_t)r * N;
     const T* grow = gy + (size_t)r * N;
     T* dst = gx + (size_t)r * N;
@@ -156,9 +156,9 @@ template <bool GELU, typename T, int NQ>
 #endif
 __global__ __launch_bounds__(IN_T, (NQ == 25 ? UNO_IN_FWD25_WPE : 1)) void instnorm_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, T* __restrict__ y,
-                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps) {
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int N, float eps, int rev) {
     __shared__ float red[IN_T / 64];
-    const int r = blockIdx.x, c = r % C;
+    const int r = sweep_x(rev), c = r % C;       // (rev: rows in descending order on every other launch, uno_common.h)
     const T* row = x + (size_t)r * N;
     T* dst = y + (size_t)r * N;
     const int nq = N >> 2, tail = N & 3;
@@ -205,9 +205,9 @@ template <bool GELU, typename T, int NQ>
 __global__ __launch_bounds__(IN_T) void instnorm_bwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                                T* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N) {
+                                                                T* __restrict__ gx, float* __restrict__ s1_out, float* __restrict__ s2_out, int C, int N, int rev) {
     __shared__ float red[IN_T / 64];
-    const int r = blockIdx.x, c = r % C;
+    const int r = sweep_x(rev), c = r % C;       // (rev: rows in descending order on every other launch, uno_common.h)
     const T* row = x + (size_t)r * N;
     const T* grow = gy + (size_t)r * N;
     T* dst = gx + (size_t)r * N;
@@ -271,10 +271,11 @@ int launch_instnorm_fwd(const void* x, const float* gamma, const float* beta, vo
                         long long N, float eps, int gelu, int bf16, hipStream_t s) {
     typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
+    const int rev = next_sweep_reversed(SWEEP_NORM);
     if (const int rq = (N >= 4 ? instnorm_reg_quads(N, 32) : 0)) {
         ProfScope prof("uno::instnorm_fwd_reg_kernel", (bf16 ? 4.0 : 8.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
-#define UNO_IN_FWD(G, TT, Q) hipLaunchKernelGGL((instnorm_fwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, (int)N, eps)
+#define UNO_IN_FWD(G, TT, Q) hipLaunchKernelGGL((instnorm_fwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, C, (int)N, eps, rev)
 #define UNO_IN_FWD_Q(G, TT) do { switch (rq) { case 4: UNO_IN_FWD(G, TT, 4); break; case 8: UNO_IN_FWD(G, TT, 8); break; case 13: UNO_IN_FWD(G, TT, 13); break; \
                                    case 16: UNO_IN_FWD(G, TT, 16); break; case 25: UNO_IN_FWD(G, TT, 25); break; default: UNO_IN_FWD(G, TT, 32); } } while (0)
         if (bf16) { if (gelu) UNO_IN_FWD_Q(true, bf_t); else UNO_IN_FWD_Q(false, bf_t); }
@@ -285,11 +286,11 @@ int launch_instnorm_fwd(const void* x, const float* gamma, const float* beta, vo
         ProfScope prof("uno::instnorm_fwd_kernel", (bf16 ? 4.0 : 8.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
         if (bf16) {
-            if (gelu) hipLaunchKernelGGL((instnorm_fwd_kernel<true, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, gamma, beta, (bf_t*)y, mean, rstd, C, (int)N, eps);
-            else hipLaunchKernelGGL((instnorm_fwd_kernel<false, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, gamma, beta, (bf_t*)y, mean, rstd, C, (int)N, eps);
+            if (gelu) hipLaunchKernelGGL((instnorm_fwd_kernel<true, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, gamma, beta, (bf_t*)y, mean, rstd, C, (int)N, eps, rev);
+            else hipLaunchKernelGGL((instnorm_fwd_kernel<false, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, gamma, beta, (bf_t*)y, mean, rstd, C, (int)N, eps, rev);
         } else {
-            if (gelu) hipLaunchKernelGGL((instnorm_fwd_kernel<true, float>), grid, dim3(IN_T), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, C, (int)N, eps);
-            else hipLaunchKernelGGL((instnorm_fwd_kernel<false, float>), grid, dim3(IN_T), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, C, (int)N, eps);
+            if (gelu) hipLaunchKernelGGL((instnorm_fwd_kernel<true, float>), grid, dim3(IN_T), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, C, (int)N, eps, rev);
+            else hipLaunchKernelGGL((instnorm_fwd_kernel<false, float>), grid, dim3(IN_T), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, C, (int)N, eps, rev);
         }
     }
     const hipError_t e = hipGetLastError();
@@ -301,6 +302,7 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
                         void* gx, float* s1, float* s2, long long rows, int C, long long N, int gelu, int bf16, hipStream_t s) {
     typedef unsigned short bf_t;
     if (rows > 0x7fffffffLL || N > 0x7fffffffLL) { set_error("instnorm: too many rows or row too long"); return -2; }
+    const int rev = next_sweep_reversed(SWEEP_NORM);
     // (rounds 3-4 kept the GELU form to 8 quads per thread: with the library erff - a branching piecewise form - the compiler
     // spilled 40 registers at 13 quads and 344 at 25; with the branch-free uno_erf every size fits: 255 registers, no spills, at 25.
     // The 128-channel 223^2 level of the Darcy model - rows of 49 729 floats - left the sweep kernel, which read x and gy twice.)
@@ -310,7 +312,7 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
     if (const int rq = (N >= 4 ? instnorm_reg_quads(N, gelu ? UNO_IN_GELU_Q : 25) : 0)) {
         ProfScope prof("uno::instnorm_bwd_reg_kernel", (bf16 ? 6.0 : 12.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
-#define UNO_IN_BWD(G, TT, Q) hipLaunchKernelGGL((instnorm_bwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, (const TT*)gy, gamma, beta, mean, rstd, (TT*)gx, s1, s2, C, (int)N)
+#define UNO_IN_BWD(G, TT, Q) hipLaunchKernelGGL((instnorm_bwd_reg_kernel<G, TT, Q>), grid, dim3(IN_T), 0, s, (const TT*)x, (const TT*)gy, gamma, beta, mean, rstd, (TT*)gx, s1, s2, C, (int)N, rev)
 #define UNO_IN_BWD_Q(G, TT) do { switch (rq) { case 4: UNO_IN_BWD(G, TT, 4); break; case 8: UNO_IN_BWD(G, TT, 8); break; case 13: UNO_IN_BWD(G, TT, 13); break; \
                                    case 16: UNO_IN_BWD(G, TT, 16); break; default: UNO_IN_BWD(G, TT, 25); } } while (0)
         if (bf16) { if (gelu) UNO_IN_BWD_Q(true, bf_t); else UNO_IN_BWD_Q(false, bf_t); }
@@ -321,11 +323,11 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
         ProfScope prof("uno::instnorm_bwd_kernel", (bf16 ? 6.0 : 12.0) * rows * (double)N, s);
         const dim3 grid((unsigned)rows);
         if (bf16) {
-            if (gelu) hipLaunchKernelGGL((instnorm_bwd_kernel<true, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, (const bf_t*)gy, gamma, beta, mean, rstd, (bf_t*)gx, s1, s2, C, (int)N);
-            else hipLaunchKernelGGL((instnorm_bwd_kernel<false, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, (const bf_t*)gy, gamma, beta, mean, rstd, (bf_t*)gx, s1, s2, C, (int)N);
+            if (gelu) hipLaunchKernelGGL((instnorm_bwd_kernel<true, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, (const bf_t*)gy, gamma, beta, mean, rstd, (bf_t*)gx, s1, s2, C, (int)N, rev);
+            else hipLaunchKernelGGL((instnorm_bwd_kernel<false, bf_t>), grid, dim3(IN_T), 0, s, (const bf_t*)x, (const bf_t*)gy, gamma, beta, mean, rstd, (bf_t*)gx, s1, s2, C, (int)N, rev);
         } else {
-            if (gelu) hipLaunchKernelGGL((instnorm_bwd_kernel<true, float>), grid, dim3(IN_T), 0, s, (const float*)x, (const float*)gy, gamma, beta, mean, rstd, (float*)gx, s1, s2, C, (int)N);
-            else hipLaunchKernelGGL((instnorm_bwd_kernel<false, float>), grid, dim3(IN_T), 0, s, (const float*)x, (const float*)gy, gamma, beta, mean, rstd, (float*)gx, s1, s2, C, (int)N);
+            if (gelu) hipLaunchKernelGGL((instnorm_bwd_kernel<true, float>), grid, dim3(IN_T), 0, s, (const float*)x, (const float*)gy, gamma, beta, mean, rstd, (float*)gx, s1, s2, C, (int)N, rev);
+            else hipLaunchKernelGGL((instnorm_bwd_kernel<false, float>), grid, dim3(IN_T), 0, s, (const float*)x, (const float*)gy, gamma, beta, mean, rstd, (float*)gx, s1, s2, C, (int)N, rev);
         }
     }
     const hipError_t e = hipGetLastError();

@@ -86,6 +86,7 @@ struct LiftBwdParams {
     int B, Cin;
     LiftGeom geo;
     unsigned long long* stamps;     // development (-DUNO_LB_DEV): per-phase cycles of every wave, 8 values each
+    int rev;                        // alternating sweep direction (uno_common.h): tile groups and batch entries in descending order
 };
 
 __device__ __forceinline__ float4 lb_vh(const float4& t, const float4* q) {       // t = (w[c][0..2], b[c]); q: the real channels at 4 pixels
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     float4* sVH = reinterpret_cast<float4*>(sWT + LB_CO * LB_WTS);      // [32]
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
+    const int b = sweep_y(p.rev), bxs = sweep_x(p.rev);
     const LiftGeom& G = p.geo;
 
     // weights: once per workgroup
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
 #else
 #define LB_STAMP(i) do { } while (0)
 #endif
-    const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
+    const int t_begin = bxs * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
     // a tile's global loads: this thread's quad (slots 4 (tid & 31) ..) of the real channels and of rows (tid >> 5) + 8 u of g - straight-
     // line code (the guarded form of the first version, branches around scalar tails with a wait inside each, serialised the eight row
     // loads: 17 k of a tile's 38 k cycles).  The NEXT tile's loads are issued as soon as the current tile's values are in LDS and arrive
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     }
 #endif
     // partial sums of this workgroup: (64, 33) block, bias in column 32
-    float* part = p.part + ((size_t)b * gridDim.x + blockIdx.x) * (LB_CO * (LB_CM + 1));
+    float* part = p.part + ((size_t)b * gridDim.x + bxs) * (LB_CO * (LB_CM + 1));
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void lift_backward_kernel(LiftBwdParams p) 
     bsum += __shfl_xor(bsum, 32);
     if (kk == 0) part[(16 * wave + r16) * (LB_CM + 1) + LB_CM] = bsum;
     // fc_n1: the 32 lanes of a half wave hold the same rows; (32, Cin + 1) block, bias in column Cin
-    float* part1 = p.part1 + ((size_t)b * gridDim.x + blockIdx.x) * (LB_CM * (p.Cin + 1));
+    float* part1 = p.part1 + ((size_t)b * gridDim.x + bxs) * (LB_CM * (p.Cin + 1));
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -346,6 +347,7 @@ struct LiftFwdParams {
     int B, Cin, tail;       // tail: columns of a padded row behind its last quad (Wp mod 4)
     LiftGeom geo;
     unsigned long long* stamps;     // development (-DUNO_LB_DEV)
+    int rev;                // alternating sweep direction (uno_common.h)
 };
 
 __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
     float4* sVH = reinterpret_cast<float4*>(sW + LB_CM * LB_WS);
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
+    const int b = sweep_y(p.rev), bxs = sweep_x(p.rev);
     const LiftGeom& G = p.geo;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void lift_forward_kernel(LiftFwdParams p) {
 #ifdef UNO_LB_DEV
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
 #endif
-    const int t_begin = blockIdx.x * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
+    const int t_begin = bxs * LB_TPW, t_end = min(t_begin + LB_TPW, G.npt);
     if (t_begin < t_end) load_x(t_begin, xqA, qdA);
     if (t_begin + 1 < t_end) load_x(t_begin + 1, xqB, qdB);
     __syncthreads();
@@ -480,6 +482,7 @@ int launch_lift_forward_fused(const float* x, const float* w1, const float* b1, 
     p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.act = act;
     p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp, Wp & ~3); p.tail = Wp & 3;
     p.stamps = nullptr;
+    p.rev = next_sweep_reversed(SWEEP_LIFT);
 #ifdef UNO_LB_DEV
     if (getenv("UNO_LF_STAMPS")) p.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("UNO_LF_STAMPS"), nullptr, 0));
 #endif
@@ -513,6 +516,7 @@ int launch_lift_backward_fused(const float* x, const float* w1, const float* b1,
     p.x = x; p.w1 = w1; p.b1 = b1; p.w0 = w0; p.b0 = b0; p.g = g; p.g2 = g2; p.part = part; p.part1 = part1;
     p.B = B; p.Cin = Cin; p.geo = lift_geom(H, W, Hp, Wp);
     p.stamps = nullptr;
+    p.rev = next_sweep_reversed(SWEEP_LIFT);
 #ifdef UNO_LB_DEV
     if (getenv("UNO_LB_STAMPS")) p.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("UNO_LB_STAMPS"), nullptr, 0));
 #endif

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gelu_project_fwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restrict__ pre, const float* __restrict__ w,
                                                                const T* __restrict__ gout, T* __restrict__ gpre,
-                                                               float* __restrict__ part, int C, int P, int Cs, PixMap pm) {
+                                                               float* __restrict__ part, int C, int P, int Cs, PixMap pm, int rev) {
     // pm: pixel window (uno_common.h) - pre, gout (one plane per batch entry) and gpre on one window; dense: pm.PS == P
     // blockIdx.z = channel split: channels [z Cs, min(C, (z + 1) Cs)); small tensors (one-wave workgroups) are split over
     // channels as well, so that the chip sees 4x the waves (a 64 x 64 grid at batch 32 gave 512 waves walking 128 channels each)
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restri
     const int nw = blockDim.x >> 6;
     for (int c = threadIdx.x; c < C; c += blockDim.x) sw[c] = w[c];
     __syncthreads();
-    const int b = blockIdx.y;
-    const int px = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int bxs = sweep_x(rev), b = sweep_y(rev);           // (alternating sweep direction, uno_common.h: the partial-sum slot follows the work item)
+    const int px = (bxs * blockDim.x + threadIdx.x) * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = px < P;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void gelu_project_bwd_kernel(const T* __restri
     wave_sum((g[0] + g[1]) + (g[2] + g[3]), C);
     __syncthreads();
     // part[z][blk][C + 1]: a split fills its own channels (split 0 also the bias slot C); the reduction reads exactly those
-    float* prow = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (C + 1);
+    float* prow = part + (((size_t)blockIdx.z * gridDim.y + b) * gridDim.x + bxs) * (C + 1);
     auto total = [&](int e) {
         float t = swave[e];
         for (int k = 1; k < nw; ++k) t += swave[k * (C + 1) + e];          // wave order: fixed
@@ -230,11 +230,12 @@ int launch_gelu_project_bwd(const void* pre, const float* w, const void* gout, v
     const int threads = gelu_project_threads(B, P);
     const unsigned nb = (unsigned)((P + 4 * threads - 1) / (4 * threads));
     const int nsplit = gelu_project_splits(B, C, P), Cs = (C + nsplit - 1) / nsplit;
+    const int rev = next_sweep_reversed(SWEEP_PROJ);
     {
         ProfScope prof("uno::gelu_project_bwd_kernel", (bf16 ? 2.0 : 4.0) * B * (double)P * (2 * C + 1), s);
         const size_t lds = (threads / 64) * (C + 1) * sizeof(float);
-        if (bf16) hipLaunchKernelGGL(gelu_project_bwd_kernel<bf_t>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const bf_t*)pre, w, (const bf_t*)gout, (bf_t*)gpre, ws, C, (int)P, Cs, pm);
-        else hipLaunchKernelGGL(gelu_project_bwd_kernel<float>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const float*)pre, w, (const float*)gout, (float*)gpre, ws, C, (int)P, Cs, pm);
+        if (bf16) hipLaunchKernelGGL(gelu_project_bwd_kernel<bf_t>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const bf_t*)pre, w, (const bf_t*)gout, (bf_t*)gpre, ws, C, (int)P, Cs, pm, rev);
+        else hipLaunchKernelGGL(gelu_project_bwd_kernel<float>, dim3(nb, B, nsplit), dim3(threads), lds, s, (const float*)pre, w, (const float*)gout, (float*)gpre, ws, C, (int)P, Cs, pm, rev);
     }
     hipLaunchKernelGGL(gelu_project_reduce_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, ws, gw, gb, C, (int)(nb * B), Cs);
     const hipError_t e = hipGetLastError();

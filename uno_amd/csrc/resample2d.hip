@@ -125,9 +125,9 @@ __global__ __launch_bounds__(512, (ACCUM ? (KT <= 5 ? 7 : 1) : (KT <= 12 ? 8 : 1
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int n = (slot / ntiles) * 8 + xcd;
     const int tile = slot % ntiles;
+    // rev: the images in DESCENDING order (alternating sweep direction, uno_common.h): the call runs right before the K1 of the same
+    // block, which reads the same tensor - what this sweep read last is still in the Infinity Cache when K1, walking the other way, starts
     if (n >= n_img) return;
-    // rev: the images in DESCENDING order - the call runs right before a kernel that reads the same tensor in ascending order (K1 of the
-    // same block): what this sweep read last, the 256 MB of the Infinity Cache that tensor's head still occupies, the next one reads first
     if (rev) n = n_img - 1 - n;
     const int i0 = tile * RS_TR;
     const int tid = threadIdx.x;
@@ -375,8 +375,8 @@ static bool launch_fused_one(dim3 grid, int nthreads, size_t lds, hipStream_t s,
 int launch_resample2d(const void* in_, void* out_, float* tmp, int n_img, int H, int W, int Ho, int Wo, const int* startH,
                       const float* wtH, int KH, const int* startW, const float* wtW, int KW, const int* tile_p0,
                       const float* tile_w, int NP, int accumulate, int bf16, hipStream_t s) {
-    const int rev = (accumulate >> 1) & 1;          // bit 1 of `accumulate`: descending image order (fused kernel only; the result is the same)
-    accumulate &= 1;
+    accumulate &= 1;                                // (bit 1, the explicit "descending" request of this round's first form, is superseded)
+    const int rev = next_sweep_reversed(SWEEP_K7);          // fused kernel: images in descending order on every other launch (uno_common.h)
     typedef unsigned short bf_t;
     const float* in = static_cast<const float*>(in_);
     float* out = static_cast<float*>(out_);

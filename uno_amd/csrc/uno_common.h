@@ -166,6 +166,9 @@ inline int pick_waves_per_image(int n_row_tiles) {
     return best;
 }
 
+__device__ __forceinline__ int sweep_x(int rev) { return rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x; }
+__device__ __forceinline__ int sweep_y(int rev) { return rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y; }
+
 struct Dft2dParams {
     const float* in;        // forward: images (n_img, H, W) f32; inverse: spectra (n_img, 2*m1, m2) c64
     float* out;             // forward: spectra; inverse: images
@@ -187,6 +190,7 @@ struct Dft2dParams {
     // K3-A (dft2d_inv_add_kernel.h): out = transform + separable banded up-sampling of add_src (n_img, add_Hs, add_Ws); host-built operand
     // tables (uno_amd/resample.py): first source row of each 16-row tile, row operator [tile][3][64], first source column of each
     // (column tile, side), column operator [column tile][2][3][64]
+    int rev = 0;            // set by the K1 / K3 launchers (row-tiled forms): workgroups walk the images in descending order
     const float* add_src = nullptr;
     int add_Hs = 0, add_Ws = 0;
     const int* add_p0 = nullptr;
@@ -261,6 +265,14 @@ void set_error(const char* fmt, ...);
 // communication kernels (uno_reserve_cus: RCCL's all-reduce of the previous gradient buckets runs beside the backward pass under data
 // parallelism, and a geometry tuned to "one workgroup per CU on all CUs" would run a second round for the CUs RCCL holds)
 int reserved_cus();
+// Alternating sweep direction (round 6).  A tensor larger than the 256 MB Infinity Cache that one kernel writes (or reads) front to back
+// leaves its TAIL in that cache; the next kernel that streams it front to back again starts with what has been evicted and evicts the
+// tail before reaching it.  So consecutive launches of the streaming kernels walk their work items (images, batch entries, pixel tiles)
+// in opposite directions: every launcher takes the next direction from a per-thread counter.  Only the ORDER changes - workgroup k
+// computes work item G - 1 - k, writes that item's outputs and partial-sum slots - never the result.  uno_sweep_alternation(0) turns
+// it off (every launch front to back).
+int next_sweep_reversed(int family);       // family: SWEEP_* bit (uno_sweep_alternation takes a mask of them; 1 = all)
+enum { SWEEP_K1 = 1, SWEEP_K3 = 2, SWEEP_K7 = 4, SWEEP_K8 = 8, SWEEP_K9 = 16, SWEEP_NORM = 32, SWEEP_PROJ = 64, SWEEP_LIFT = 128 };
 inline int usable_cus(int device_cus) { const int r = reserved_cus(); return device_cus - r >= 8 ? device_cus - r : (device_cus < 8 ? device_cus : 8); }
 
 // RAII timing scope around one kernel launch (no-op unless uno_profile_begin() is active).
