@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNO_SPECTRAL_ABI_VERSION 11
+#define UNO_SPECTRAL_ABI_VERSION 12
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
@@ -285,6 +285,24 @@ int uno_channel_wgrad2_win(const float* gy, const float* x1, const float* x2, in
                            int Co, int rows, int cols, int pitch, long long plane, int act_x, int accumulate, void* stream);
 int uno_gelu_project_backward_win(const float* pre, const float* w, const float* gout, float* gpre, float* gw, float* gb, void* ws,
                                   int B, int C, int rows, int cols, int pitch, long long plane, void* stream);
+/* ABI 12.  The backward pass of the models' last two layers in two launches, the gradient at fc1's output never in memory
+ * (reference darcy_flow_uno2d.py:125-131, `x = self.fc1(x); x = F.gelu(x); x = self.fc2(x)` on `torch.cat([x_c5, x_fc0], dim=1)`;
+ * uno_gelu_project_backward wrote that gradient - 726 MB at 421^2, batch 16 - and the input-gradient and weight-gradient calls each
+ * read it back).  With pre = fc1's output kept by the forward call, w2 = fc2's weights (Co) and gout (B, plane) the gradient at the
+ * model output, gy[b][o][q] = w2[o] gelu'(pre[b][o][q]) gout[b][q] is formed where the two kernels stage their operand:
+ *   g1 (B, C1, plane), g2 (B, Ci - C1, plane) = w^T gy, split at the sources (g1 multiplied by gelu'(x1) when act_in: x1 was read through
+ *     the GELU); gw (Co, Ci) [+]= gy [gelu](x1) | x2 ^T, gb (Co) [+]= sum gy (accumulate_w = 1 adds; gb may be NULL);
+ *     gw2 (Co) = sum gelu(pre) gout, gb2 (1) = sum gout (overwritten; gb2 may be NULL).
+ * Geometry as the *_win calls (rows x cols window of planes `plane` elements apart, row r at r * pitch; elements outside the window are
+ * neither read nor written), or rows = cols = pitch = 0: dense planes of `plane` pixels.  x2 = NULL: one source (C1 is ignored).
+ * uno_project_backward_applies: 1 where both kernels take the shape (float32; Ci a multiple of 128, Co a multiple of 16 below 128, sources
+ * split at a multiple of 64, >= 100 000 pixels in all, a multiple of 4 per plane) - elsewhere use the three separate calls.
+ * ws: uno_project_backward_ws_bytes(B, Ci, Co, pixels per plane = rows * cols) bytes. */
+int uno_project_backward_applies(int B, int C1, int Ci, int Co, int rows, int cols, int pitch, long long plane);
+long long uno_project_backward_ws_bytes(int B, int Ci, int Co, long long P);
+int uno_project_backward(const float* x1, const float* x2, int C1, const float* w, const float* pre, const float* w2, const float* gout,
+                         float* g1, float* g2, float* gw, float* gb, float* gw2, float* gb2, void* ws, int B, int Ci, int Co, int rows,
+                         int cols, int pitch, long long plane, int act_in, int accumulate_w, void* stream);
 /* Everything outside the top-left rows x cols corner of n_planes contiguous (Hp, Wp) float32 planes := 0 (the border a windowed
  * call leaves untouched in a fresh gradient tensor). */
 int uno_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, void* stream);

@@ -1,6 +1,7 @@
 """A/B of the fused `inverse transform + up-sampled addend` kernel (K3-A) in one process on one box:
   (1) kernel level at the two Darcy shapes: K3 alone, K3 + accumulating K7, K3-A
-  (2) the training step with integral_operators.FUSE_UPSAMPLE_ADD on / off (alternating groups)
+  (2) the training step with each of the round's switches on / off (alternating groups): integral_operators.FUSE_UPSAMPLE_ADD,
+      PROJECT_BACKWARD_FUSED, PAIR_BACKWARD_GEMMS, REVERSE_SWEEP_RESAMPLE, uno_sweep_alternation
 python tools/dev/fusetime.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -50,63 +51,28 @@ torch.manual_seed(0)
 model = UNO_9(3, 64, pad=5).to(dev)
 tr = DarcyTrainer(model, lr=1e-3, weight_decay=1e-3)
 a, u = synthetic_darcy_batch(16, 421, 1234, dev)
-res = {True: [], False: []}
-for rnd in range(3):
-    for fuse in (True, False):
-        io.FUSE_UPSAMPLE_ADD = fuse
-        for _ in range(3):
-            tr.step(a, u)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.step(a, u)
-        torch.cuda.synchronize()
-        res[fuse].append((time.perf_counter() - t0) / steps * 1e3)
-        print(f"round {rnd} fuse={fuse}: {res[fuse][-1]:.3f} ms/step loss {float(loss):.6f}", flush=True)
-print("fused", min(res[True]), "two-kernel", min(res[False]))
-io.FUSE_UPSAMPLE_ADD = True
-res = {True: [], False: []}
-for rnd in range(3):
-    for pair in (True, False):
-        io.PAIR_BACKWARD_GEMMS = pair
-        for _ in range(3):
-            tr.step(a, u)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.step(a, u)
-        torch.cuda.synchronize()
-        res[pair].append((time.perf_counter() - t0) / steps * 1e3)
-        print(f"round {rnd} pair_backward_gemms={pair}: {res[pair][-1]:.3f} ms/step", flush=True)
-io.PAIR_BACKWARD_GEMMS = True
-print("paired", min(res[True]), "composite with side stream", min(res[False]))
-res = {True: [], False: []}
-for rnd in range(3):
-    for rv in (True, False):
-        io.REVERSE_SWEEP_RESAMPLE = rv
-        for _ in range(3):
-            tr.step(a, u)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.step(a, u)
-        torch.cuda.synchronize()
-        res[rv].append((time.perf_counter() - t0) / steps * 1e3)
-        print(f"round {rnd} reverse_sweep_resample={rv}: {res[rv][-1]:.3f} ms/step", flush=True)
-io.REVERSE_SWEEP_RESAMPLE = True
-print("reverse sweep before K1", min(res[True]), "after the spectral branch", min(res[False]))
-res = {True: [], False: []}
-for rnd in range(3):
-    for alt in (True, False):
-        _native.sweep_alternation(alt)
-        for _ in range(3):
-            tr.step(a, u)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.step(a, u)
-        torch.cuda.synchronize()
-        res[alt].append((time.perf_counter() - t0) / steps * 1e3)
-        print(f"round {rnd} sweep_alternation={alt}: {res[alt][-1]:.3f} ms/step loss {float(loss):.6f}", flush=True)
-_native.sweep_alternation(True)
-print("alternating sweeps", min(res[True]), "all front to back", min(res[False]))
+
+
+def ab(label, on_label, off_label, setter):
+    res = {True: [], False: []}
+    for rnd in range(3):
+        for on in (True, False):
+            setter(on)
+            for _ in range(3):
+                tr.step(a, u)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = tr.step(a, u)
+            torch.cuda.synchronize()
+            res[on].append((time.perf_counter() - t0) / steps * 1e3)
+            print(f"round {rnd} {label}={on}: {res[on][-1]:.3f} ms/step loss {float(loss):.6f}", flush=True)
+    setter(True)
+    print(on_label, min(res[True]), off_label, min(res[False]), flush=True)
+
+
+ab("fuse", "fused", "two-kernel", lambda v: setattr(io, "FUSE_UPSAMPLE_ADD", v))
+ab("project_backward_fused", "fc1 - GELU - fc2 backward without the stored gradient", "three calls", lambda v: setattr(io, "PROJECT_BACKWARD_FUSED", v))
+ab("pair_backward_gemms", "paired", "composite with side stream", lambda v: setattr(io, "PAIR_BACKWARD_GEMMS", v))
+ab("reverse_sweep_resample", "reverse sweep before K1", "after the spectral branch", lambda v: setattr(io, "REVERSE_SWEEP_RESAMPLE", v))
+ab("sweep_alternation", "alternating sweeps", "all front to back", _native.sweep_alternation)

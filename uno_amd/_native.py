@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuno_spectral.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 _lock = threading.Lock()
@@ -74,6 +74,9 @@ _SIGNATURES = {
     "uno_channel_wgrad_finish": (C.c_int, [_fp, _fp, _fp, _i, _i, C.c_longlong, _i, _fp]),
     "uno_mode_wgrad_acc": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
     "uno_spectral_conv2d_backward_acc": (C.c_int, [_fp] * 8 + [_i] * 11 + [_fp]),
+    "uno_project_backward_applies": (C.c_int, [_i] * 7 + [C.c_longlong]),
+    "uno_project_backward_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
+    "uno_project_backward": (C.c_int, [_fp, _fp, _i] + [_fp] * 11 + [_i] * 6 + [C.c_longlong, _i, _i, _fp]),
     "uno_gelu_project_forward": (C.c_int, [_fp, _fp, _fp, _fp, _i, _i, C.c_longlong, _fp]),
     "uno_gelu_project_bwd_ws_bytes": (C.c_longlong, [_i, _i, C.c_longlong]),
     "uno_gelu_project_backward": (C.c_int, [_fp] * 7 + [_i, _i, C.c_longlong, _fp]),
@@ -983,6 +986,71 @@ def gelu_project_backward(pre, w, gout, need_bias=True, window=None):
                 _stream(pre))
     _check(rc, "uno_gelu_project_backward")
     return gpre, gw, gb
+
+
+def _project_geometry(window, P: int):
+    if window is None:
+        return (0, 0, 0, P), P
+    rows, cols, pitch = _window_args(window, P, False)
+    return (rows, cols, pitch, P), rows * cols
+
+
+def project_backward_applies(B: int, C1: int, Ci: int, Co: int, P: int, window=None) -> bool:
+    """Does uno_project_backward take fc1 (Ci -> Co, sources split at C1; C1 = Ci: one source) on planes of P elements [on that window]?"""
+    if window is not None:
+        rows, cols, pitch = (int(v) for v in window)
+        if rows < 1 or cols % 4 or cols < 260 or pitch < cols or (rows - 1) * pitch + cols > P or rows * cols >= 1 << 24:
+            return False
+        geo = (rows, cols, pitch, P)
+    else:
+        geo = (0, 0, 0, P)
+    return bool(lib().uno_project_backward_applies(B, C1, Ci, Co, *geo))
+
+
+def project_backward(x1, x2, w, pre, w2, gout, act_in: bool = False, need_bias: bool = True, need_bias2: bool = True, window=None,
+                     out_w=None, out_b=None, accumulate: bool = False):
+    """The backward pass of `fc2(gelu(fc1(cat([gelu](x1), x2))))` (uno_project_backward, ABI 12): x1 (B, C1, P), x2 (B, C2, P) or None,
+    w (Co, C1 + C2), pre (B, Co, P) = fc1's output, w2 (Co), gout (B, P) -> g1, g2 (or None), gw (Co, Ci), gb (Co) or None, gw2 (Co),
+    gb2 (1) or None.  The gradient at fc1's output is formed inside the two kernels.  window: see channel_mix2 (elements outside the
+    window of the fresh g1 / g2 are left as they are).  out_w / out_b / accumulate: as channel_wgrad2."""
+    for t, name in ((x1, "x1"), (w, "weight"), (pre, "pre"), (w2, "weight2"), (gout, "grad_output")):
+        _require(t, torch.float32, name)
+    B, C1, P = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _require(x2, torch.float32, "x2")
+        C2 = x2.shape[1]
+        if x2.shape[0] != B or x2.shape[2] != P:
+            raise RuntimeError("uno_amd: the two sources disagree in batch / pixel count")
+    Ci, Co = C1 + C2, pre.shape[1]
+    if tuple(pre.shape) != (B, Co, P) or tuple(gout.shape) != (B, P) or w.numel() != Co * Ci or w2.numel() != Co:
+        raise RuntimeError("uno_amd: project_backward: operand shapes do not match the two layers")
+    geo, Pl = _project_geometry(window, P)
+    L = lib()
+    g1 = torch.empty_like(x1)
+    g2 = torch.empty_like(x2) if x2 is not None else None
+    if out_w is None:
+        accumulate = False
+        gw = torch.empty((Co, Ci), dtype=torch.float32, device=x1.device)
+        gb = torch.empty((Co,), dtype=torch.float32, device=x1.device) if need_bias else None
+    else:
+        gw, gb = out_w, (out_b if need_bias else None)
+        _require(gw, torch.float32, "weight-gradient buffer")
+        if gw.numel() != Co * Ci or (need_bias and (gb is None or gb.numel() != Co)):
+            raise RuntimeError("uno_amd: gradient buffers do not match the layer")
+        if gb is not None:
+            _require(gb, torch.float32, "bias-gradient buffer")
+    gw2 = torch.empty((Co,), dtype=torch.float32, device=x1.device)
+    gb2 = torch.empty((1,), dtype=torch.float32, device=x1.device) if need_bias2 else None
+    null = C.c_void_p(0)
+    with torch.cuda.device(x1.device):
+        ws = torch.empty(max(1, L.uno_project_backward_ws_bytes(B, Ci, Co, Pl)), dtype=torch.uint8, device=x1.device)
+        rc = L.uno_project_backward(_ptr(x1), _ptr(x2) if x2 is not None else null, C1, _ptr(w), _ptr(pre), _ptr(w2), _ptr(gout),
+                                    _ptr(g1), _ptr(g2) if g2 is not None else null, _ptr(gw), _ptr(gb) if gb is not None else null,
+                                    _ptr(gw2), _ptr(gb2) if gb2 is not None else null, _ptr(ws), B, Ci, Co, *geo,
+                                    1 if act_in else 0, 1 if accumulate else 0, _stream(x1))
+    _check(rc, "uno_project_backward")
+    return g1, g2, gw, gb, gw2, gb2
 
 
 def gelu_pad(s, Hp: int, Wp: int):

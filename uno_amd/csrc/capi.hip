@@ -550,6 +550,69 @@ int uno_channel_mix2_win(const float* x1, const float* x2, int C1, const float* 
                              proj_w, proj_b, proj_out, 0, stream, win);
 }
 
+// ---- the backward pass of `fc2(F.gelu(fc1(cat)))` without the gradient at fc1's output in memory (ABI 12)
+static bool project_backward_geometry(const char* who, int rows, int cols, int pitch, long long plane, PixelWindow* win, long long* P) {
+    if (rows == 0 && cols == 0 && pitch == 0) {          // dense planes
+        if (plane < 1) { if (who) set_error("%s: bad plane size %lld", who, plane); return false; }
+        *win = PixelWindow(); *P = plane;
+        return true;
+    }
+    if (rows < 1 || cols < 1 || pitch < cols || plane < 1) { if (who) set_error("%s: bad window rows=%d cols=%d pitch=%d plane=%lld", who, rows, cols, pitch, plane); return false; }
+    win->plane = plane; win->cols = cols; win->pitch = pitch;
+    *P = (long long)rows * cols;
+    if (const char* why = pix_window_error(*win, *P)) { if (who) set_error("%s: %s", who, why); return false; }
+    return true;
+}
+
+int uno_project_backward_applies(int B, int C1, int Ci, int Co, int rows, int cols, int pitch, long long plane) {
+    PixelWindow win; long long P;
+    if (B < 1 || B > 65535 || Ci < 1 || Co < 1 || C1 < 1 || C1 > Ci || !project_backward_geometry(nullptr, rows, cols, pitch, plane, &win, &P)) return 0;
+    // the input gradients: the wide kernel's general form on fc1's Co channels -> Ci gradient channels, destinations split at C1
+    if (Ci % 128 || Co % 16 || Co >= 128 || P < 128 || P % 4 || (C1 < Ci && C1 % 64)) return 0;
+    if ((long long)Ci * plane >= (1LL << 29) || (long long)Ci * Co >= (1LL << 30)) return 0;
+    return channel_wgrad_pb_applies(B, Ci, Co, C1, P) ? 1 : 0;
+}
+
+long long uno_project_backward_ws_bytes(int B, int Ci, int Co, long long P) {
+    if (B < 1 || Ci < 1 || Co < 1 || P < 1) return 0;
+    return 4LL * channel_wgrad_pb_ws_floats(B, Ci, Co, P);
+}
+
+int uno_project_backward(const float* x1, const float* x2, int C1, const float* w, const float* pre, const float* w2, const float* gout,
+                         float* g1, float* g2, float* gw, float* gb, float* gw2, float* gb2, void* ws, int B, int Ci, int Co, int rows,
+                         int cols, int pitch, long long plane, int act_in, int accumulate_w, void* stream) {
+    PixelWindow win; long long P;
+    if (B < 0 || Ci < 1 || Co < 1) { set_error("uno_project_backward: bad sizes B=%d Ci=%d Co=%d", B, Ci, Co); return -1; }
+    if (!project_backward_geometry("uno_project_backward", rows, cols, pitch, plane, &win, &P)) return -1;
+    if (accumulate_w != 0 && accumulate_w != 1) { set_error("uno_project_backward: accumulate_w is 0 or 1"); return -1; }
+    if (!gw || !gw2) { set_error("uno_project_backward: null pointer"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        if ((!accumulate_w && (hipMemsetAsync(gw, 0, sizeof(float) * Co * Ci, s) != hipSuccess || (gb && hipMemsetAsync(gb, 0, sizeof(float) * Co, s) != hipSuccess))) ||
+            hipMemsetAsync(gw2, 0, sizeof(float) * Co, s) != hipSuccess || (gb2 && hipMemsetAsync(gb2, 0, sizeof(float), s) != hipSuccess)) {
+            set_error("uno_project_backward: memset failed");
+            return -5;
+        }
+        return 0;
+    }
+    if (!x2) C1 = Ci;
+    if (!uno_project_backward_applies(B, C1, Ci, Co, rows, cols, pitch, plane)) {
+        set_error("uno_project_backward: shape outside the fused kernels' range (query uno_project_backward_applies)");
+        return -3;
+    }
+    if (!x1 || !w || !pre || !w2 || !gout || !g1 || (x2 && !g2) || !ws) { set_error("uno_project_backward: null pointer"); return -1; }
+    {   // both input gradients from one pass over the pre-activation
+        ChannelMixArgs a{};
+        a.x = pre; a.w = w; a.y = g1; a.y2 = x2 ? g2 : nullptr; a.dgelu_of = act_in ? x1 : nullptr;
+        a.B = B; a.Ci = Co; a.Co = Ci; a.C1 = Co; a.Co1 = x2 ? C1 : Ci; a.P = P; a.transpose_w = 1;
+        a.win = win; a.pb_w2 = w2; a.pb_g = gout;
+        if (int rc = launch_channel_mix2(a, s)) return rc;
+    }
+    WgradProjectedBack pb;
+    pb.w2 = w2; pb.g = gout; pb.gw2 = gw2; pb.gb2 = gb2;
+    return launch_channel_wgrad2(pre, x1, x2, C1, gw, gb, (float*)ws, B, Ci, Co, P, act_in, accumulate_w, 0, s, win, pb);
+}
+
 int uno_clear_border(float* t, long long n_planes, int Hp, int Wp, int rows, int cols, void* stream) {
     if (n_planes < 0 || Hp < 1 || Wp < 1 || rows < 0 || rows > Hp || cols < 0 || cols > Wp) {
         set_error("uno_clear_border: bad sizes planes=%lld (%d, %d) keep (%d, %d)", n_planes, Hp, Wp, rows, cols);

@@ -92,6 +92,12 @@ struct ChannelMixParams {
                             // gradient that must still pass through a GELU: the factor multiplies the completed sum
     const void* dgelu_of;   // nullptr, or (B, Co1, P): the product is multiplied by gelu'(dgelu_of) before bias-free accumulation
                             // (first destination only)
+    // PROJECTED-BACK operand (wide kernel, template PB; round 6): the X operand of the call is the gradient at the output of the layer
+    // BEFORE a one-channel projection, never stored - x[b][k][q] stands for pb_w2[k] gelu'(x[b][k][q]) pb_g[b][q] with x the layer's
+    // pre-activation, pb_w2 (Ci) the projection's weights and pb_g (B, plane) the gradient at the projection's output (reference
+    // darcy_flow_uno2d.py:128-131 backward: `fc2(F.gelu(fc1(x)))`).  The kernel applies gelu' as it stages x, pb_w2 as it stages the
+    // weights and pb_g to the finished product.
+    const float* pb_w2; const float* pb_g;
 };
 
 // where output channel tile o0 of batch entry b lives: row o of the tile = base + (o - ob) * P
@@ -507,7 +513,11 @@ constexpr int CMW_WS = 128 + 16;
 // GEN (round 6): the same tile on a pixel WINDOW (ChannelMixParams::pm), with the two 64-channel halves of the tile going to two
 // destinations (Co1 = 64 mod 128) and the gelu' epilogue on the first destination - the two input gradients of fc1 from ONE staging of
 // the output gradient (the generic kernel ran the 128 outputs as two 64-channel tiles, each staging grad_y again: 808 us for 2.9 GB).
-template <bool BF, bool GEN = false>
+//
+// PB (with GEN): the X operand is the projected-back gradient of ChannelMixParams::pb_w2 / pb_g (gelu' at staging time - the loaded
+// registers wait for the current chunk's MFMAs anyway -, pb_w2 on the weight rows, pb_g on the finished tile).  The last, partial
+// pixel tile runs this path too (pixel quads past the end re-read the last quad and are not stored; P % 4 == 0), not the generic tile.
+template <bool BF, bool GEN = false, bool PB = false>
 __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(ChannelMixParams p) {
     using T = typename IoElem<BF>::type;
     constexpr int PT = CM_PT, XS = PT + 16, NM = PT / 16;
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(Ch
     const int tile = (bx_ & 7) * p.per_xcd + (bx_ >> 3);
     if (tile >= p.ntile) return;
     const int p0 = (tile / p.ncot) * PT, o0 = (tile % p.ncot) * 128, b = sweep_y(p.rev);
-    if (p0 + PT > p.P || (p.Ci & (CM_KC - 1)) != 0) {
+    if (!PB && (p0 + PT > p.P || (p.Ci & (CM_KC - 1)) != 0)) {
         auto sWn = reinterpret_cast<float (*)[CM_KC * CM_WS]>(&sW[0][0]);
         if constexpr (GEN) {
             if (p.dgelu_of) channel_mix_tile<1, PT, false, true, BF>(p, sX, sWn, p0, o0, b); else channel_mix_tile<1, PT, false, false, BF>(p, sX, sWn, p0, o0, b);
@@ -540,13 +550,18 @@ __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(Ch
     const bool tr = p.w_so == 1 && p.w_si != 1;
 
     float4 rx[2], rw[2];
+    float rs = 1.f;                                     // PB: pb_w2 of this thread's weight row
+    // PB: a pixel quad past the end of the (last) tile stands for the last quad of the call
+    const int xq = PB ? run(min(p0 + (tid & 31) * 4, p.P - 4)) : 0;
     auto load_chunk = [&](int k0) {
         const T* cb = k0 < C1 ? xb : xb2;
         const int kb = k0 < C1 ? k0 : k0 - C1;
+        if constexpr (PB) rs = p.pb_w2[k0 + (tid >> 4)];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
-            if constexpr (GEN) rx[u] = io_ld4(cb + (size_t)(kb + (e >> 5)) * PS + run(p0 + (e & 31) * 4));
+            if constexpr (PB) rx[u] = io_ld4(cb + (size_t)(kb + (e >> 5)) * PS + xq);
+            else if constexpr (GEN) rx[u] = io_ld4(cb + (size_t)(kb + (e >> 5)) * PS + run(p0 + (e & 31) * 4));
             else rx[u] = io_ld4(cb + (unsigned)((kb + (e >> 5)) * p.P + p0 + (e & 31) * 4));
             const unsigned woff = tr ? (unsigned)((k0 + (tid >> 4)) * p.w_si + o0 + 64 * u + (tid & 15) * 4)
                                      : (unsigned)((o0 + 64 * u + (tid >> 2)) * p.w_so + k0 + (tid & 3) * 4);
@@ -558,6 +573,10 @@ __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(Ch
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 256 * u;
+            if constexpr (PB) {
+                rx[u] = make_float4(cm_dgelu(rx[u].x), cm_dgelu(rx[u].y), cm_dgelu(rx[u].z), cm_dgelu(rx[u].w));
+                rw[u].x *= rs; rw[u].y *= rs; rw[u].z *= rs; rw[u].w *= rs;
+            }
             *reinterpret_cast<float4*>(&sX[buf][(e >> 5) * XS + (e & 31) * 4]) = rx[u];
             float* d = sW[buf] + (tr ? (tid >> 4) * CMW_WS + 64 * u + (tid & 15) * 4 : (tid & 3) * 4 * CMW_WS + 64 * u + (tid >> 2));
             const int dstep = tr ? 1 : CMW_WS;
@@ -600,7 +619,10 @@ __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(Ch
     const int c4 = (lane & 31) * 4;
     const CmDest<T> dd0 = cm_dest<T>(p, o0, b);         // a 128-channel tile lies in one destination (Co1 % 128 == 0) - GEN: one per half
     T* const aall = (!GEN && p.y_act) ? reinterpret_cast<T*>(p.y_act) + (size_t)b * p.Co * p.P : nullptr;
-    const int poff = GEN ? run(p0 + c4) : p0 + c4;      // this lane's four pixels inside a plane
+    const bool live = !PB || p0 + c4 < p.P;
+    const int poff = PB ? run(min(p0 + c4, p.P - 4)) : GEN ? run(p0 + c4) : p0 + c4;      // this lane's four pixels inside a plane
+    float4 gq = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (PB) gq = io_ld4(p.pb_g + (size_t)b * PS + poff);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int ob = o0 + 64 * g + 16 * wave;
@@ -634,12 +656,13 @@ __global__ __launch_bounds__(256, (GEN ? 3 : 4)) void channel_mix_wide_kernel(Ch
                 const float4 v = *reinterpret_cast<const float4*>(sO + row * OS + c4);
                 const float bv = __shfl(bias_l, 8 * h + row);
                 float t0 = v.x + bv, t1 = v.y + bv, t2 = v.z + bv, t3 = v.w + bv;
+                if constexpr (PB) { t0 = fmaf(v.x, gq.x, bv); t1 = fmaf(v.y, gq.y, bv); t2 = fmaf(v.z, gq.z, bv); t3 = fmaf(v.w, gq.w, bv); }
                 if constexpr (GEN) {
                     // as the generic kernel's epilogue: the PRODUCT is multiplied by gelu'(dgelu_of), then added to the old value
                     if (dall) { t0 *= cm_dgelu(dgv[it].x); t1 *= cm_dgelu(dgv[it].y); t2 *= cm_dgelu(dgv[it].z); t3 *= cm_dgelu(dgv[it].w); }
                 }
                 const float w0 = old[it].x + t0, w1 = old[it].y + t1, w2 = old[it].z + t2, w3 = old[it].w + t3;
-                io_store4(dst[it], w0, w1, w2, w3);
+                if (live) io_store4(dst[it], w0, w1, w2, w3);
                 if (aall) io_store4(aall + aoff[it], cm_gelu(w0), cm_gelu(w1), cm_gelu(w2), cm_gelu(w3));
             }
             __syncthreads();
@@ -1178,6 +1201,13 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     // the general wide form (round 6): windows, the gelu' epilogue on the first destination, destinations split at 64 mod 128 channels
     const bool wide_gen = !wide && !vh && !bf16 && Co % 128 == 0 && P >= PT && !act_in && !act_pad && !a.gmul && !a.proj_w && !a.y_act && a.y &&
                           a.accumulate != 2 && (!two_dst || p.Co1 % 64 == 0) && Ci % CM_KC == 0 && Ci < 128;
+    // the projected-back operand (ChannelMixParams::pb_*) exists in that kernel only
+    p.pb_w2 = a.pb_w2; p.pb_g = a.pb_g;
+    const bool pb = a.pb_w2 != nullptr;
+    if (pb && (!a.pb_g || !wide_gen || !a.transpose_w || a.bias || two_src || P % 4)) {
+        set_error("channel_mix: the projected-back operand goes with a transposed, bias-free float32 call of < 128 input and a multiple of 128 output channels on >= %d pixels (a multiple of 4)", PT);
+        return -3;
+    }
     // K8-S: the wide layers whose f32 MFMA time exceeds their memory time (from 128 input channels on)
 #ifdef UNO_CMS_DEV        // development build only (tools/dev/mkvariant.py): A/B switch, knock-outs, stamp buffer from the environment
     static const bool split_off = getenv("UNO_CM_SPLIT_OFF") != nullptr;
@@ -1233,7 +1263,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
     {
         const double dgc = dgelu_of ? p.Co1 : 0;
         ProfScope prof((split || split64) ? "uno::channel_mix_split_kernel" : (wide || wide_gen) ? "uno::channel_mix_wide_kernel" : "uno::channel_mix_kernel",
-                       (bf16 ? 2.0 : 4.0) * B * (double)P * ((vh == 1 ? a.vh_ci : Ci) + (vh == 2 ? a.vh_ci : 0) + (a.y ? Co : 0) + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.gmul ? Co : 0) + (a.proj_w ? 1 : 0)) + 4.0 * Ci * Co, s);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * ((vh == 1 ? a.vh_ci : Ci) + (vh == 2 ? a.vh_ci : 0) + (a.y ? Co : 0) + (accumulate ? Co : 0) + dgc + (a.y_act ? Co : 0) + (a.gmul ? Co : 0) + (a.proj_w ? 1 : 0) + (pb ? 1 : 0)) + 4.0 * Ci * Co, s);
         if (split64 || split) {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
             const bool trw = p.w_so == 1 && p.w_si != 1;
@@ -1264,6 +1294,7 @@ int launch_channel_mix2(const ChannelMixArgs& a, hipStream_t s) {
         }
         else if (wide && bf16) hipLaunchKernelGGL(channel_mix_wide_kernel<true>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (wide) hipLaunchKernelGGL(channel_mix_wide_kernel<false>, dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
+        else if (pb) hipLaunchKernelGGL((channel_mix_wide_kernel<false, true, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else if (wide_gen) hipLaunchKernelGGL((channel_mix_wide_kernel<false, true>), dim3((unsigned)(8 * p.per_xcd), B), dim3(256), 0, s, p);
         else {
             const dim3 grid((unsigned)(8 * p.per_xcd), B);
@@ -1317,6 +1348,10 @@ struct ChannelWgradParams {
     int act_x;              // scalar kernel: x := gelu(x)
     long long span;         // pixels per split (informational)
     int rev;                // alternating sweep direction (vector and split kernels): pixel splits in descending order
+    // split kernel, template PB (round 6): gy is the PRE-ACTIVATION of the layer and the gradient at its output is never stored -
+    // gy[b][o][q] stands for pb_w2[o] gelu'(gy[b][o][q]) pb_g[b][q] (see ChannelMixParams::pb_w2); the kernel also leaves the partial sums
+    // of the projection's own gradients in part2 (nsplit, Co + 1): sum_q gelu(gy[b][o][q]) pb_g[b][q] per channel, sum_q pb_g[b][q] in slot Co
+    const float* pb_w2; const float* pb_g; float* part2;
 };
 
 template <bool BF>
@@ -1602,8 +1637,11 @@ static int wgrad_split_rows(int Co) { return Co >= 96 ? CWS_T : 64; }      // ou
 
 // BF: bfloat16 activations (exact in ONE piece: gY x X is one product; with the GELU applied on read, gelu(x) is an f32 value again: three
 // pieces of X against the one of gY)
-template <bool ACTX, int MR, bool BF>
+// PB: the gy operand is the projected-back gradient of ChannelWgradParams::pb_* - gelu' (and gelu, for the projection's weight gradient)
+// where the staged quad is split, pb_g as a fifth staged row, pb_w2 on the finished sums.
+template <bool ACTX, int MR, bool BF, bool PB = false>
 __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgradParams p, int npc, int chunks_per_split) {
+    static_assert(!(PB && BF), "the projected-back operand is float32");
     __shared__ __attribute__((aligned(16))) char smem[3 * CWS_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1641,6 +1679,8 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     }
     // two half chunks in flight (register sets 0 / 1): with one, the loads had the 96 MFMAs of ONE half (~0.8 us) to arrive in and the
     // wave waited for them at every store (256 x 256 at 111^2: 173 us at 45 % MFMA-pipe use)
+    u32x4 rqs[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};  // PB: the four pixels' pb_g
+    float bs2[4] = {0.f, 0.f, 0.f, 0.f}, qs = 0.f;                  // PB: sums of gelu(pre) pb_g per staged row, of pb_g
     u32x4 rgs[2][4], rxs[2][4];                                     // RAW loaded pieces: anything computed from them at load time makes the wave wait for its loads at once
     int shs[2] = {0, 0};
     // the zero fill past the row end / past the channel counts is needed only in the last half chunk of a row and in partial weight
@@ -1648,7 +1688,7 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     bool tails[2] = {false, false};
     const bool edge = o0 + TO > p.Co || i0 + CWS_T > p.Ci;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], int& sh_cur, bool& tail) {     // half chunk it: 32 pixels of chunk it >> 1
+    auto load_half = [&](int it, u32x4 (&rg)[4], u32x4 (&rxv)[4], u32x4& rq, int& sh_cur, bool& tail) {     // half chunk it: 32 pixels of chunk it >> 1
         const int idx = it >> 1;
         const int b = idx / npc, pp = (idx - b * npc) * CWV_PK + (it & 1) * CWS_PK;
         const int PS = p.pm.PS;
@@ -1659,6 +1699,10 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         sh_cur = px - pl;
         tail = pp + CWS_PK > p.P;
         const int pc = pix_run(p.pm, pp)(pl);            // offset of the piece inside its channel plane
+        if constexpr (PB) {
+            const __amdgpu_buffer_rsrc_t rq_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pb_g + (size_t)b * PS), 0, PS * 4, 0x00020000);
+            rq = __builtin_amdgcn_raw_buffer_load_b128(rq_, pc * 4, 0, 0);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc[u] + (size_t)b * xcs[u] * PS), 0, xcs[u] * PS * ES, 0x00020000);
@@ -1698,12 +1742,29 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     // 80-byte rows in plain order three of the 16 accesses of every group met another one's banks (PMC, 256 x 256 at 111^2:
     // SQ_LDS_BANK_CONFLICT 19.0 M of 38.0 M LDS cycles); with the swap the 16 four-bank windows of a group are distinct.
     const int wpos = 16 * ((c4 >> 2 >> 1) ^ (((row0 & 15) + 4) >> 3 & 1)) + 8 * ((c4 >> 2) & 1);       // rows row0 + 32 u: the same row0 & 15
-    auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], int sh_cur, bool slow) {
+    auto store_half = [&](const u32x4 (&rg)[4], const u32x4 (&rxv)[4], const u32x4& rq, int sh_cur, bool slow) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PB) { q = shifted(rq, true, sh_cur, slow); qs += (q.x + q.y) + (q.z + q.w); }      // (zero past the row end: the products below vanish there)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + 32 * u;
             if (u < MR) {
-                const float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur, slow);
+                float4 g = shifted(rg[u], o0 + row < p.Co, sh_cur, slow);
+                if constexpr (PB) {
+                    // (the four products are summed like the bias gradient's below, not fma-chained into bs2[u]: the chained form was packed by
+                    // the SLP vectoriser into v_pk_fma_f32 on the (bs2[0], bs2[1]) pair and - in the ACTX = false, MR = 2 instantiation only -
+                    // lanes 48-63 of a wave lost one half chunk's terms of bs2[0] in about every fourth launch; -fno-slp-vectorize and this
+                    // form are both clean over hundreds of launches: tests/test_hip_project_backward.py repeats the launch)
+                    auto back = [&](float v, float qv, float& t) {
+                        const float cdf = 0.5f * (1.f + uno_erf(v * 0.70710678118654752440f));
+                        const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+                        t = v * cdf * qv;
+                        return fmaf(v, pdf, cdf) * qv;
+                    };
+                    float t0, t1, t2, t3;
+                    g = make_float4(back(g.x, q.x, t0), back(g.y, q.y, t1), back(g.z, q.z, t2), back(g.w, q.w, t3));
+                    bs2[u] += (t0 + t1) + (t2 + t3);
+                }
                 if constexpr (NPG == 1) put1(smem + row * CWS_RS + wpos, g); else put3(smem + row * CWS_RS + wpos, g);
                 bs[u] += (g.x + g.y) + (g.z + g.w);
             }
@@ -1770,9 +1831,9 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
 
     const int it_begin = 2 * c_begin, it_end = 2 * c_end;          // an even number of half chunks
     if (it_begin < it_end) {
-        load_half(it_begin, rgs[0], rxs[0], shs[0], tails[0]);
+        load_half(it_begin, rgs[0], rxs[0], rqs[0], shs[0], tails[0]);
         __builtin_amdgcn_sched_barrier(0);          // set 0's loads strictly before set 1's: the loop's vmcnt waits are derived from BOTH orders
-        load_half(it_begin + 1, rgs[1], rxs[1], shs[1], tails[1]);
+        load_half(it_begin + 1, rgs[1], rxs[1], rqs[1], shs[1], tails[1]);
         __builtin_amdgcn_sched_barrier(0);
     }
     // development build (-DUNO_CWS_STAMPS, tools/dev/mkvariant.py): cycles per phase of every wave of one workgroup, summed over its
@@ -1787,12 +1848,12 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
     for (int it = it_begin; it < it_end; it += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (tails[h] || edge) store_half(rgs[h], rxs[h], shs[h], true);          // (waits for this half chunk's loads only: vmcnt counts the other set's)
-            else store_half(rgs[h], rxs[h], shs[h], false);
+            if (tails[h] || edge) store_half(rgs[h], rxs[h], rqs[h], shs[h], true);          // (waits for this half chunk's loads only: vmcnt counts the other set's)
+            else store_half(rgs[h], rxs[h], rqs[h], shs[h], false);
             CWS_STAMP(tS);
             __syncthreads();
             CWS_STAMP(tB1);
-            load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], shs[h], tails[h]);
+            load_half(min(it + h + 2, it_end - 1), rgs[h], rxs[h], rqs[h], shs[h], tails[h]);
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __builtin_amdgcn_sched_barrier(0);
@@ -1815,23 +1876,50 @@ __global__ __launch_bounds__(256, 2) void channel_wgrad_split_kernel(ChannelWgra
         for (int r = 0; r < 4; ++r) {
             const int o = o0 + 16 * MR * wa + 16 * m + 4 * kk + r;
             if (o < p.Co) {
+                const float sc = PB ? p.pb_w2[o] : 1.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int i = i0 + 64 * wb + 16 * t + r16;
-                    if (i < p.Ci) part[(size_t)o * (p.Ci + 1) + i] = acc[m][t][r];
+                    if (i < p.Ci) part[(size_t)o * (p.Ci + 1) + i] = PB ? acc[m][t][r] * sc : acc[m][t][r];
                 }
             }
         }
     if (i0 == 0) {          // bias gradient: the 8 threads that share a row hold its partial sums
+        float* part2 = PB ? p.part2 + (size_t)split * (p.Co + 1) : nullptr;
 #pragma unroll
         for (int u = 0; u < MR; ++u) {
             float v = bs[u];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
             const int o = o0 + row0 + 32 * u;
-            if ((tid & 7) == 0 && o < p.Co) part[(size_t)o * (p.Ci + 1) + p.Ci] = v;
+            if constexpr (PB) {
+                float v2 = bs2[u];
+                v2 += __shfl_xor(v2, 1); v2 += __shfl_xor(v2, 2); v2 += __shfl_xor(v2, 4);
+                if ((tid & 7) == 0 && o < p.Co) { part[(size_t)o * (p.Ci + 1) + p.Ci] = v * p.pb_w2[o]; part2[o] = v2; }
+            } else if ((tid & 7) == 0 && o < p.Co) part[(size_t)o * (p.Ci + 1) + p.Ci] = v;
+        }
+        if constexpr (PB) {
+            float v = qs;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            if (tid == 0 && o0 == 0) part2[p.Co] = v;
         }
     }
 }
+
+// second stage of the projection's own gradients (PB): one wave per entry, lanes stride over the splits, fixed order
+__global__ __launch_bounds__(256) void channel_wgrad_pb_reduce_kernel(const float* __restrict__ part2, float* __restrict__ gw2, float* __restrict__ gb2,
+                                                                      int Co, int nsplit) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e > Co) return;
+    float v = 0.f;
+    for (int k = lane; k < nsplit; k += 64) v += part2[(size_t)k * (Co + 1) + e];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) {
+        if (e < Co) gw2[e] = v;
+        else if (gb2) gb2[0] = v;
+    }
+}
+
 
 // Weight gradient with few input channels (CI <= 4): a thread owns four pixels at a time and accumulates its 16 output channels x
 // (CI + 1) sums in registers over the pixels of its split (the + 1: the bias gradient); fixed-order reduction inside the workgroup
@@ -1969,6 +2057,7 @@ int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w
     p.gy = gy; p.x = vh_x; p.x2 = nullptr; p.C1 = Ci; p.part = ws; p.B = B; p.Ci = Ci; p.Co = Co; p.P = (int)P; p.act_x = 1;
     p.pm = pix_map(PixelWindow(), P);
     p.vh_x = vh_x; p.vh_w = vh_w; p.vh_b = vh_b; p.vh_ci = vh_ci;
+    p.pb_w2 = nullptr; p.pb_g = nullptr; p.part2 = nullptr;
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
     p.span = (long long)cps * pk;
@@ -1984,8 +2073,20 @@ int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w
     return 0;
 }
 
+bool channel_wgrad_pb_applies(int B, int Ci, int Co, int C1, long long P) {
+    int nsplit, npc, cps, pk;
+    if (B < 1 || P < 64) return false;
+    wgrad_plan(B, Ci, Co, P, &nsplit, &npc, &cps, &pk);
+    return wgrad_split_shape(B, Ci, Co, P) && pk == CWV_PK && Ci > 4 && (C1 == Ci || C1 % 32 == 0);
+}
+long long channel_wgrad_pb_ws_floats(int B, int Ci, int Co, long long P) {
+    int nsplit;
+    const long long n = channel_wgrad_ws_floats(B, Ci, Co, P, &nsplit);
+    return n + (long long)nsplit * (Co + 1);
+}
+
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
-                          long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win) {
+                          long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win, const WgradProjectedBack& pb) {
     const bool windowed = win.cols != 0;
     if (const char* why = pix_window_error(win, P)) { set_error("channel_wgrad: %s", why); return -2; }
     const long long PSl = windowed ? win.plane : P;
@@ -2003,6 +2104,11 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
     p.vh_x = nullptr; p.vh_w = nullptr; p.vh_b = nullptr; p.vh_ci = 0;
     int npc, cps, pk;
     wgrad_plan(B, Ci, Co, P, &p.nsplit, &npc, &cps, &pk);
+    p.pb_w2 = pb.w2; p.pb_g = pb.g; p.part2 = ws + (size_t)p.nsplit * Co * (Ci + 1);
+    if (pb.w2 && (!pb.g || !pb.gw2 || bf16 || accumulate == 3 || !channel_wgrad_pb_applies(B, Ci, Co, x2 ? C1 : Ci, P))) {
+        set_error("channel_wgrad: the projected-back gradient goes with the float32 split kernel (both stages)");
+        return -3;
+    }
     if (windowed && (pk != CWV_PK || (Ci <= 4 && !act_x))) { set_error("channel_wgrad: the pixel window goes with the vector / split kernels (>= 64 pixels, > 4 input channels)"); return -2; }
     p.span = (long long)cps * pk;
     p.rev = next_sweep_reversed(SWEEP_K9);
@@ -2027,7 +2133,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
     const bool split_form = wgrad_split_shape(B, Ci, Co, P) && pk == CWV_PK && (!x2 || C1 % 32 == 0);
     {
         ProfScope prof(split_form ? "uno::channel_wgrad_split_kernel" : pk == CWV_PK ? "uno::channel_wgrad_vec_kernel" : "uno::channel_wgrad_kernel",
-                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co), s);
+                       (bf16 ? 2.0 : 4.0) * B * (double)P * (Ci + Co + (pb.w2 ? 1 : 0)), s);
         const dim3 gv(8 * tiles * ((p.nsplit + 7) / 8));
         if (split_form) {
             const int to = wgrad_split_rows(Co);
@@ -2035,8 +2141,14 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
             const dim3 gs(8 * tiles_s * ((p.nsplit + 7) / 8));
 #define UNO_CWS(A_, M_) do { if (bf16) hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, true>), gs, dim3(256), 0, s, p, npc, cps); \
                              else hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, false>), gs, dim3(256), 0, s, p, npc, cps); } while (0)
-            if (to == CWS_T) { if (act_x) UNO_CWS(true, 4); else UNO_CWS(false, 4); }
+#define UNO_CWS_PB(A_, M_) hipLaunchKernelGGL((channel_wgrad_split_kernel<A_, M_, false, true>), gs, dim3(256), 0, s, p, npc, cps)
+            if (pb.w2) {
+                if (to == CWS_T) { if (act_x) UNO_CWS_PB(true, 4); else UNO_CWS_PB(false, 4); }
+                else { if (act_x) UNO_CWS_PB(true, 2); else UNO_CWS_PB(false, 2); }
+            }
+            else if (to == CWS_T) { if (act_x) UNO_CWS(true, 4); else UNO_CWS(false, 4); }
             else { if (act_x) UNO_CWS(true, 2); else UNO_CWS(false, 2); }
+#undef UNO_CWS_PB
 #undef UNO_CWS
         } else if (pk == CWV_PK && Ci <= 32) {           // (one tile of input channels: the narrow form)
             if (act_x) { if (bf16) hipLaunchKernelGGL((channel_wgrad_vec_kernel<true, true, 2>), gv, dim3(256), 0, s, p, npc, cps);
@@ -2058,6 +2170,7 @@ int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1,
     const int n = Co * (Ci + 1);
     if (accumulate != 3)        // 3: the partial sums stay in ws; launch_channel_wgrad_finish sums any number of such blocks later
         hipLaunchKernelGGL(channel_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, ws, gw, gb, Co, Ci, p.nsplit, accumulate);
+    if (pb.w2) hipLaunchKernelGGL(channel_wgrad_pb_reduce_kernel, dim3((Co + 1 + 3) / 4), dim3(256), 0, s, p.part2, pb.gw2, pb.gb2, Co, p.nsplit);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("channel_wgrad launch: %s", hipGetErrorString(e)); return -5; }
     return 0;

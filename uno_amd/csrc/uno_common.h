@@ -316,6 +316,7 @@ struct ChannelMixArgs {
     void* ws = nullptr; size_t ws_bytes = 0;                       // optional scratch (uno_scratch_provide): 6 Ci Co bytes let K8-S run on pre-split weights
     const float* vh_x = nullptr; const float* vh_w = nullptr; const float* vh_b = nullptr; int vh_ci = 0, vh_mode = 0;   // virtual operand (channel_mix.hip): 1 = the input, 2 = dgelu_of
     const void* gmul = nullptr;                                     // y = gelu'(product + bias) * gmul, gmul on the padded planes described below
+    const float* pb_w2 = nullptr; const float* pb_g = nullptr;      // the X operand is pb_w2[k] gelu'(x[b][k][q]) pb_g[b][q] (channel_mix.hip, wide kernel)
     int act_cols = 0, act_pitch = 0; long long act_plane = 0;       // y_act on padded planes (generic kernel): the P = H * act_cols dense
                                                                     // pixels land in the top-left corner of act_plane / act_pitch rows
 };
@@ -346,8 +347,14 @@ int launch_instnorm_bwd(const void* x, const void* gy, const float* gamma, const
 long long channel_wgrad_ws_floats(int B, int Ci, int Co, long long P, int* nsplit_out);
 int launch_channel_wgrad(const void* gy, const void* x, float* gw, float* gb, float* ws, int B, int Ci, int Co, long long P,
                          int act_x, int bf16, hipStream_t s);
+// pb (channel_mix.hip, ChannelWgradParams::pb_*): gy is the layer's pre-activation and stands for w2[o] gelu'(gy) g; the projection's own
+// gradients go to gw2 (Co) / gb2 (1, may be null); ws then holds channel_wgrad_pb_ws_floats() floats
+struct WgradProjectedBack { const float* w2 = nullptr; const float* g = nullptr; float* gw2 = nullptr; float* gb2 = nullptr; };
+bool channel_wgrad_pb_applies(int B, int Ci, int Co, int C1, long long P);
+long long channel_wgrad_pb_ws_floats(int B, int Ci, int Co, long long P);
 int launch_channel_wgrad2(const void* gy, const void* x, const void* x2, int C1, float* gw, float* gb, float* ws, int B, int Ci, int Co,
-                          long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win = PixelWindow());
+                          long long P, int act_x, int accumulate, int bf16, hipStream_t s, const PixelWindow& win = PixelWindow(),
+                          const WgradProjectedBack& pb = WgradProjectedBack());
 // weight gradient with the X operand virtual (see ChannelMixParams: gelu of it is taken when act_x): Ci <= 32 virtual channels
 int launch_channel_wgrad_vh(const void* gy, const float* vh_x, const float* vh_w, const float* vh_b, int vh_ci, float* gw, float* gb, float* ws,
                             int B, int Ci, int Co, long long P, int act_x, hipStream_t s, int accumulate = 0);

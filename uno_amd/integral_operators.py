@@ -555,6 +555,10 @@ PAIR_BACKWARD_GEMMS = True
 # that K1 and walks the images in descending order, so that what it read last - the part of the tensor still in the 256 MB Infinity
 # Cache - is what K1, walking up, reads first.  False: after the spectral branch, ascending (A/B switch).
 REVERSE_SWEEP_RESAMPLE = True
+# The backward pass of `fc2(F.gelu(fc1(cat)))` (reference darcy_flow_uno2d.py:125-131).  True: uno_project_backward where it applies - the
+# gradient at fc1's output is formed inside the input-gradient and weight-gradient kernels from fc1's saved output; False: written by
+# uno_gelu_project_backward and read back by the two (A/B switch; tools/dev/fusetime.py).
+PROJECT_BACKWARD_FUSED = True
 
 
 def _fused_addend(t, H, W, m1, m2, adjoint):
@@ -869,8 +873,51 @@ class _ChannelMixCatProjectFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gout):
         x1, x2, w, y, w2 = ctx.saved_tensors
+        mode = _ChannelMixCatProjectFn._fused_mode(ctx, x1, x2, y)
+        if mode:
+            return _ChannelMixCatProjectFn._backward_fused(ctx, x1, x2, w, y, w2, _plain(gout), mode)
         gy, gw2, gb2 = _native.gelu_project_backward(y, w2, _plain(gout), need_bias=ctx.has_b2, window=ctx.window)
         g1, g2, gw, gb = _ChannelMixCatFn._backward(ctx, x1, x2, w, gy)
+        return g1, g2, gw, gb, gw2, gb2, None, None, None, None
+
+    @staticmethod
+    def _fused_mode(ctx, x1, x2, y):
+        """0: the three-call backward pass; 1: uno_project_backward, both input gradients returned; 2: the same with x2's gradient handed
+        to the owner of the joined gradient as a second tensor (the lift's backward kernel adds the two as it reads them)."""
+        if not PROJECT_BACKWARD_FUSED or x1.dtype != torch.float32 or not all(ctx.needs_input_grad[:3]) or not ctx.needs_input_grad[4]:
+            return 0
+        B, C1, P = x1.shape
+        if not _native.project_backward_applies(B, C1, C1 + x2.shape[1], y.shape[1], P, ctx.window):
+            return 0
+        if ctx.defer is None:
+            return 1
+        if ctx.window is not None and ctx.defer.accepts_extra and not ctx.defer.extra:
+            return 2
+        return 0
+
+    @staticmethod
+    def _backward_fused(ctx, x1, x2, w, y, w2, gout, mode):
+        window = ctx.window
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        Co, Ci = y.shape[1], x1.shape[1] + x2.shape[1]
+        tg = None
+        if ctx.leaves is not None and (ctx.leaves[1] is not None) == need_b:
+            tg = _grad_targets([ctx.leaves[0]] + ([ctx.leaves[1]] if need_b else []))        # committed: the call below writes them
+        g1, g2, gw, gb, gw2, gb2 = _native.project_backward(
+            x1, x2, w, y, w2, gout, act_in=ctx.gelu_first, need_bias=need_b, need_bias2=ctx.has_b2 and ctx.needs_input_grad[5], window=window,
+            out_w=None if tg is None else tg[0][0], out_b=None if tg is None or not need_b else tg[1][0],
+            accumulate=False if tg is None else tg[0][1])
+        if tg is not None:
+            gw = None if tg[0][2] is None else tg[0][2].view(Co, Ci)
+            gb = tg[1][2] if need_b else None
+        if window is not None:
+            rows, cols, pitch = window
+            _native.clear_border(g1.view(g1.shape[0], g1.shape[1], -1, pitch), rows, cols)
+            if mode == 2:
+                ctx.defer.extra.append((g2, window))        # (no border to clear: the lift's backward kernel reads the domain only)
+                g2 = None
+            else:
+                _native.clear_border(g2.view(g2.shape[0], g2.shape[1], -1, pitch), rows, cols)
         return g1, g2, gw, gb, gw2, gb2, None, None, None, None
 
 
