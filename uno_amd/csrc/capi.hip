@@ -46,6 +46,19 @@ static void fill_twiddles(int N, std::vector<float2>& t) {
     for (int n = 0; n < N; ++n) t[n] = twiddle_value(n, N);
 }
 
+void* upload_table(const void* host, size_t bytes) {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) return nullptr;
+    void* d = nullptr;
+    hipStream_t st = nullptr;
+    bool ok = hipMalloc(&d, bytes) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+              hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (st) (void)hipStreamDestroy(st);
+    if (!ok && d) { (void)hipFree(d); d = nullptr; }
+    (void)hipThreadExchangeStreamCaptureMode(&mode);          // back to the caller's mode
+    return d;
+}
+
 const float2* twiddle_table(int N) {
     static std::mutex mu;
     static std::map<std::pair<int, int>, float2*> cache;
@@ -56,9 +69,8 @@ const float2* twiddle_table(int N) {
     if (it != cache.end()) return it->second;
     std::vector<float2> host;
     fill_twiddles(N, host);
-    float2* d = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(float2) * N) != hipSuccess ||
-        hipMemcpy(d, host.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess) {
+    float2* d = static_cast<float2*>(upload_table(host.data(), sizeof(float2) * N));
+    if (!d) {
         set_error("twiddle table allocation for N=%d failed: %s", N, hipGetErrorString(hipGetLastError()));
         return nullptr;
     }

@@ -131,8 +131,8 @@ static const void* b16_table(int kind, int W, int m2, int n_ent, F value) {
                 host[((size_t)e * 2 + 0) * 512 + ln * 8 + j] = hi;
                 host[((size_t)e * 2 + 1) * 512 + ln * 8 + j] = lo;
             }
-    void* d = nullptr;
-    if (hipMalloc(&d, host.size() * 2) != hipSuccess || hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+    void* d = upload_table(host.data(), host.size() * 2);
+    if (!d) {
         set_error("bf16 twiddle operand table (W = %d) allocation failed: %s", W, hipGetErrorString(hipGetLastError()));
         return nullptr;
     }

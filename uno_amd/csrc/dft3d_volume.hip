@@ -83,9 +83,8 @@ static const float* vol_table(const VolTabKey& key_in, const std::function<void(
     if (it != cache.end()) return it->second;
     std::vector<float> host;
     build(host);
-    float* d = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&d), host.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    float* d = static_cast<float*>(upload_table(host.data(), host.size() * sizeof(float)));
+    if (!d) {
         set_error("dft3d volume operand table: allocation of %zu bytes failed: %s", host.size() * sizeof(float), hipGetErrorString(hipGetLastError()));
         return nullptr;
     }

@@ -245,6 +245,11 @@ struct Vol3dParams {
 };
 
 const float2* twiddle_table(int N);      // device-resident, cached per (device, N); nullptr on failure
+// A fresh device allocation holding `bytes` bytes of host data (the cached operand tables), or nullptr.  Safe while a stream of this
+// thread - or, under the global capture mode PyTorch uses, of any thread - is being captured into a hipGraph: the allocation and the
+// copy are made under the relaxed capture mode on a stream of their own and are complete on return, so a shape first seen inside a
+// capture gets its tables without ending the capture (the launches that use them are captured as usual).
+void* upload_table(const void* host, size_t bytes);
 float2 twiddle_value(long long n, int N);      // host: (cos, sin)(2 pi n / N) as the tables hold it (f32 from f64, exact at multiples of pi / 2)
 
 // Raise a kernel's dynamic-LDS limit to the largest size any launch of it (on this device) has asked for so far.  The driver call is
