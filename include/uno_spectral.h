@@ -29,6 +29,11 @@ extern "C" {
 
 /* ABI version of the loaded library (== UNO_SPECTRAL_ABI_VERSION it was built with). */
 int uno_abi_version(void);
+/* ABI 12 (no reference counterpart).  `bytes` bytes of host data in a fresh device allocation of the current device that is never
+ * freed (an operand table a binding caches per shape), complete on return; NULL on failure.  Unlike a plain hipMalloc + hipMemcpy it
+ * may be called while a stream is being captured into a hipGraph - the library's own tables are built this way, so a shape that
+ * first appears inside a capture does not end the capture. */
+void* uno_upload_table(const void* host, long long bytes);
 
 /* Message of the last failing call on this thread ("" if none). */
 const char* uno_last_error(void);

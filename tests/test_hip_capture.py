@@ -43,3 +43,22 @@ def test_first_seen_bf16_grid_inside_a_capture():
     layer = enable_mixed_precision(SpectralConv2d_Uno(8, 8, 58, 62, 6, 6).cuda())
     x = torch.randn(2, 8, 58, 62).cuda().bfloat16()
     _capture_then_compare(layer, x, lambda m, v: m(v))
+
+
+def test_first_seen_block_with_resampling_inside_a_capture():
+    """the Python-side operand tables (banded interpolation operators, the fused up-sampling operands) are uploaded through
+    uno_upload_table while the stream is capturing"""
+    from uno_amd.integral_operators import OperatorBlock_2D
+    torch.manual_seed(0)
+    down = OperatorBlock_2D(4, 6, 37, 43, 5, 5).cuda()             # 73 x 83 -> 37 x 43
+    up = OperatorBlock_2D(6, 4, 73, 83, 5, 5).cuda()               # ... and back
+    x = torch.randn(2, 4, 73, 83).cuda()
+    _capture_then_compare((down, up), x, lambda m, v: m[1](m[0](v, 37, 43), 73, 83))
+
+
+def test_first_seen_3d_block_inside_a_capture():
+    from uno_amd.integral_operators import OperatorBlock_3D
+    torch.manual_seed(0)
+    blk = OperatorBlock_3D(4, 4, 18, 22, 12, 3, 3, 3).cuda()       # 26 x 30 x 16 -> 18 x 22 x 12 (kept-index tables of the 3-D resampling)
+    x = torch.randn(2, 4, 26, 30, 16).cuda()
+    _capture_then_compare(blk, x, lambda m, v: m(v, 18, 22, 12))

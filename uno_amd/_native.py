@@ -74,6 +74,7 @@ _SIGNATURES = {
     "uno_channel_wgrad_finish": (C.c_int, [_fp, _fp, _fp, _i, _i, C.c_longlong, _i, _fp]),
     "uno_mode_wgrad_acc": (C.c_int, [_fp, _fp, C.POINTER(_fp)] + [_i] * 6 + [_fp]),
     "uno_spectral_conv2d_backward_acc": (C.c_int, [_fp] * 8 + [_i] * 11 + [_fp]),
+    "uno_upload_table": (C.c_void_p, [_fp, C.c_longlong]),
     "uno_project_backward_applies": (C.c_int, [_i] * 7 + [C.c_longlong]),
     "uno_project_backward_ws_bytes": (C.c_longlong, [_i, _i, _i, C.c_longlong]),
     "uno_project_backward": (C.c_int, [_fp, _fp, _i] + [_fp] * 11 + [_i] * 6 + [C.c_longlong, _i, _i, _fp]),
@@ -986,6 +987,30 @@ def gelu_project_backward(pre, w, gout, need_bias=True, window=None):
                 _stream(pre))
     _check(rc, "uno_gelu_project_backward")
     return gpre, gw, gb
+
+
+class _DeviceView:
+    """a library-owned device allocation seen through the CUDA array interface"""
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def table_to_device(t: torch.Tensor, device) -> torch.Tensor:
+    """A host-built operand table on the device.  Outside a graph capture: `t.to(device)`.  While the current stream is being captured
+    (a shape first seen inside a capture) the copy torch would make is not permitted: the table then goes through uno_upload_table
+    (an allocation of the library's own, uploaded under the relaxed capture mode, never freed - the callers cache per shape)."""
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_current_stream_capturing():
+        return t.to(device)
+    t = t.contiguous()
+    if t.numel() == 0:
+        return torch.empty(t.shape, dtype=t.dtype, device=device)
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8", torch.float64: "<f8"}[t.dtype]
+    with torch.cuda.device(device):
+        ptr = lib().uno_upload_table(C.c_void_p(t.data_ptr()), t.numel() * t.element_size())
+    if not ptr:
+        _check(-5, "uno_upload_table")
+    return torch.as_tensor(_DeviceView(ptr, t.shape, typestr), device=device)
 
 
 def _project_geometry(window, P: int):

@@ -264,6 +264,13 @@ extern "C" {
 
 int uno_abi_version(void) { return UNO_SPECTRAL_ABI_VERSION; }
 
+void* uno_upload_table(const void* host, long long bytes) {
+    if (!host || bytes < 1) { set_error("uno_upload_table: bad arguments"); return nullptr; }
+    void* d = upload_table(host, (size_t)bytes);
+    if (!d) set_error("uno_upload_table: allocation / upload of %lld bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+    return d;
+}
+
 int uno_sweep_alternation(int enable) {
     return __atomic_exchange_n(&uno::g_sweep_alternation, enable == 1 ? 255 : (enable & 255), __ATOMIC_RELAXED);      // (1: all families; other values: a mask, development)
 }

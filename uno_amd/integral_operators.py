@@ -1760,8 +1760,8 @@ def _resample3d_plan(din, dout, device):
               and 1 <= m3 <= 16 and 16 <= din[1] * din[2] <= 1792 and 16 <= dout[1] * dout[2] <= 1792
               and din[2] <= 64 and dout[2] <= 64)
         if ok:
-            t1 = torch.tensor(k1, dtype=torch.int32, device=device)
-            t2 = torch.tensor(k2, dtype=torch.int32, device=device)
+            t1 = _native.table_to_device(torch.tensor(k1, dtype=torch.int32), device)
+            t2 = _native.table_to_device(torch.tensor(k2, dtype=torch.int32), device)
             plan = (t1, t2, m3)
         _RESAMPLE3D_TABLES[key] = plan
     return _RESAMPLE3D_TABLES[key]

@@ -85,7 +85,8 @@ def _tables(n_in: int, n_out: int, device_str: str, mode: str = "bicubic_aa"):
     for M in (R, R.t().contiguous()):
         s, w, _ = _band(M)
         p0, tw = _row_tiles(M)
-        out.append(((s.to(dev), w.contiguous().to(dev)), (p0.to(dev), tw.contiguous().to(dev))))
+        up = lambda t: _native.table_to_device(t.contiguous(), dev)          # (also inside a graph capture)
+        out.append(((up(s), up(w)), (up(p0), up(tw))))
     return tuple(out)
 
 
@@ -156,7 +157,7 @@ def upsample_add_tables(Hs: int, Ws: int, H: int, W: int, device_str: str, adjoi
     if ops is None:
         return None
     dev = torch.device(device_str)
-    return tuple(t.to(dev) for t in ops)
+    return tuple(_native.table_to_device(t, dev) for t in ops)
 
 
 def resample_forward(x: torch.Tensor, Ho: int, Wo: int, out: torch.Tensor | None = None, reverse: bool = False) -> torch.Tensor:
