@@ -100,8 +100,12 @@ __global__ __launch_bounds__(256) void resample_cols_generic_kernel(const TI* __
 constexpr int RS_TR = 16;
 // phase-1 prefetch depth (k-steps of four input rows in flight per lane).  Measured 1 .. 8 on one box (tools/rsbench.py, six Darcy
 // shapes + the accumulating calls): 2 is best, 3 (rounds 2-3) 2-4 % behind, 6 and 8 are 5-25 % SLOWER - more loads in flight per
-// wave hurt this kernel (Darcy step 13.95 -> 13.84 ms with 2)
-constexpr int RS_PD = 2;
+// wave hurt this kernel (Darcy step 13.95 -> 13.84 ms with 2).  Re-measured at the end of round 6 under the 64-register cap (3 and 4 still fit
+// it: 61 / 64 registers, 8 waves per SIMD): 446 -> 223 270 / 269 / 302 us, the accumulating 223 -> 446 389 / 435 / 491 us for 2 / 3 / 4.
+#ifndef UNO_RS_PD
+#define UNO_RS_PD 2
+#endif
+constexpr int RS_PD = UNO_RS_PD;
 
 // MF: phase 1 on v_mfma_f32_16x16x4_f32.  The dense 16 x NP row operator of the tile is the A operand (one LDS read per k-step
 // from a table in operand layout), a lane's 16-byte piece of an input row is the B operand of FOUR column tiles (tile e = columns 4 n + e of the
