@@ -19,7 +19,7 @@ for (B, C1, C2, Co, act, rows) in ((3, 128, 0, 64, 0, 130), (3, 64, 64, 64, 0, 1
     L = _native.lib()
     nws = L.uno_project_backward_ws_bytes(B, Ci, Co, rows * cols)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    for run in range(12):
+    for run in range(int(os.environ.get("PB_RUNS", "12"))):
         g1, g2 = torch.zeros(B, C1, P).cuda(), torch.zeros(B, max(C2, 1), P).cuda()
         gw, gb, gw2, gb2 = torch.empty(Co, Ci).cuda(), torch.empty(Co).cuda(), torch.empty(Co).cuda(), torch.empty(1).cuda()
         ws = torch.full((nws // 4,), 0.0).cuda()
