@@ -209,6 +209,28 @@ def test_headline_optimiser_full_size():
         assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-9
 
 
+def test_headline_gradients_are_bit_reproducible_launch_to_launch():
+    """forward + loss + backward of the headline model at batch 16, eight times from the same weights and batch: every parameter gradient
+    bit for bit (fixed-order reductions everywhere; round 6 found one packed accumulation that lost terms in one launch of four - a
+    failure mode an oracle comparison at 1e-4 can miss)"""
+    from uno_amd.harness import UNO_9, lp_loss_rel_sum, synthetic_darcy_batch
+    torch.manual_seed(0)
+    model = UNO_9(3, WIDTH, pad=5).to(dev())
+    a, u = synthetic_darcy_batch(B, S, 99, dev())
+    ref = None
+    for it in range(8):
+        for prm in model.parameters():
+            prm.grad = None
+        out = model(a)
+        lp_loss_rel_sum(out.reshape(B, -1), u.reshape(B, -1)).backward()
+        grads = [prm.grad.clone() for prm in model.parameters()]
+        if ref is None:
+            ref = grads
+        else:
+            for k, (g0, g1) in enumerate(zip(ref, grads)):
+                assert torch.equal(torch.view_as_real(g0) if g0.is_complex() else g0, torch.view_as_real(g1) if g1.is_complex() else g1), (it, k)
+
+
 def test_zz_every_kernel_of_the_timed_step_was_oracle_checked_at_bench_geometry():
     """The kernels of the headline step - taken from the library's launch records of two steps of the workload run HERE, at the
     bench geometry (not from a committed profile) - all ran inside a full-size oracle comparison of this module."""
